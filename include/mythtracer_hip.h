@@ -1,0 +1,208 @@
+/* mythtracer_hip.h — C ABI of libmythtracer_hip.so (MI355X / gfx950).
+ *
+ * The reference (gynvael/MythTracer, /root/reference/VerStarting) has no FFI or
+ * plugin layer: its seam is the C++ class raytracer::MythTracer
+ * (mythtracer.h:55-66).  This C ABI sits directly UNDER that seam.  Each entry
+ * point below names the reference code it replaces; the host-side C++ facade
+ * (mythtracer_amd/host, same class/field names as the reference) and any other
+ * language binding call these and nothing else.  See INTEGRATION.md.
+ *
+ * Conventions: plain C, POD only, no exceptions.  Functions returning int
+ * return MT_OK (0) or a negative MT_ERR_*; mt_last_error() gives the text for
+ * the calling thread.  All pointers in mt_scene_desc / mt_render_* arguments
+ * are HOST pointers unless the name starts with d_ (device pointer on the
+ * scene's GPU).  One render may be in flight per mt_scene at a time.  The
+ * library never falls back to a CPU path: without a usable HIP device every
+ * call fails with MT_ERR_HIP.
+ */
+#ifndef MYTHTRACER_HIP_H_
+#define MYTHTRACER_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MT_ABI_VERSION 1
+
+enum {
+  MT_OK = 0,
+  MT_ERR_ARG = -1,         /* bad argument / inconsistent description */
+  MT_ERR_HIP = -2,         /* HIP runtime error (text in mt_last_error) */
+  MT_ERR_UNSUPPORTED = -3, /* e.g. octree deeper than MT_MAX_TREE_DEPTH */
+  MT_ERR_NOMEM = -4,
+  MT_ERR_INTERNAL = -5     /* a device-side loop bound tripped: kernel logic error */
+};
+
+/* Deepest octree (root = depth 1) the traversal stack can hold.  The
+ * reference has no limit (octtree.cc:52-135 recurses while a node holds >= 16
+ * primitives); we refuse deeper trees instead of overflowing. */
+#define MT_MAX_TREE_DEPTH 64
+/* Deepest reflection/refraction recursion (reference: compile-time
+ * MAX_RECURSION_LEVEL = 5, mythtracer.h:11). */
+#define MT_MAX_RECURSION 16
+
+/* raytracer::Material (material.h:12-48), tex = index into textures or -1. */
+typedef struct mt_material {
+  double ambient[3], diffuse[3], specular[3];
+  double specular_exp, reflectance, transparency;
+  double transmission_filter[3];
+  double refraction_index;
+  int32_t tex;
+  int32_t reserved;
+} mt_material;
+
+/* raytracer::Light (light.h:8-14). */
+typedef struct mt_light {
+  double position[3], ambient[3], diffuse[3], specular[3];
+} mt_light;
+
+enum { MT_TEX_RGB8 = 0, MT_TEX_F64 = 1 };
+
+/* raytracer::Texture (texture.h:13-23).  RGB8: 3 bytes per texel, colour =
+ * byte / 255.0 (exactly what texture.cc:100-104 stores); F64: 3 doubles. */
+typedef struct mt_texture {
+  int32_t width, height;
+  int32_t format;
+  int32_t reserved;
+  const void *texels;
+} mt_texture;
+
+/* Camera::Sensor after Sensor::Reset (camera.cc:27-63) plus the camera
+ * origin: what Sensor::GetRay (camera.cc:65-69) needs.  Computed on the host
+ * (sin/cos stay glibc's). */
+typedef struct mt_sensor {
+  double origin[3];
+  double start_point[3];
+  double delta_scanline[3];
+  double delta_pixel[3];
+} mt_sensor;
+
+/* PerPixelDebugInfo (mythtracer.h:13-16). */
+typedef struct mt_debug_px {
+  int32_t line_no; /* -1 = no hit */
+  int32_t reserved;
+  double point[3];
+} mt_debug_px;
+
+/* Work counters of one call (sums over all pixels / rays). */
+typedef struct mt_stats {
+  uint64_t rays_primary;   /* OctTree::IntersectRay from level-0 TraceRayWorker */
+  uint64_t rays_secondary; /* ... from level>0 (reflection / refraction) */
+  uint64_t rays_shadow;    /* ... from the shadow loop (mythtracer.cc:94-156) */
+  uint64_t box_tests;      /* Node::NodeIntersectRay evaluations (root included) */
+  uint64_t node_visits;    /* Node::PrimitiveIntersectRay evaluations */
+  uint64_t tri_tests;      /* Triangle::IntersectRay evaluations */
+  uint64_t mt_tests;       /* ... that passed the AABB pre-filter */
+  uint64_t shaded_hits;    /* TraceRayWorker calls that hit a primitive */
+  uint64_t wave_node_steps;/* wave-level node scans executed (GPU only) */
+  uint64_t wave_tri_steps; /* wave-level triangle slab evaluations (GPU only) */
+  double kernel_ms;        /* device time of the kernel(s), HIP events */
+  double total_ms;         /* wall time of the call incl. copies */
+} mt_stats;
+
+/* Flattened scene: what Scene{tree, materials, textures} (scene.h:9-15) holds
+ * after OctTree::Finalize (octtree.cc:16-24).
+ *
+ * Nodes are in breadth-first order, root = node 0; the 8 children of a split
+ * node are the consecutive nodes first_child .. first_child+7 in the
+ * reference's child order (octtree.cc:61-100: bit0 = x high, bit1 = z high,
+ * bit2 = y high); first_child = 0 means "no children".
+ *
+ * Triangles are in NODE-STREAM order: node after node (same order as the node
+ * array), inside a node in the order of Node::primitives.  prim_begin/count
+ * index into that stream.  tri_id gives the AddPrimitive order index. */
+typedef struct mt_scene_desc {
+  uint32_t struct_size; /* sizeof(mt_scene_desc) */
+  uint32_t abi_version; /* MT_ABI_VERSION */
+  int32_t device;       /* HIP device ordinal */
+  int32_t n_nodes, n_tris, n_materials, n_textures;
+  int32_t tree_depth;   /* root = 1 */
+  const double *node_aabb;        /* n_nodes x 6: min xyz, max xyz */
+  const double *node_center;      /* n_nodes x 3 (Node::CalcCenter) */
+  const int32_t *node_first_child;
+  const int32_t *node_prim_begin;
+  const int32_t *node_prim_count;
+  const double *tri_vertex;       /* n_tris x 9 */
+  const double *tri_normal;       /* n_tris x 9 */
+  const double *tri_uvw;          /* n_tris x 9 */
+  const double *tri_aabb;         /* n_tris x 6 (Triangle::cached_aabb) */
+  const int32_t *tri_material;    /* -1 = mtl == nullptr */
+  const int32_t *tri_line_no;     /* Primitive::debug_line_no */
+  const int32_t *tri_id;
+  const mt_material *materials;
+  const mt_texture *textures;
+} mt_scene_desc;
+
+typedef struct mt_scene mt_scene;
+
+const char *mt_last_error(void);
+int mt_abi_version(void);
+/* Number of visible HIP devices (<0 on error). */
+int mt_device_count(void);
+
+/* Uploads the flattened scene to HBM.  Replaces: the in-memory Scene the
+ * reference keeps after LoadObj + Finalize (mythtracer.cc:247-256,281-285). */
+mt_scene *mt_scene_create(const mt_scene_desc *desc);
+void mt_scene_destroy(mt_scene *scene);
+
+/* scene.lights (scene.h:14) — read at render time (mythtracer.cc:78), mutated
+ * by the caller between frames (main_local.cc:79-110). */
+int mt_scene_set_lights(mt_scene *scene, const mt_light *lights, int n);
+
+/* MythTracer::RayTrace(WorkChunk*) (mythtracer.cc:280-312): renders the chunk
+ * [chunk_x, chunk_x+chunk_w) x [chunk_y, chunk_y+chunk_h) of an image_w x
+ * image_h image.  out_rgb: chunk_w*chunk_h*3 bytes, chunk-local row-major
+ * RGB8 (WorkChunk::output_bitmap).  out_debug (nullable): chunk_w*chunk_h
+ * entries (WorkChunk::output_debug).  max_depth = MAX_RECURSION_LEVEL (5). */
+int mt_render_chunk(mt_scene *scene, const mt_sensor *sensor, int image_w,
+                    int image_h, int chunk_x, int chunk_y, int chunk_w,
+                    int chunk_h, int max_depth, uint8_t *out_rgb,
+                    mt_debug_px *out_debug, mt_stats *stats);
+
+/* Same, asynchronous, output left in HBM: d_rgb / d_debug are device pointers
+ * on the scene's GPU, stream is a hipStream_t (NULL = default stream).  Work
+ * counters accumulate in the scene and are fetched with mt_scene_read_stats
+ * after the stream has been synchronised. */
+int mt_render_chunk_device(mt_scene *scene, const mt_sensor *sensor,
+                           int image_w, int image_h, int chunk_x, int chunk_y,
+                           int chunk_w, int chunk_h, int max_depth,
+                           void *d_rgb, void *d_debug, void *stream);
+
+/* The master's work split (main_net_master.cc:195-221 GenerateWork, 128x128
+ * WorkChunks) for a multi-GPU frame: the image is cut into tile_w x tile_h
+ * tiles in row-major order; this call renders tiles first_tile,
+ * first_tile+tile_stride, ... (n_tiles of them) in ONE launch.  Tile number j
+ * of the call is written to d_rgb + j*tile_w*tile_h*3 as a chunk-local
+ * row-major bitmap of its actual (edge-clipped) width x height, i.e. the PXLS
+ * payload of that WorkChunk.  mt_blit_tiles_device is BlitWorkChunk
+ * (main_net_master.cc:223-236) for such a buffer. */
+int mt_render_tiles_device(mt_scene *scene, const mt_sensor *sensor,
+                           int image_w, int image_h, int tile_w, int tile_h,
+                           int first_tile, int tile_stride, int n_tiles,
+                           int max_depth, void *d_rgb, void *stream);
+int mt_blit_tiles_device(mt_scene *scene, int image_w, int image_h,
+                         int tile_w, int tile_h, int first_tile,
+                         int tile_stride, int n_tiles, const void *d_tiles,
+                         void *d_image, void *stream);
+
+/* Fetches and clears the accumulated counters (kernel_ms/total_ms = 0). */
+int mt_scene_read_stats(mt_scene *scene, mt_stats *stats);
+
+/* OctTree::IntersectRay (octtree.cc:26-40) for a batch: rays = n x 6 doubles
+ * (origin, direction).  Outputs (each nullable): tri = stream-order triangle
+ * index or -1, line_no, t, point (3 per ray; untouched = NaN on miss). */
+int mt_intersect_rays(mt_scene *scene, int n, const double *rays,
+                      int32_t *tri, int32_t *line_no, double *t,
+                      double *point, mt_stats *stats);
+
+/* Test hook: 0 = automatic (default), 1 = always use the exact
+ * std::min/std::max comparison path, 2 = allow min/max instructions but not
+ * the octant-uniform path.  Results are identical in every mode. */
+int mt_scene_set_traversal_mode(mt_scene *scene, int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYTHTRACER_HIP_H_ */

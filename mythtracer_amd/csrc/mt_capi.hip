@@ -1,0 +1,603 @@
+// mt_capi.hip — host side of libmythtracer_hip.so: the C ABI declared in
+// include/mythtracer_hip.h.  Validates the flattened scene (so that the kernel
+// can index it without bounds checks), keeps it resident in HBM and launches
+// the kernels of mt_render.hip.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unistd.h>
+#include <vector>
+
+// Single translation unit: the kernels are compiled together with their host
+// side so that no relocatable device code is needed.
+#include "mt_render.hip"
+
+using namespace mt;
+
+namespace {
+
+thread_local char g_err[1024] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e_ = (expr);                                                             \
+    if (e_ != hipSuccess)                                                               \
+      return fail(MT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),    \
+                  __FILE__, __LINE__);                                                  \
+  } while (0)
+
+constexpr size_t kLdsBudget = 160 * 1024;
+
+}  // namespace
+
+struct mt_scene {
+  int device = 0;
+  DevScene dev{};
+  std::vector<void *> allocs;  // everything to hipFree
+  mt_light *d_lights = nullptr;
+  int lights_cap = 0;
+  unsigned long long *d_counters = nullptr;
+  unsigned int *d_work = nullptr;
+  double *d_frames = nullptr;
+  size_t frames_bytes = 0;
+  uint8_t *d_rgb = nullptr;
+  size_t rgb_bytes = 0;
+  mt_debug_px *d_debug = nullptr;
+  size_t debug_bytes = 0;
+  int waves_per_block = 4;
+  size_t lds_bytes = 0;
+  int grid_blocks = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int n_cu = 0;
+  bool stats_enabled = true;
+  unsigned long long *hb_host = nullptr;  // MT_DEBUG_HEARTBEAT: pinned, device-visible
+};
+
+namespace {
+
+template <typename T>
+int upload(mt_scene *s, const T *host, size_t count, const T **dev_out) {
+  T *d = nullptr;
+  const size_t bytes = (count ? count : 1) * sizeof(T);
+  HIP_TRY(hipMalloc((void **)&d, bytes));
+  s->allocs.push_back(d);
+  if (count) HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+  *dev_out = d;
+  return MT_OK;
+}
+
+bool finite3(const double *p, size_t n) {
+  for (size_t i = 0; i < n; i++) {
+    if (!std::isfinite(p[i])) return false;
+  }
+  return true;
+}
+
+// Launch geometry: as many 4-wave blocks as the CU's LDS/VGPR budget admits.
+int configure_launch(mt_scene *s) {
+  const size_t per_wave = wave_stack_bytes(s->dev.tree_depth);
+  int wpb = 4;
+  while (wpb > 1 && per_wave * wpb > kLdsBudget) wpb >>= 1;
+  if (per_wave * wpb > kLdsBudget) {
+    return fail(MT_ERR_UNSUPPORTED, "octree depth %d needs %zu B of LDS per wave (> %zu)",
+                s->dev.tree_depth, per_wave, kLdsBudget);
+  }
+  s->waves_per_block = wpb;
+  s->lds_bytes = per_wave * wpb;
+  HIP_TRY(hipFuncSetAttribute((const void *)render_kernel<true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+  HIP_TRY(hipFuncSetAttribute((const void *)render_kernel<false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+  HIP_TRY(hipFuncSetAttribute((const void *)intersect_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+  int per_cu = 0;
+  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_kernel<true>,
+                                                       wpb * 64, s->lds_bytes));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu * wpb > 16) per_cu = 16 / wpb;  // more waves only add divergence state
+  s->grid_blocks = s->n_cu * per_cu;
+  return MT_OK;
+}
+
+int ensure_bytes(void **ptr, size_t *have, size_t need) {
+  if (*have >= need && *ptr) return MT_OK;
+  if (*ptr) HIP_TRY(hipFree(*ptr));
+  *ptr = nullptr;
+  *have = 0;
+  HIP_TRY(hipMalloc(ptr, need ? need : 1));
+  *have = need;
+  return MT_OK;
+}
+
+int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h, int rx, int ry,
+                  int rw, int rh, int tile_w, int tile_h, int first_tile, int tile_stride,
+                  int n_tiles, int max_depth, uint8_t *d_rgb, mt_debug_px *d_debug,
+                  hipStream_t stream) {
+  if (max_depth < 0 || max_depth > MT_MAX_RECURSION) {
+    return fail(MT_ERR_ARG, "max_depth %d outside [0, %d]", max_depth, MT_MAX_RECURSION);
+  }
+  RenderParams P{};
+  P.sensor = *sensor;
+  P.image_w = image_w;
+  P.image_h = image_h;
+  P.region_x = rx; P.region_y = ry; P.region_w = rw; P.region_h = rh;
+  P.tile_w = tile_w; P.tile_h = tile_h;
+  P.tiles_x = (rw + tile_w - 1) / tile_w;
+  P.first_tile = first_tile; P.tile_stride = tile_stride; P.n_tiles = n_tiles;
+  P.blocks_x = (tile_w + 7) / 8;
+  P.blocks_y = (tile_h + 7) / 8;
+  P.max_depth = max_depth;
+  const unsigned long long items = (unsigned long long)n_tiles * P.blocks_x * P.blocks_y;
+  if (items > 0xfffffff0ull) return fail(MT_ERR_ARG, "too many work items (%llu)", items);
+  P.n_items = (unsigned)items;
+  P.out_rgb = d_rgb;
+  P.out_debug = d_debug;
+  P.counters = s->d_counters;
+  P.work_counter = s->d_work;
+  const size_t waves = (size_t)s->grid_blocks * s->waves_per_block;
+  const size_t fbytes = waves * (size_t)(max_depth > 0 ? max_depth : 1) * kFrameSlots * 64 * sizeof(double);
+  {
+    int rc = ensure_bytes((void **)&s->d_frames, &s->frames_bytes, fbytes);
+    if (rc != MT_OK) return rc;
+  }
+  P.frames = s->d_frames;
+  HIP_TRY(hipMemsetAsync(s->d_work, 0, sizeof(unsigned), stream));
+  if (P.n_items == 0) return MT_OK;
+  const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
+  if (s->stats_enabled) {
+    hipLaunchKernelGGL(render_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
+  } else {
+    hipLaunchKernelGGL(render_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
+  }
+  HIP_TRY(hipGetLastError());
+  if (s->hb_host) {
+    // Debug mode: watch the launch from the host and report where it is stuck.
+    const auto t0 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(stream) == hipErrorNotReady) {
+      const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (sec > 10.0) {
+        fprintf(stderr, "[mt heartbeat] kernel still running after %.0f s\n", sec);
+        int hist[8] = {0};
+        const int nw = s->grid_blocks * s->waves_per_block;
+        for (int w = 0; w < nw; w++) {
+          const unsigned long long *h = s->hb_host + (size_t)w * 4;
+          hist[h[0] & 7]++;
+          if ((h[0] & 255) != 5 && (h[0] & 255) != 0) {
+            fprintf(stderr, "  wave %d: stage %llu arg %llu exec@fetch %llx alive %llx exec %llx\n", w, h[0] & 255,
+                    h[0] >> 8, h[1], h[2], h[3]);
+          }
+        }
+        fprintf(stderr, "  stage histogram:");
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %d:%d", i, hist[i]);
+        fprintf(stderr, "\n");
+        fflush(stderr);
+        _exit(86);
+      }
+    }
+  }
+  return MT_OK;
+}
+
+int check_status(const unsigned long long *c) {
+  if (c[ST_STATUS] == DEV_OK) return MT_OK;
+  return fail(MT_ERR_INTERNAL, "device loop bound tripped (code %llu): kernel logic error", c[ST_STATUS]);
+}
+
+void fill_stats(const unsigned long long *c, mt_stats *st) {
+  st->rays_primary = c[ST_RAYS_PRIMARY];
+  st->rays_secondary = c[ST_RAYS_SECONDARY];
+  st->rays_shadow = c[ST_RAYS_SHADOW];
+  st->box_tests = c[ST_BOX_TESTS];
+  st->node_visits = c[ST_NODE_VISITS];
+  st->tri_tests = c[ST_TRI_TESTS];
+  st->mt_tests = c[ST_MT_TESTS];
+  st->shaded_hits = c[ST_SHADED_HITS];
+  st->wave_node_steps = c[ST_WAVE_NODE_STEPS];
+  st->wave_tri_steps = c[ST_WAVE_TRI_STEPS];
+}
+
+int check_image_args(const mt_scene *s, const mt_sensor *sensor, int image_w, int image_h) {
+  if (!s) return fail(MT_ERR_ARG, "scene is NULL");
+  if (!sensor) return fail(MT_ERR_ARG, "sensor is NULL");
+  if (image_w <= 0 || image_h <= 0 || image_w > 100000 || image_h > 100000) {
+    return fail(MT_ERR_ARG, "image size %dx%d out of range", image_w, image_h);
+  }
+  return MT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mt_last_error(void) { return g_err; }
+int mt_abi_version(void) { return MT_ABI_VERSION; }
+
+int mt_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) return fail(MT_ERR_HIP, "hipGetDeviceCount: %s", hipGetErrorString(e));
+  return n;
+}
+
+void mt_scene_destroy(mt_scene *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  for (void *p : s->allocs) (void)hipFree(p);
+  if (s->d_frames) (void)hipFree(s->d_frames);
+  if (s->d_rgb) (void)hipFree(s->d_rgb);
+  if (s->d_debug) (void)hipFree(s->d_debug);
+  if (s->d_lights) (void)hipFree(s->d_lights);
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  delete s;
+}
+
+static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
+  if (d->struct_size != sizeof(mt_scene_desc) || d->abi_version != MT_ABI_VERSION) {
+    return fail(MT_ERR_ARG, "mt_scene_desc size/version mismatch (%u/%u, want %zu/%d)",
+                d->struct_size, d->abi_version, sizeof(mt_scene_desc), MT_ABI_VERSION);
+  }
+  if (d->n_nodes < 1 || d->n_tris < 0 || d->n_materials < 0 || d->n_textures < 0) {
+    return fail(MT_ERR_ARG, "negative or empty counts");
+  }
+  if (!d->node_aabb || !d->node_center || !d->node_first_child || !d->node_prim_begin ||
+      !d->node_prim_count) {
+    return fail(MT_ERR_ARG, "node arrays missing");
+  }
+  if (d->n_tris > 0 && (!d->tri_vertex || !d->tri_normal || !d->tri_uvw || !d->tri_aabb ||
+                        !d->tri_material || !d->tri_line_no)) {
+    return fail(MT_ERR_ARG, "triangle arrays missing");
+  }
+  if ((d->n_materials > 0 && !d->materials) || (d->n_textures > 0 && !d->textures)) {
+    return fail(MT_ERR_ARG, "material/texture arrays missing");
+  }
+  // --- structural validation: the kernel indexes all of this unchecked.
+  const int nn = d->n_nodes;
+  std::vector<int> depth_of((size_t)nn, 0);
+  depth_of[0] = 1;
+  int max_depth = 1;
+  long long prim_total = 0;
+  for (int i = 0; i < nn; i++) {
+    const int fc = d->node_first_child[i];
+    const int pb = d->node_prim_begin[i], pc = d->node_prim_count[i];
+    if (pb < 0 || pc < 0 || (long long)pb + pc > d->n_tris) {
+      return fail(MT_ERR_ARG, "node %d: primitive range [%d,+%d) outside 0..%d", i, pb, pc, d->n_tris);
+    }
+    prim_total += pc;
+    if (depth_of[i] == 0) return fail(MT_ERR_ARG, "node %d is not reachable in BFS order", i);
+    if (fc != 0) {
+      if (fc <= i || (long long)fc + 8 > nn) {
+        return fail(MT_ERR_ARG, "node %d: first_child %d invalid (n_nodes %d)", i, fc, nn);
+      }
+      for (int k = 0; k < 8; k++) {
+        if (depth_of[fc + k] != 0) return fail(MT_ERR_ARG, "node %d has two parents", fc + k);
+        depth_of[fc + k] = depth_of[i] + 1;
+      }
+      if (depth_of[i] + 1 > max_depth) max_depth = depth_of[i] + 1;
+    }
+  }
+  if (prim_total != d->n_tris) {
+    return fail(MT_ERR_ARG, "nodes reference %lld primitives, scene has %d", prim_total, d->n_tris);
+  }
+  if (max_depth > MT_MAX_TREE_DEPTH) {
+    return fail(MT_ERR_UNSUPPORTED, "octree depth %d exceeds MT_MAX_TREE_DEPTH %d", max_depth,
+                MT_MAX_TREE_DEPTH);
+  }
+  for (int i = 0; i < d->n_tris; i++) {
+    const int m = d->tri_material[i];
+    if (m < -1 || m >= d->n_materials) {
+      return fail(MT_ERR_ARG, "triangle %d: material index %d outside -1..%d", i, m, d->n_materials - 1);
+    }
+  }
+  for (int i = 0; i < d->n_materials; i++) {
+    const int t = d->materials[i].tex;
+    if (t < -1 || t >= d->n_textures) {
+      return fail(MT_ERR_ARG, "material %d: texture index %d outside -1..%d", i, t, d->n_textures - 1);
+    }
+  }
+  for (int i = 0; i < d->n_textures; i++) {
+    const mt_texture &t = d->textures[i];
+    if (t.width <= 0 || t.height <= 0 || t.width > 30000 || t.height > 30000 || !t.texels ||
+        (t.format != MT_TEX_RGB8 && t.format != MT_TEX_F64)) {
+      return fail(MT_ERR_ARG, "texture %d: bad size/format", i);
+    }
+  }
+  // --- is the min/max-instruction path admissible for this scene?
+  bool regular = finite3(d->node_aabb, (size_t)nn * 6) && finite3(d->node_center, (size_t)nn * 3) &&
+                 finite3(d->tri_aabb, (size_t)d->n_tris * 6);
+  for (int i = 0; regular && i < nn; i++) {
+    for (int k = 0; k < 3; k++) {
+      const double lo = d->node_aabb[i * 6 + k], hi = d->node_aabb[i * 6 + 3 + k];
+      const double c = d->node_center[i * 3 + k];
+      if (!(lo <= hi)) regular = false;
+      if (d->node_first_child[i] != 0 && !(lo <= c && c <= hi)) regular = false;
+    }
+  }
+  for (int i = 0; regular && i < d->n_tris; i++) {
+    for (int k = 0; k < 3; k++) {
+      if (!(d->tri_aabb[i * 6 + k] <= d->tri_aabb[i * 6 + 3 + k])) regular = false;
+    }
+  }
+
+  HIP_TRY(hipSetDevice(d->device));
+  s->device = d->device;
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, d->device));
+  s->n_cu = prop.multiProcessorCount;
+
+  std::vector<NodeRec> recs((size_t)nn);
+  for (int i = 0; i < nn; i++) {
+    NodeRec &r = recs[i];
+    memset(&r, 0, sizeof r);
+    for (int k = 0; k < 3; k++) {
+      r.lo[k] = d->node_aabb[i * 6 + k];
+      r.hi[k] = d->node_aabb[i * 6 + 3 + k];
+      r.c[k] = d->node_center[i * 3 + k];
+    }
+    r.first_child = d->node_first_child[i];
+    r.prim_begin = d->node_prim_begin[i];
+    r.prim_count = d->node_prim_count[i];
+  }
+  int rc;
+  if ((rc = upload(s, recs.data(), recs.size(), &s->dev.nodes)) != MT_OK) return rc;
+  const size_t nt = (size_t)d->n_tris;
+  {
+    // The scan loop looks two boxes ahead (mt_trace.h): pad the stream.
+    std::vector<double> boxes(nt * 6 + 4 * 6, 0.0);
+    if (nt) memcpy(boxes.data(), d->tri_aabb, nt * 6 * sizeof(double));
+    if ((rc = upload(s, boxes.data(), boxes.size(), &s->dev.tri_aabb)) != MT_OK) return rc;
+  }
+  if ((rc = upload(s, d->tri_vertex, nt * 9, &s->dev.tri_vertex)) != MT_OK) return rc;
+  if ((rc = upload(s, d->tri_normal, nt * 9, &s->dev.tri_normal)) != MT_OK) return rc;
+  if ((rc = upload(s, d->tri_uvw, nt * 9, &s->dev.tri_uvw)) != MT_OK) return rc;
+  if ((rc = upload(s, d->tri_material, nt, &s->dev.tri_mtl)) != MT_OK) return rc;
+  if ((rc = upload(s, d->tri_line_no, nt, &s->dev.tri_line)) != MT_OK) return rc;
+  if ((rc = upload(s, d->materials, (size_t)d->n_materials, &s->dev.mtls)) != MT_OK) return rc;
+  std::vector<DevTexture> texs((size_t)d->n_textures);
+  for (int i = 0; i < d->n_textures; i++) {
+    const mt_texture &t = d->textures[i];
+    const size_t texel_bytes = (t.format == MT_TEX_RGB8 ? 3 : 24);
+    const uint8_t *dev_texels = nullptr;
+    if ((rc = upload(s, (const uint8_t *)t.texels, (size_t)t.width * t.height * texel_bytes,
+                     &dev_texels)) != MT_OK) {
+      return rc;
+    }
+    texs[i] = DevTexture{dev_texels, t.width, t.height, t.format, 0};
+  }
+  if ((rc = upload(s, texs.data(), texs.size(), &s->dev.texs)) != MT_OK) return rc;
+  s->dev.n_tris = d->n_tris;
+  s->dev.n_nodes = nn;
+  s->dev.tree_depth = max_depth;
+  s->dev.force_mode = 0;
+  s->dev.scene_regular = regular ? 1 : 0;
+  s->dev.n_lights = 0;
+  s->dev.lights = nullptr;
+  HIP_TRY(hipMalloc((void **)&s->d_counters, ST_COUNT * sizeof(unsigned long long)));
+  s->allocs.push_back(s->d_counters);
+  HIP_TRY(hipMemset(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc((void **)&s->d_work, 64));
+  s->allocs.push_back(s->d_work);
+  HIP_TRY(hipEventCreate(&s->ev0));
+  HIP_TRY(hipEventCreate(&s->ev1));
+  if ((rc = mt_scene_set_lights(s, nullptr, 0)) != MT_OK) return rc;
+  s->dev.hb = nullptr;
+  if (getenv("MT_DEBUG_HEARTBEAT")) {
+    HIP_TRY(hipHostMalloc((void **)&s->hb_host, 65536 * sizeof(unsigned long long), hipHostMallocMapped));
+    memset(s->hb_host, 0, 65536 * sizeof(unsigned long long));
+    void *dp = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dp, s->hb_host, 0));
+    s->dev.hb = (volatile unsigned long long *)dp;
+  }
+  return configure_launch(s);
+}
+
+mt_scene *mt_scene_create(const mt_scene_desc *d) {
+  if (!d) {
+    fail(MT_ERR_ARG, "desc is NULL");
+    return nullptr;
+  }
+  mt_scene *s = new mt_scene();
+  if (scene_create_impl(s, d) != MT_OK) {
+    mt_scene_destroy(s);
+    return nullptr;
+  }
+  return s;
+}
+
+int mt_scene_set_lights(mt_scene *s, const mt_light *lights, int n) {
+  if (!s || n < 0 || (n > 0 && !lights)) return fail(MT_ERR_ARG, "bad lights argument");
+  HIP_TRY(hipSetDevice(s->device));
+  if (n > s->lights_cap || !s->d_lights) {
+    if (s->d_lights) HIP_TRY(hipFree(s->d_lights));
+    s->d_lights = nullptr;
+    const int cap = n > 8 ? n : 8;
+    HIP_TRY(hipMalloc((void **)&s->d_lights, (size_t)cap * sizeof(mt_light)));
+    s->lights_cap = cap;
+  }
+  if (n) HIP_TRY(hipMemcpy(s->d_lights, lights, (size_t)n * sizeof(mt_light), hipMemcpyHostToDevice));
+  s->dev.lights = s->d_lights;
+  s->dev.n_lights = n;
+  return MT_OK;
+}
+
+int mt_scene_set_traversal_mode(mt_scene *s, int mode) {
+  if (!s || mode < 0 || mode > 2) return fail(MT_ERR_ARG, "mode must be 0, 1 or 2");
+  s->dev.force_mode = mode;
+  return MT_OK;
+}
+
+int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
+  if (!s || !st) return fail(MT_ERR_ARG, "NULL argument");
+  HIP_TRY(hipSetDevice(s->device));
+  unsigned long long c[ST_COUNT];
+  HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemset(s->d_counters, 0, sizeof c));
+  memset(st, 0, sizeof *st);
+  fill_stats(c, st);
+  return check_status(c);
+}
+
+int mt_render_chunk_device(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h,
+                           int chunk_x, int chunk_y, int chunk_w, int chunk_h, int max_depth,
+                           void *d_rgb, void *d_debug, void *stream) {
+  int rc = check_image_args(s, sensor, image_w, image_h);
+  if (rc != MT_OK) return rc;
+  // WorkChunk::DeserializeInput's constraints, mythtracer.cc:358-371
+  if (chunk_x < 0 || chunk_y < 0 || chunk_w <= 0 || chunk_h <= 0 ||
+      (long long)chunk_x + chunk_w > image_w || (long long)chunk_y + chunk_h > image_h) {
+    return fail(MT_ERR_ARG, "chunk %d,%d %dx%d outside image %dx%d", chunk_x, chunk_y, chunk_w,
+                chunk_h, image_w, image_h);
+  }
+  if (!d_rgb) return fail(MT_ERR_ARG, "d_rgb is NULL");
+  HIP_TRY(hipSetDevice(s->device));
+  return launch_render(s, sensor, image_w, image_h, chunk_x, chunk_y, chunk_w, chunk_h, chunk_w,
+                       chunk_h, 0, 1, 1, max_depth, (uint8_t *)d_rgb, (mt_debug_px *)d_debug,
+                       (hipStream_t)stream);
+}
+
+int mt_render_tiles_device(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h,
+                           int tile_w, int tile_h, int first_tile, int tile_stride, int n_tiles,
+                           int max_depth, void *d_rgb, void *stream) {
+  int rc = check_image_args(s, sensor, image_w, image_h);
+  if (rc != MT_OK) return rc;
+  if (tile_w <= 0 || tile_h <= 0 || first_tile < 0 || tile_stride <= 0 || n_tiles < 0) {
+    return fail(MT_ERR_ARG, "bad tiling arguments");
+  }
+  const long long tiles_total =
+      (long long)((image_w + tile_w - 1) / tile_w) * ((image_h + tile_h - 1) / tile_h);
+  if (n_tiles > 0 && (long long)first_tile + (long long)(n_tiles - 1) * tile_stride >= tiles_total) {
+    return fail(MT_ERR_ARG, "tile selection exceeds the %lld tiles of the image", tiles_total);
+  }
+  if (!d_rgb && n_tiles > 0) return fail(MT_ERR_ARG, "d_rgb is NULL");
+  HIP_TRY(hipSetDevice(s->device));
+  return launch_render(s, sensor, image_w, image_h, 0, 0, image_w, image_h, tile_w, tile_h,
+                       first_tile, tile_stride, n_tiles, max_depth, (uint8_t *)d_rgb, nullptr,
+                       (hipStream_t)stream);
+}
+
+int mt_blit_tiles_device(mt_scene *s, int image_w, int image_h, int tile_w, int tile_h,
+                         int first_tile, int tile_stride, int n_tiles, const void *d_tiles,
+                         void *d_image, void *stream) {
+  if (!s || !d_tiles || !d_image || image_w <= 0 || image_h <= 0 || tile_w <= 0 || tile_h <= 0 ||
+      first_tile < 0 || tile_stride <= 0 || n_tiles < 0) {
+    return fail(MT_ERR_ARG, "bad blit arguments");
+  }
+  const int tiles_x = (image_w + tile_w - 1) / tile_w;
+  const long long tiles_total = (long long)tiles_x * ((image_h + tile_h - 1) / tile_h);
+  if (n_tiles > 0 && (long long)first_tile + (long long)(n_tiles - 1) * tile_stride >= tiles_total) {
+    return fail(MT_ERR_ARG, "tile selection exceeds the %lld tiles of the image", tiles_total);
+  }
+  if (n_tiles == 0) return MT_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  hipLaunchKernelGGL(blit_tiles_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, image_w,
+                     image_h, tile_w, tile_h, tiles_x, first_tile, tile_stride, n_tiles,
+                     (const uint8_t *)d_tiles, (uint8_t *)d_image);
+  HIP_TRY(hipGetLastError());
+  return MT_OK;
+}
+
+int mt_render_chunk(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h, int chunk_x,
+                    int chunk_y, int chunk_w, int chunk_h, int max_depth, uint8_t *out_rgb,
+                    mt_debug_px *out_debug, mt_stats *stats) {
+  if (!out_rgb) return fail(MT_ERR_ARG, "out_rgb is NULL");
+  int rc = check_image_args(s, sensor, image_w, image_h);
+  if (rc != MT_OK) return rc;
+  const auto w0 = std::chrono::steady_clock::now();
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t npx = (size_t)(chunk_w > 0 ? chunk_w : 0) * (size_t)(chunk_h > 0 ? chunk_h : 0);
+  if ((rc = ensure_bytes((void **)&s->d_rgb, &s->rgb_bytes, npx * 3)) != MT_OK) return rc;
+  if (out_debug) {
+    if ((rc = ensure_bytes((void **)&s->d_debug, &s->debug_bytes, npx * sizeof(mt_debug_px))) != MT_OK) {
+      return rc;
+    }
+  }
+  HIP_TRY(hipMemset(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(hipEventRecord(s->ev0, nullptr));
+  rc = mt_render_chunk_device(s, sensor, image_w, image_h, chunk_x, chunk_y, chunk_w, chunk_h,
+                              max_depth, s->d_rgb, out_debug ? s->d_debug : nullptr, nullptr);
+  if (rc != MT_OK) return rc;
+  HIP_TRY(hipEventRecord(s->ev1, nullptr));
+  HIP_TRY(hipMemcpy(out_rgb, s->d_rgb, npx * 3, hipMemcpyDeviceToHost));
+  if (out_debug) {
+    HIP_TRY(hipMemcpy(out_debug, s->d_debug, npx * sizeof(mt_debug_px), hipMemcpyDeviceToHost));
+  }
+  mt_stats local;
+  if ((rc = mt_scene_read_stats(s, &local)) != MT_OK) return rc;  // also checks the device status
+  if (stats) {
+    *stats = local;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+    stats->total_ms =
+        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+  }
+  return MT_OK;
+}
+
+int mt_intersect_rays(mt_scene *s, int n, const double *rays, int32_t *tri, int32_t *line_no,
+                      double *t, double *point, mt_stats *stats) {
+  if (!s || n < 0 || (n > 0 && !rays)) return fail(MT_ERR_ARG, "bad ray batch");
+  if (stats) memset(stats, 0, sizeof *stats);
+  if (n == 0) return MT_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  double *d_rays = nullptr, *d_t = nullptr, *d_point = nullptr;
+  int *d_tri = nullptr, *d_line = nullptr;
+  int rc = MT_OK;
+  auto cleanup = [&]() {
+    (void)hipFree(d_rays); (void)hipFree(d_t); (void)hipFree(d_point);
+    (void)hipFree(d_tri); (void)hipFree(d_line);
+  };
+#define TRY_OR_CLEAN(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      cleanup();                                                                             \
+      return fail(MT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));                \
+    }                                                                                        \
+  } while (0)
+  TRY_OR_CLEAN(hipMalloc((void **)&d_rays, (size_t)n * 48));
+  TRY_OR_CLEAN(hipMalloc((void **)&d_t, (size_t)n * 8));
+  TRY_OR_CLEAN(hipMalloc((void **)&d_point, (size_t)n * 24));
+  TRY_OR_CLEAN(hipMalloc((void **)&d_tri, (size_t)n * 4));
+  TRY_OR_CLEAN(hipMalloc((void **)&d_line, (size_t)n * 4));
+  TRY_OR_CLEAN(hipMemcpy(d_rays, rays, (size_t)n * 48, hipMemcpyHostToDevice));
+  TRY_OR_CLEAN(hipMemset(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long)));
+  const int block = s->waves_per_block * 64;
+  const int grid = (n + block - 1) / block;
+  TRY_OR_CLEAN(hipEventRecord(s->ev0, nullptr));
+  hipLaunchKernelGGL(intersect_kernel, dim3(grid), dim3(block), s->lds_bytes, nullptr, s->dev, n,
+                     d_rays, d_tri, d_line, d_t, d_point, s->d_counters);
+  TRY_OR_CLEAN(hipGetLastError());
+  TRY_OR_CLEAN(hipEventRecord(s->ev1, nullptr));
+  TRY_OR_CLEAN(hipDeviceSynchronize());
+  if (tri) TRY_OR_CLEAN(hipMemcpy(tri, d_tri, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (line_no) TRY_OR_CLEAN(hipMemcpy(line_no, d_line, (size_t)n * 4, hipMemcpyDeviceToHost));
+  if (t) TRY_OR_CLEAN(hipMemcpy(t, d_t, (size_t)n * 8, hipMemcpyDeviceToHost));
+  if (point) TRY_OR_CLEAN(hipMemcpy(point, d_point, (size_t)n * 24, hipMemcpyDeviceToHost));
+  cleanup();
+#undef TRY_OR_CLEAN
+  mt_stats local;
+  if ((rc = mt_scene_read_stats(s, &local)) != MT_OK) return rc;
+  if (stats) {
+    *stats = local;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    stats->kernel_ms = ms;
+  }
+  return MT_OK;
+}
+
+}  // extern "C"

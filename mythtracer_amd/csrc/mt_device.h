@@ -1,0 +1,101 @@
+// mt_device.h — device-side data layout shared by the kernels and the host
+// side of libmythtracer_hip.so.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mythtracer_hip.h"
+
+namespace mt {
+
+// One octree node, 96 bytes so that a wave fetches it with two scalar loads
+// (s_load_dwordx16 + s_load_dwordx8).  lo/c/hi are OctTree::Node::aabb.min,
+// ::center, ::aabb.max (octtree.h:47-53): the eight child boxes are
+// combinations of these nine planes (octtree.cc:61-100), so the child slab
+// tests need nothing else.
+struct NodeRec {
+  double lo[3];
+  double c[3];
+  double hi[3];
+  int32_t first_child;  // 0 = leaf
+  int32_t prim_begin;
+  int32_t prim_count;
+  int32_t pad0;
+  double pad1;
+};
+static_assert(sizeof(NodeRec) == 96, "NodeRec must be 96 bytes");
+
+struct DevTexture {
+  const void *texels;
+  int32_t width, height, format, pad;
+};
+
+// Everything the kernels read.  Passed by value as a kernel argument.
+struct DevScene {
+  const NodeRec *nodes;
+  const double *tri_aabb;    // 6 per triangle, node-stream order
+  const double *tri_vertex;  // 9 per triangle
+  const double *tri_normal;  // 9 per triangle
+  const double *tri_uvw;     // 9 per triangle
+  const int32_t *tri_mtl;
+  const int32_t *tri_line;
+  const mt_material *mtls;
+  const DevTexture *texs;
+  const mt_light *lights;
+  int32_t n_lights;
+  int32_t n_tris;
+  int32_t n_nodes;
+  int32_t tree_depth;
+  int32_t force_mode;  // 0 auto, 1 exact only, 2 no octant path
+  int32_t scene_regular;  // 1: all coordinates finite and boxes ordered
+  // Debug heartbeat (normally NULL): host-visible words the kernel updates so
+  // that a stuck launch can be diagnosed from the host (MT_DEBUG_HEARTBEAT=1).
+  volatile unsigned long long *hb;
+};
+
+enum {
+  ST_RAYS_PRIMARY = 0,
+  ST_RAYS_SECONDARY,
+  ST_RAYS_SHADOW,
+  ST_BOX_TESTS,
+  ST_NODE_VISITS,
+  ST_TRI_TESTS,
+  ST_MT_TESTS,
+  ST_SHADED_HITS,
+  ST_WAVE_NODE_STEPS,
+  ST_WAVE_TRI_STEPS,
+  ST_STATUS,  // 0 = ok, else a DEV_ERR_* code: a loop bound tripped (never expected)
+  ST_COUNT
+};
+
+// Every data-dependent loop in the kernels carries an iteration bound derived
+// from the scene size, so that a logic error ends the launch with a status code
+// instead of hanging the GPU.
+enum { DEV_OK = 0, DEV_ERR_TRAVERSAL_BOUND = 1, DEV_ERR_UNWIND_BOUND = 2, DEV_ERR_PIXEL_BOUND = 3 };
+
+// Tiling of one launch (see mt_render_tiles_device in the C ABI).
+struct RenderParams {
+  mt_sensor sensor;
+  int32_t image_w, image_h;
+  // region that is cut into tiles, in image coordinates
+  int32_t region_x, region_y, region_w, region_h;
+  int32_t tile_w, tile_h;
+  int32_t tiles_x;         // tiles per row of the region
+  int32_t first_tile, tile_stride, n_tiles;
+  int32_t blocks_x, blocks_y;  // 8x8 pixel blocks per tile slot
+  int32_t max_depth;
+  uint32_t n_items;        // n_tiles * blocks_x * blocks_y
+  uint8_t *out_rgb;
+  mt_debug_px *out_debug;  // nullable; same slot layout as out_rgb
+  unsigned long long *counters;  // ST_COUNT
+  unsigned int *work_counter;
+  double *frames;          // recursion frames scratch
+};
+
+// Bytes of LDS one wave needs for its traversal stack.
+__host__ __device__ inline size_t wave_stack_bytes(int depth) {
+  return (size_t)depth * 64 * 20;
+}
+
+constexpr int kFrameSlots = 11;  // 10 doubles + 1 packed meta word per frame
+
+}  // namespace mt

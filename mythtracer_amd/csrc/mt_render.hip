@@ -1,0 +1,432 @@
+// mt_render.hip — the per-pixel megakernel and the ray-batch kernel.
+//
+// Replaces the pixel loop of MythTracer::RayTrace(WorkChunk*)
+// (mythtracer.cc:292-305): Sensor::GetRay (camera.cc:65-69), TraceRayWorker
+// (mythtracer.cc:13-228) and V3DtoRGB (:235-241).
+//
+// Execution model: persistent waves.  Every wave owns a slice of the block's
+// LDS (its traversal stack) and pulls 8x8-pixel work items from one global
+// counter until none are left; waves never synchronise with each other.  One
+// lane renders one pixel.  The reference's recursion (reflection, refraction)
+// and its shadow loop are run as a per-lane state machine with ONE call site
+// of the wave-synchronous traversal (mt_trace.h), so that whatever kind of ray
+// each lane needs next, all 64 lanes traverse together.
+#include "mt_shade.h"
+
+namespace mt {
+
+enum { MODE_RADIANCE = 0, MODE_SHADOW = 1 };
+enum { STAGE_REFL = 0, STAGE_REFR = 1 };
+
+// Recursion frames (one per level that has a child in flight) live in a
+// global scratch buffer, [wave][level][slot][lane] doubles: coalesced, and
+// touched only once per secondary ray.
+struct FrameIO {
+  double *base;  // this wave's block
+  int lane;
+  __device__ __forceinline__ double *slot(int level, int s) const {
+    return base + ((size_t)level * kFrameSlots + s) * 64 + lane;
+  }
+  __device__ __forceinline__ void put3(int level, int s, V3 v) const {
+    *slot(level, s) = v.x; *slot(level, s + 1) = v.y; *slot(level, s + 2) = v.z;
+  }
+  __device__ __forceinline__ V3 get3(int level, int s) const {
+    return V3{*slot(level, s), *slot(level, s + 1), *slot(level, s + 2)};
+  }
+};
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void render_kernel(DevScene S, RenderParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  const int waves_per_block = blockDim.x >> 6;
+  const int wave_id = blockIdx.x * waves_per_block + wave_in_block;
+  WaveStack stk;
+  stk.bind(smem + (size_t)wave_in_block * wave_stack_bytes(S.tree_depth), S.tree_depth);
+  FrameIO fio;
+  fio.base = P.frames + (size_t)wave_id * (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64;
+  fio.lane = lane;
+
+  const MT_CONST mt_material *mtls = as_const(S.mtls);
+  const MT_CONST mt_light *lights = as_const(S.lights);
+
+  LaneStats st;
+  st.clear();
+
+  const V3 cam_origin = v3_load(P.sensor.origin);
+  const V3 s_start = v3_load(P.sensor.start_point);
+  const V3 s_ds = v3_load(P.sensor.delta_scanline);
+  const V3 s_dp = v3_load(P.sensor.delta_pixel);
+  const int items_per_tile = P.blocks_x * P.blocks_y;
+
+  for (;;) {
+    // Work fetch.  Written WITHOUT a divergent branch: every lane issues the
+    // add (lane 0 adds 1, the others 0; hipcc merges them into one atomic per
+    // wave) and lane 0's return value is broadcast.  The obvious form
+    // `if (lane == 0) v = atomicAdd(..); v = readfirstlane(v);` was miscompiled
+    // by hipcc 7.2 (the broadcast was folded per control-flow path, so lanes
+    // 1..63 kept looping on item 0 for ever).
+    unsigned item = atomicAdd(P.work_counter, lane == 0 ? 1u : 0u);
+    item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
+    if (S.hb) {
+      const unsigned long long ex = __builtin_amdgcn_read_exec();
+      if (lane == 0) { S.hb[wave_id * 4 + 0] = 1 | ((unsigned long long)item << 8); S.hb[wave_id * 4 + 1] = ex; }
+    }
+    if (item >= P.n_items) break;
+
+    // work item -> tile slot j, 8x8 block (bx, by) inside the tile
+    const int j = (int)(item / (unsigned)items_per_tile);
+    const int b = (int)(item % (unsigned)items_per_tile);
+    const int tile = P.first_tile + j * P.tile_stride;
+    const int tx0 = P.region_x + (tile % P.tiles_x) * P.tile_w;
+    const int ty0 = P.region_y + (tile / P.tiles_x) * P.tile_h;
+    const int cw = min(P.tile_w, P.region_x + P.region_w - tx0);  // edge clipping as
+    const int ch = min(P.tile_h, P.region_y + P.region_h - ty0);  // main_net_master.cc:205-206
+    const int lx = (b % P.blocks_x) * 8 + (lane & 7);
+    const int ly = (b / P.blocks_x) * 8 + (lane >> 3);
+    bool alive = (lx < cw) && (ly < ch);
+    const size_t slot_px = (size_t)j * (size_t)P.tile_w * (size_t)P.tile_h;
+    const size_t px_index = slot_px + (size_t)ly * (size_t)cw + (size_t)lx;
+
+    // ---- per-lane state of TraceRayWorker
+    int mode = MODE_RADIANCE;
+    int level = 0;
+    bool in_object = false;
+    double coef = 1.0;
+    V3 ro = cam_origin, rd = v3(0, 0, 1);
+    if (alive) {  // Sensor::GetRay, camera.cc:65-69
+      const V3 d = s_start + (s_ds * (double)(ty0 + ly)) + (s_dp * (double)(tx0 + lx));
+      rd = normalized(d);
+    }
+    V3 Pt = v3(0, 0, 0), Nn = Pt, surf = Pt, color = Pt, Rd = Pt, dir = Pt, L = Pt, start = Pt,
+       lp = Pt;
+    int mtl = -1, li = 0;
+    bool traversing = false;
+
+    // Bound on traversals per 8x8 item: every ray of a pixel is one pass; a
+    // pixel needs at most 2^(max_depth+1) radiance rays, each with one shadow
+    // loop per light whose iterations each cross a different surface.
+    const long long pass_bound =
+        (2ll << P.max_depth) * (1 + (long long)S.n_lights * ((long long)S.n_tris + 2)) + 16;
+    long long passes = 0;
+    while (__ballot(alive) != 0ull) {
+      int prim;
+      double t;
+      if (S.hb) {
+        const unsigned long long am = __ballot(alive);
+        const unsigned long long ex = __builtin_amdgcn_read_exec();
+        if (lane == 0) {
+          S.hb[wave_id * 4 + 0] = 2 | ((unsigned long long)passes << 8);
+          S.hb[wave_id * 4 + 2] = am;
+          S.hb[wave_id * 4 + 3] = ex;
+        }
+      }
+      const int trc =
+          trace_wave<STATS>(S, stk, lane, alive, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, prim, t, st);
+      if (S.hb) {
+        const unsigned long long ex = __builtin_amdgcn_read_exec();
+        if (lane == 0) { S.hb[wave_id * 4 + 0] = 3 | ((unsigned long long)passes << 8); S.hb[wave_id * 4 + 3] = ex; }
+      }
+      if (trc != DEV_OK || ++passes > pass_bound) {
+        if (lane == 0) atomicMax(P.counters + ST_STATUS, (unsigned long long)(trc != DEV_OK ? trc : DEV_ERR_PIXEL_BOUND));
+        alive = false;
+        break;
+      }
+      if (alive) {
+        bool next_light = false, after_lights = false, do_return = false;
+        V3 retval = v3(0, 0, 0);
+        if (mode == MODE_RADIANCE) {
+          if (STATS) st.v[level == 0 ? ST_RAYS_PRIMARY : ST_RAYS_SECONDARY]++;
+          if (prim < 0) {  // mythtracer.cc:23-31
+            if (level == 0 && P.out_debug != nullptr) {
+              mt_debug_px *dbg = P.out_debug + px_index;
+              dbg->line_no = -1;
+              dbg->reserved = 0;
+              dbg->point[0] = dbg->point[1] = dbg->point[2] = __builtin_nan("");
+            }
+            do_return = true;
+          } else {
+            if (STATS) st.v[ST_SHADED_HITS]++;
+            Pt = ro + rd * t;  // primitive_triangle.cc:141
+            dir = rd;
+            if (level == 0 && P.out_debug != nullptr) {  // :33-36
+              mt_debug_px *dbg = P.out_debug + px_index;
+              dbg->line_no = S.tri_line[prim];
+              dbg->reserved = 0;
+              dbg->point[0] = Pt.x; dbg->point[1] = Pt.y; dbg->point[2] = Pt.z;
+            }
+            const double *vtx = S.tri_vertex + (size_t)prim * 9;
+            const Bary w = barycentric(vtx, Pt);
+            Nn = interpolate(S.tri_normal + (size_t)prim * 9, w);  // :38
+            const V3 towards_camera = -dir;
+            double normal_ray_dot = dot(Nn, towards_camera);
+            if (normal_ray_dot < 0.0) {  // :42-45
+              Nn = -Nn;
+              normal_ray_dot = dot(Nn, towards_camera);
+            }
+            mtl = S.tri_mtl[prim];
+            if (mtl < 0) {  // :49-52
+              normal_ray_dot = (normal_ray_dot + 1.0) * 0.5;
+              retval = v3(normal_ray_dot, normal_ray_dot, normal_ray_dot);
+              do_return = true;
+            } else {
+              const MT_CONST mt_material *m = mtls + mtl;
+              surf = v3(m->ambient[0], m->ambient[1], m->ambient[2]);  // :58
+              if (m->tex >= 0) {  // :59-64
+                const V3 uvw = interpolate(S.tri_uvw + (size_t)prim * 9, w);
+                surf = surf * texture_color_at(S.texs[m->tex], uvw.x, uvw.y);
+              }
+              Rd = dir - Nn * (2 * dot(dir, Nn));  // :68-69
+              color = v3(0, 0, 0);
+              li = 0;
+              next_light = true;
+            }
+          }
+        } else {  // ---- one iteration of the shadow loop, mythtracer.cc:94-156
+          if (STATS) st.v[ST_RAYS_SHADOW]++;
+          const MT_CONST mt_light *lt = lights + li;
+          const V3 lpos = v3(lt->position[0], lt->position[1], lt->position[2]);
+          bool light_done = false, in_shadow = false;
+          if (prim < 0) {
+            light_done = true;  // :109-112
+          } else {
+            const double light_distance = distance(start, lpos);  // :101-102
+            if (t > light_distance) {
+              light_done = true;  // :115-118
+            } else {
+              // :121 dereferences shadow_primitive->mtl unconditionally (a
+              // crash for material-less occluders); defined here as opaque.
+              const int sm = S.tri_mtl[prim];
+              const double s_tr = sm >= 0 ? mtls[sm].transparency : 0.0;
+              if (s_tr == 0.0) {
+                lp = v3(0, 0, 0);
+                in_shadow = true;
+                light_done = true;
+              } else {
+                if (!traversing) {  // :129-132
+                  const MT_CONST mt_material *smm = mtls + sm;
+                  const V3 tf = v3(smm->transmission_filter[0], smm->transmission_filter[1],
+                                   smm->transmission_filter[2]);
+                  lp = lp * (tf * s_tr);
+                }
+                traversing = !traversing;
+                const V3 sp = ro + rd * t;
+                start = sp + (L * 0.0000001);  // :137
+                if (sqr_distance(Pt, start) > sqr_distance(Pt, lpos)) {
+                  light_done = true;  // :141-145
+                } else if (lp.x <= 0.001 && lp.y <= 0.001 && lp.z <= 0.001) {
+                  lp = v3(0, 0, 0);  // :149-155
+                  in_shadow = true;
+                  light_done = true;
+                } else {
+                  ro = start + (L * 0.00001);  // next iteration, :95-99
+                  rd = L;
+                }
+              }
+            }
+          }
+          if (light_done) {
+            const MT_CONST mt_material *m = mtls + mtl;
+            const V3 amb = v3(lt->ambient[0], lt->ambient[1], lt->ambient[2]);
+            lp.x = std_max(lp.x, amb.x);  // :159-161
+            lp.y = std_max(lp.y, amb.y);
+            lp.z = std_max(lp.z, amb.z);
+            const V3 kd = v3(m->diffuse[0], m->diffuse[1], m->diffuse[2]);
+            const V3 ld = v3(lt->diffuse[0], lt->diffuse[1], lt->diffuse[2]);
+            color = color + kd * surf * dot(L, Nn) * ld * lp;  // :163-167
+            if (!in_shadow) {  // :169-177
+              const double refl_dot = dot(Rd, -dir);
+              if (refl_dot > 0) {
+                const V3 ks = v3(m->specular[0], m->specular[1], m->specular[2]);
+                const V3 ls = v3(lt->specular[0], lt->specular[1], lt->specular[2]);
+                color = color + ks * surf * ::pow(refl_dot, m->specular_exp) * ls;
+              }
+            }
+            li++;
+            next_light = true;
+          }
+        }
+
+        if (next_light) {
+          if (li < S.n_lights) {  // head of the light loop, :78-99
+            const MT_CONST mt_light *lt = lights + li;
+            const V3 lpos = v3(lt->position[0], lt->position[1], lt->position[2]);
+            L = normalized(lpos - Pt);
+            color = color + v3(lt->ambient[0], lt->ambient[1], lt->ambient[2]) * surf;  // :83-84
+            lp = v3(1.0, 1.0, 1.0);
+            traversing = false;
+            start = Pt;
+            ro = start + (L * 0.00001);
+            rd = L;
+            mode = MODE_SHADOW;
+          } else {
+            after_lights = true;
+          }
+        }
+
+        if (after_lights) {
+          const MT_CONST mt_material *m = mtls + mtl;
+          const double refl = m->reflectance, tr = m->transparency;
+          if (level < P.max_depth && refl > 0.0 && coef > 0.01 && !in_object) {  // :181-189
+            fio.put3(level, 0, color);
+            fio.put3(level, 3, Pt);
+            fio.put3(level, 6, dir);
+            *fio.slot(level, 9) = coef;
+            *(long long *)fio.slot(level, 10) =
+                (long long)mtl | ((long long)(in_object ? 1 : 0) << 32) | ((long long)STAGE_REFL << 33);
+            ro = Pt + (Rd * 0.0001);  // :70-74
+            rd = Rd;
+            coef = coef * refl;
+            level++;
+            mode = MODE_RADIANCE;
+          } else if (level < P.max_depth && tr > 0.0) {  // :192-225
+            fio.put3(level, 0, color);
+            *(long long *)fio.slot(level, 10) =
+                (long long)mtl | ((long long)(in_object ? 1 : 0) << 32) | ((long long)STAGE_REFR << 33);
+            const V3 rdir = normalized(dir);  // :208-212 (direction unchanged, re-normalised)
+            ro = Pt + rdir * 0.00001;
+            rd = rdir;
+            in_object = !in_object;
+            level++;
+            mode = MODE_RADIANCE;
+          } else {
+            retval = color;
+            do_return = true;
+          }
+        }
+
+        while (do_return) {  // unwinding TraceRayWorker returns
+          if (level == 0) {
+            uint8_t *o = P.out_rgb + px_index * 3;  // V3DtoRGB + chunk-local store, :301
+            o[0] = channel_to_u8(retval.x);
+            o[1] = channel_to_u8(retval.y);
+            o[2] = channel_to_u8(retval.z);
+            alive = false;
+            break;
+          }
+          level--;
+          const long long meta = *(long long *)fio.slot(level, 10);
+          const int fm = (int)(meta & 0xffffffffll);
+          const bool f_in = ((meta >> 32) & 1) != 0;
+          const int stage = (int)((meta >> 33) & 1);
+          const MT_CONST mt_material *m = mtls + fm;
+          const V3 fcolor = fio.get3(level, 0);
+          if (stage == STAGE_REFL) {
+            color = fcolor + retval * m->reflectance;  // :185-188
+            const double tr = m->transparency;
+            if (tr > 0.0) {  // level < max_depth holds: this frame pushed a child
+              Pt = fio.get3(level, 3);
+              dir = fio.get3(level, 6);
+              coef = *fio.slot(level, 9);
+              fio.put3(level, 0, color);
+              *(long long *)fio.slot(level, 10) =
+                  (long long)fm | ((long long)(f_in ? 1 : 0) << 32) | ((long long)STAGE_REFR << 33);
+              const V3 rdir = normalized(dir);
+              ro = Pt + rdir * 0.00001;
+              rd = rdir;
+              in_object = !f_in;
+              level++;
+              mode = MODE_RADIANCE;
+              do_return = false;
+            } else {
+              retval = color;
+            }
+          } else {
+            const V3 tf = v3(m->transmission_filter[0], m->transmission_filter[1],
+                             m->transmission_filter[2]);
+            retval = fcolor + retval * tf * m->transparency;  // :220-224
+          }
+        }
+      }
+    }
+
+    if (S.hb && lane == 0) S.hb[wave_id * 4 + 0] = 4;
+    if (STATS) {  // one atomic per counter per work item (64 pixels)
+      for (int i = 0; i < ST_WAVE_NODE_STEPS; i++) {
+        const unsigned s = wave_sum_u32(st.v[i]);
+        if (lane == 0 && s) atomicAdd(P.counters + i, (unsigned long long)s);
+      }
+      if (lane == 0) {
+        atomicAdd(P.counters + ST_WAVE_NODE_STEPS, (unsigned long long)st.wave_node_steps);
+        atomicAdd(P.counters + ST_WAVE_TRI_STEPS, (unsigned long long)st.wave_tri_steps);
+      }
+      st.clear();
+    }
+  }
+  if (S.hb && lane == 0) S.hb[wave_id * 4 + 0] = 5;
+}
+
+// OctTree::IntersectRay for a batch of arbitrary rays: lane i of the grid
+// traces ray i.
+__global__ __launch_bounds__(256) void intersect_kernel(DevScene S, int n, const double *rays,
+                                                        int *out_tri, int *out_line,
+                                                        double *out_t, double *out_point,
+                                                        unsigned long long *counters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  WaveStack stk;
+  stk.bind(smem + (size_t)wave_in_block * wave_stack_bytes(S.tree_depth), S.tree_depth);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool want = i < n;
+  double o[3] = {0, 0, 0}, d[3] = {0, 0, 1};
+  if (want) {
+    for (int k = 0; k < 3; k++) {
+      o[k] = rays[(size_t)i * 6 + k];
+      d[k] = rays[(size_t)i * 6 + 3 + k];
+    }
+  }
+  LaneStats st;
+  st.clear();
+  int prim;
+  double t;
+  const int trc = trace_wave<true>(S, stk, lane, want, o[0], o[1], o[2], d[0], d[1], d[2], prim, t, st);
+  if (trc != DEV_OK && counters && lane == 0) atomicMax(counters + ST_STATUS, (unsigned long long)trc);
+  if (want) {
+    if (out_tri) out_tri[i] = prim;
+    if (out_line) out_line[i] = prim >= 0 ? S.tri_line[prim] : -1;
+    if (out_t) out_t[i] = prim >= 0 ? t : __builtin_nan("");
+    if (out_point) {
+      for (int k = 0; k < 3; k++) {
+        out_point[(size_t)i * 3 + k] = prim >= 0 ? o[k] + d[k] * t : __builtin_nan("");
+      }
+    }
+  }
+  if (counters) {
+    for (int k = 0; k < ST_WAVE_NODE_STEPS; k++) {
+      const unsigned s = wave_sum_u32(st.v[k]);
+      if (lane == 0 && s) atomicAdd(counters + k, (unsigned long long)s);
+    }
+    if (lane == 0) {
+      atomicAdd(counters + ST_WAVE_NODE_STEPS, (unsigned long long)st.wave_node_steps);
+      atomicAdd(counters + ST_WAVE_TRI_STEPS, (unsigned long long)st.wave_tri_steps);
+    }
+  }
+}
+
+// BlitWorkChunk (main_net_master.cc:223-236) for a buffer of tile slots.
+__global__ void blit_tiles_kernel(int image_w, int image_h, int tile_w, int tile_h, int tiles_x,
+                                  int first_tile, int tile_stride, int n_tiles,
+                                  const uint8_t *tiles, uint8_t *image) {
+  const size_t slot_bytes = (size_t)tile_w * tile_h * 3;
+  const size_t total = (size_t)n_tiles * tile_w * tile_h;
+  for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < total;
+       p += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(p / ((size_t)tile_w * tile_h));
+    const int q = (int)(p % ((size_t)tile_w * tile_h));
+    const int tile = first_tile + j * tile_stride;
+    const int x0 = (tile % tiles_x) * tile_w, y0 = (tile / tiles_x) * tile_h;
+    const int cw = min(tile_w, image_w - x0), ch = min(tile_h, image_h - y0);
+    if (q >= cw * ch) continue;
+    const int lx = q % cw, ly = q / cw;
+    const uint8_t *src = tiles + (size_t)j * slot_bytes + (size_t)q * 3;
+    uint8_t *dst = image + ((size_t)(y0 + ly) * image_w + (x0 + lx)) * 3;
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+  }
+}
+
+template __global__ void render_kernel<true>(DevScene, RenderParams);
+template __global__ void render_kernel<false>(DevScene, RenderParams);
+
+}  // namespace mt

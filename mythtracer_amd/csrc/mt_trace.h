@@ -1,0 +1,523 @@
+// mt_trace.h — wave-synchronous octree traversal for gfx950 (wave64).
+//
+// Replaces OctTree::IntersectRay (octtree.cc:26-40),
+// Node::NodeIntersectRay (:138-167), Node::PrimitiveIntersectRay (:169-257)
+// and Triangle::IntersectRay (primitive_triangle.cc:81-143) of the reference,
+// with bit-identical results.
+//
+// Design (one ray per lane, one NODE per wave step):
+//   * every lane keeps its own recursion state (the reference's call stack of
+//     PrimitiveIntersectRay) in an LDS-resident per-lane stack;
+//   * the wave repeatedly picks the lowest-numbered node any lane still has to
+//     scan (nodes are numbered breadth-first, so the big top-of-tree lists are
+//     scanned once for all lanes that need them) and scans that node's
+//     triangle list for those lanes only.  The node record and the triangle
+//     boxes are therefore WAVE-UNIFORM: they are fetched with scalar loads
+//     (one 48-byte box serves 64 rays) and fed to the VALU as SGPR operands;
+//   * the rare triangles that pass the box pre-filter are parked per lane and
+//     resolved (Möller–Trumbore) in batches, in the reference's order.
+//
+// Exactness.  fp64 throughout, no FMA contraction (-ffp-contract=off), IEEE
+// division and square root.  Three evaluation modes of the slab test produce
+// the same booleans as the reference's std::min/std::max formulation:
+//   mode 0 (exact)   literal std::min/std::max compare+select; used whenever
+//                    a ray could produce NaN (a zero direction component);
+//   mode 1 (regular) v_min_f64/v_max_f64; identical when no operand is NaN
+//                    (only the sign of a zero may differ, which no comparison
+//                    here can see);
+//   mode 2 (octant)  when all lanes scanning a node share the direction sign
+//                    octant, near/far planes are picked per axis by the sign
+//                    (max(t1,t2) is t2 when 1/d > 0 because rounding is
+//                    monotonic), which removes six min/max per box.
+// No distance-based pruning is done: the reference tests every triangle of a
+// visited node and its tie-breaking (later equal-distance hit wins,
+// octtree.cc:186-195) is reproduced literally.
+#pragma once
+#include "mt_device.h"
+
+namespace mt {
+
+#define MT_CONST __attribute__((address_space(4)))
+
+template <typename T>
+__device__ __forceinline__ const MT_CONST T *as_const(const T *p) {
+  return (const MT_CONST T *)(uintptr_t)p;
+}
+
+// std::min / std::max exactly as libstdc++ (NaN and operand order).
+__device__ __forceinline__ double std_min(double a, double b) { return (b < a) ? b : a; }
+__device__ __forceinline__ double std_max(double a, double b) { return (a < b) ? b : a; }
+__device__ __forceinline__ double std_min3(double a, double b, double c) {
+  double r = a;
+  if (b < r) r = b;
+  if (c < r) r = c;
+  return r;
+}
+__device__ __forceinline__ double std_max3(double a, double b, double c) {
+  double r = a;
+  if (r < b) r = b;
+  if (r < c) r = c;
+  return r;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ double mn(double a, double b) {
+  if constexpr (EXACT) return std_min(a, b);
+  else return __builtin_fmin(a, b);
+}
+template <bool EXACT>
+__device__ __forceinline__ double mx(double a, double b) {
+  if constexpr (EXACT) return std_max(a, b);
+  else return __builtin_fmax(a, b);
+}
+template <bool EXACT>
+__device__ __forceinline__ double mn3(double a, double b, double c) {
+  if constexpr (EXACT) return std_min3(a, b, c);
+  else return __builtin_fmin(__builtin_fmin(a, b), c);
+}
+template <bool EXACT>
+__device__ __forceinline__ double mx3(double a, double b, double c) {
+  if constexpr (EXACT) return std_max3(a, b, c);
+  else return __builtin_fmax(__builtin_fmax(a, b), c);
+}
+
+// Wave-wide minimum of a 32-bit value; every lane must be active.
+__device__ __forceinline__ int wave_min_i32(int v) {
+  // all-reduce inside each row of 16 lanes with row rotations ...
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));  // row_ror:8
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));  // row_ror:4
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));  // row_ror:2
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));  // row_ror:1
+  // ... then combine the four rows on the scalar unit.
+  int a = __builtin_amdgcn_readlane(v, 0);
+  int b = __builtin_amdgcn_readlane(v, 16);
+  int c = __builtin_amdgcn_readlane(v, 32);
+  int d = __builtin_amdgcn_readlane(v, 48);
+  return min(min(a, b), min(c, d));
+}
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);
+  unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+  unsigned b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32);
+  unsigned d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return a + b + c + d;
+}
+
+// Per-lane work counters of one wave (see mt_stats).
+struct LaneStats {
+  unsigned v[ST_WAVE_NODE_STEPS];  // the per-lane ones
+  unsigned wave_node_steps, wave_tri_steps;  // wave-uniform
+  __device__ void clear() {
+    for (int i = 0; i < ST_WAVE_NODE_STEPS; i++) v[i] = 0;
+    wave_node_steps = wave_tri_steps = 0;
+  }
+};
+
+// The per-wave traversal stack in LDS, structure-of-arrays over [depth][lane]
+// so that every access is bank-conflict free.
+struct WaveStack {
+  double *bt;      // best distance so far in that node
+  int *fc;         // first child of that node
+  int *bp;         // best primitive so far in that node (-1 none)
+  unsigned *ord;   // bits 0-23: child order (3 bits each), 24-27 count, 28-31 pos
+  __device__ __forceinline__ void bind(char *base, int depth) {
+    bt = (double *)base;
+    fc = (int *)(base + (size_t)depth * 64 * 8);
+    bp = (int *)(base + (size_t)depth * 64 * 12);
+    ord = (unsigned *)(base + (size_t)depth * 64 * 16);
+  }
+};
+
+// Möller–Trumbore, primitive_triangle.cc:110-142, for one lane's triangle.
+__device__ __forceinline__ bool moller_trumbore(const double *vtx, double ox, double oy,
+                                                double oz, double dx, double dy, double dz,
+                                                double *t_out) {
+  const MT_CONST double *v = as_const(vtx);
+  const double v0x = v[0], v0y = v[1], v0z = v[2];
+  const double e1x = v[3] - v0x, e1y = v[4] - v0y, e1z = v[5] - v0z;
+  const double e2x = v[6] - v0x, e2y = v[7] - v0y, e2z = v[8] - v0z;
+  // pvec = direction x e2
+  const double px = dy * e2z - dz * e2y;
+  const double py = dz * e2x - dx * e2z;
+  const double pz = dx * e2y - dy * e2x;
+  const double det = px * e1x + py * e1y + pz * e1z;  // e1.Dot(pvec)
+  if (det >= -0.00000001 && det < 0.00000001) return false;
+  const double inv_det = 1.0 / det;
+  const double tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+  const double u = (px * tx + py * ty + pz * tz) * inv_det;  // tvec.Dot(pvec)
+  if (u < 0.0 || u > 1.0) return false;
+  // qvec = tvec x e1
+  const double qx = ty * e1z - tz * e1y;
+  const double qy = tz * e1x - tx * e1z;
+  const double qz = tx * e1y - ty * e1x;
+  const double vv = (qx * dx + qy * dy + qz * dz) * inv_det;  // direction.Dot(qvec)
+  if (vv < 0.0 || u + vv > 1.0) return false;
+  const double dist = (qx * e2x + qy * e2y + qz * e2z) * inv_det;  // e2.Dot(qvec)
+  if (dist < 0.0) return false;
+  *t_out = dist;
+  return true;
+}
+
+struct RayRegs {
+  double ox, oy, oz;
+  double dx, dy, dz;
+  double ix, iy, iz;  // Ray::inv_direction, octtree.cc:30-33
+};
+
+// Resolves the parked candidate of every lane that has one.
+template <bool STATS>
+__device__ __forceinline__ void flush_candidates(const DevScene &S, const RayRegs &r,
+                                                 int &pend, int &best, double &best_t,
+                                                 LaneStats &st) {
+  if (pend >= 0) {
+    double t;
+    if (STATS) st.v[ST_MT_TESTS]++;
+    if (moller_trumbore(S.tri_vertex + (size_t)pend * 9, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &t)) {
+      // octtree.cc:186-195: keep the old one only if it exists and is
+      // strictly closer.
+      if (!(best >= 0 && t > best_t)) {
+        best = pend;
+        best_t = t;
+      }
+    }
+    pend = -1;
+  }
+}
+
+// Slab pre-filter of Triangle::IntersectRay (primitive_triangle.cc:83-108) for
+// one wave-uniform box `a` (min xyz, max xyz) against each lane's ray.
+template <int MODE>
+__device__ __forceinline__ bool slab_pass(const double (&a)[6], const RayRegs &r, bool sx, bool sy,
+                                          bool sz) {
+  constexpr bool EX = (MODE == 0);
+  if constexpr (MODE == 2) {
+    // near/far plane per axis picked by the (wave-uniform) direction sign
+    const double nx = sx ? a[3] : a[0], fx = sx ? a[0] : a[3];
+    const double ny = sy ? a[4] : a[1], fy = sy ? a[1] : a[4];
+    const double nz = sz ? a[5] : a[2], fz = sz ? a[2] : a[5];
+    const double tnx = (nx - r.ox) * r.ix, tfx = (fx - r.ox) * r.ix;
+    const double tny = (ny - r.oy) * r.iy, tfy = (fy - r.oy) * r.iy;
+    const double tnz = (nz - r.oz) * r.iz, tfz = (fz - r.oz) * r.iz;
+    const double tmax = __builtin_fmin(__builtin_fmin(tfx, tfy), tfz);
+    const double tmin = __builtin_fmax(__builtin_fmax(tnx, tny), tnz);
+    // no NaN can occur in this mode, so this equals !(tmax < 0) && !(tmin > tmax)
+    return (tmax >= 0.0) & (tmin <= tmax);
+  } else {
+    const double t1 = (a[0] - r.ox) * r.ix, t2 = (a[3] - r.ox) * r.ix;
+    const double t3 = (a[1] - r.oy) * r.iy, t4 = (a[4] - r.oy) * r.iy;
+    const double t5 = (a[2] - r.oz) * r.iz, t6 = (a[5] - r.oz) * r.iz;
+    const double tmax = mn3<EX>(mx<EX>(t1, t2), mx<EX>(t3, t4), mx<EX>(t5, t6));
+    const double tmin = mx3<EX>(mn<EX>(t1, t2), mn<EX>(t3, t4), mn<EX>(t5, t6));
+    if constexpr (EX) return !(tmax < 0.0) && !(tmin > tmax);
+    else return (tmax >= 0.0) & (tmin <= tmax);
+  }
+}
+
+// Scans the triangle list [pb, pb+pc) of one node for the calling lanes.
+// MODE: 0 exact, 1 regular, 2 octant-uniform (sx/sy/sz = shared sign bits).
+// Two boxes per step; the next pair is fetched (scalar loads) while the
+// current one is evaluated.  The box stream is padded by two boxes at its end
+// so the look-ahead never leaves the allocation.
+template <int MODE, bool STATS>
+__device__ __forceinline__ void scan_node_prims(const DevScene &S, const RayRegs &r, int pb,
+                                                int pc, int sx, int sy, int sz, int &best,
+                                                double &best_t, LaneStats &st) {
+  const MT_CONST double *boxes = as_const(S.tri_aabb) + (size_t)pb * 6;
+  int pend = -1;
+  unsigned long long pmask = 0;  // lanes holding a parked candidate
+  double cur0[6], cur1[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) { cur0[i] = boxes[i]; cur1[i] = boxes[6 + i]; }
+  for (int k = 0; k < pc; k += 2) {
+    double nxt0[6], nxt1[6];
+    const MT_CONST double *nb = boxes + (size_t)(k + 2) * 6;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { nxt0[i] = nb[i]; nxt1[i] = nb[6 + i]; }
+    const bool pass0 = slab_pass<MODE>(cur0, r, sx, sy, sz);
+    const bool pass1 = slab_pass<MODE>(cur1, r, sx, sy, sz) && (k + 1 < pc);
+    const unsigned long long pm0 = __ballot(pass0);
+    const unsigned long long pm1 = __ballot(pass1);
+    if (pm0 | pm1) {
+      if (pm0 & pmask) {  // some lane would need a second slot: resolve first
+        flush_candidates<STATS>(S, r, pend, best, best_t, st);
+        pmask = 0;
+      }
+      if (pass0) pend = pb + k;
+      pmask |= pm0;
+      if (pm1 & pmask) {
+        flush_candidates<STATS>(S, r, pend, best, best_t, st);
+        pmask = 0;
+      }
+      if (pass1) pend = pb + k + 1;
+      pmask |= pm1;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { cur0[i] = nxt0[i]; cur1[i] = nxt1[i]; }
+  }
+  if (pmask) flush_candidates<STATS>(S, r, pend, best, best_t, st);
+}
+
+// Child slab tests + ordering of the hit children, octtree.cc:204-216.
+// Returns ord (3 bits per entry) | count << 24.
+template <int MODE>
+__device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, const RayRegs &r) {
+  constexpr bool EX = (MODE == 0);
+  double xmin[2], xmax[2], ymin[2], ymax[2], zmin[2], zmax[2];
+  {
+    const double t0 = (N->lo[0] - r.ox) * r.ix, tc = (N->c[0] - r.ox) * r.ix,
+                 t1 = (N->hi[0] - r.ox) * r.ix;
+    // NodeIntersectRay's t1/t2 are (min - o)*inv, (max - o)*inv in that order
+    xmax[0] = mx<EX>(t0, tc); xmin[0] = mn<EX>(t0, tc);
+    xmax[1] = mx<EX>(tc, t1); xmin[1] = mn<EX>(tc, t1);
+  }
+  {
+    const double t0 = (N->lo[1] - r.oy) * r.iy, tc = (N->c[1] - r.oy) * r.iy,
+                 t1 = (N->hi[1] - r.oy) * r.iy;
+    ymax[0] = mx<EX>(t0, tc); ymin[0] = mn<EX>(t0, tc);
+    ymax[1] = mx<EX>(tc, t1); ymin[1] = mn<EX>(tc, t1);
+  }
+  {
+    const double t0 = (N->lo[2] - r.oz) * r.iz, tc = (N->c[2] - r.oz) * r.iz,
+                 t1 = (N->hi[2] - r.oz) * r.iz;
+    zmax[0] = mx<EX>(t0, tc); zmin[0] = mn<EX>(t0, tc);
+    zmax[1] = mx<EX>(tc, t1); zmin[1] = mn<EX>(tc, t1);
+  }
+  double tm[8];
+  bool valid[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const int xh = c & 1, zh = (c >> 1) & 1, yh = (c >> 2) & 1;  // octtree.cc:61-100
+    const double tmax = mn3<EX>(xmax[xh], ymax[yh], zmax[zh]);
+    const double tmin = mx3<EX>(xmin[xh], ymin[yh], zmin[zh]);
+    if constexpr (EX) valid[c] = !(tmax < 0.0) && !(tmin > tmax);
+    else valid[c] = (tmax >= 0.0) & (tmin <= tmax);
+    tm[c] = tmin;
+  }
+  unsigned ord = 0, cnt = 0;
+  if constexpr (!EX) {
+    // No NaN keys: the stable sort by tmin is the order by (tmin, index).
+    unsigned rank[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) rank[c] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+      for (int j = i + 1; j < 8; j++) {
+        const bool both = valid[i] && valid[j];
+        const bool j_first = tm[j] < tm[i];
+        rank[i] += (both && j_first) ? 1u : 0u;
+        rank[j] += (both && !j_first) ? 1u : 0u;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      if (valid[c]) {
+        ord |= (unsigned)c << (3 * rank[c]);
+        cnt++;
+      }
+    }
+  } else {
+    // libstdc++ std::sort on <= 16 elements is __insertion_sort; restated
+    // literally (front-rotate branch and unguarded linear insert) so that NaN
+    // keys land where the reference puts them.
+    double sd[8];
+    unsigned si[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) { sd[c] = 0.0; si[c] = 0; }
+    unsigned m = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      if (valid[c]) {
+        const double vd = tm[c];
+        if (m == 0) {
+          sd[0] = vd; si[0] = c;
+        } else if (vd < sd[0]) {
+#pragma unroll
+          for (int j = 7; j >= 1; j--) {
+            if ((unsigned)j <= m) { sd[j] = sd[j - 1]; si[j] = si[j - 1]; }
+          }
+          sd[0] = vd; si[0] = c;
+        } else {
+          bool moving = true;
+#pragma unroll
+          for (int j = 7; j >= 1; j--) {
+            if (moving && (unsigned)j <= m) {
+              if (vd < sd[j - 1]) {
+                sd[j] = sd[j - 1]; si[j] = si[j - 1];
+              } else {
+                sd[j] = vd; si[j] = c;
+                moving = false;
+              }
+            }
+          }
+        }
+        m++;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) ord |= (si[j] & 7u) << (3 * j);
+    cnt = m;
+    // entries >= m are zero-filled garbage; they are never read (pos < cnt)
+  }
+  return (ord & 0x00ffffffu) | (cnt << 24);
+}
+
+// One closest-hit query per lane.  Must be called by all 64 lanes of the wave
+// (want = false for lanes without a ray).  out_prim = stream index or -1.
+template <bool STATS>
+__device__ __forceinline__ int trace_wave(const DevScene &S, const WaveStack &stk, int lane,
+                                          bool want, double ox, double oy, double oz,
+                                          double dx, double dy, double dz, int &out_prim,
+                                          double &out_t, LaneStats &st) {
+  RayRegs r;
+  r.ox = ox; r.oy = oy; r.oz = oz;
+  r.dx = dx; r.dy = dy; r.dz = dz;
+  r.ix = 1.0 / dx; r.iy = 1.0 / dy; r.iz = 1.0 / dz;
+  out_prim = -1;
+  out_t = 0.0;
+
+  // A lane is "regular" when no slab product can be NaN: finite origin and a
+  // finite, non-zero reciprocal direction on every axis (see header comment).
+  const bool fin = __builtin_isfinite(ox) && __builtin_isfinite(oy) && __builtin_isfinite(oz) &&
+                   __builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
+                   r.ix != 0.0 && r.iy != 0.0 && r.iz != 0.0;
+  const bool all_regular = (S.scene_regular != 0) && (S.force_mode != 1) &&
+                           (__ballot(want && !fin) == 0ull);
+
+  const MT_CONST NodeRec *nodes = as_const(S.nodes);
+  int cur = -1;
+  if (want) {
+    // root box test, octtree.cc:35-37 (exact form; once per ray)
+    const MT_CONST NodeRec *R = nodes;
+    if (STATS) st.v[ST_BOX_TESTS]++;
+    const double t1 = (R->lo[0] - ox) * r.ix, t2 = (R->hi[0] - ox) * r.ix;
+    const double t3 = (R->lo[1] - oy) * r.iy, t4 = (R->hi[1] - oy) * r.iy;
+    const double t5 = (R->lo[2] - oz) * r.iz, t6 = (R->hi[2] - oz) * r.iz;
+    const double tmax = std_min3(std_max(t1, t2), std_max(t3, t4), std_max(t5, t6));
+    const double tmin = std_max3(std_min(t1, t2), std_min(t3, t4), std_min(t5, t6));
+    if (!(tmax < 0.0) && !(tmin > tmax)) cur = 0;
+  }
+  int depth = 0;
+  const int sxl = __builtin_signbit(r.ix) ? 1 : 0;
+  const int syl = __builtin_signbit(r.iy) ? 1 : 0;
+  const int szl = __builtin_signbit(r.iz) ? 1 : 0;
+
+  // Each step retires at least one (lane, node) visit and a lane visits a node
+  // at most once per query, so 64 * n_nodes steps can never be exceeded.
+  const long long step_bound = 64ll * (long long)S.n_nodes + 64;
+  long long steps = 0;
+  int status = DEV_OK;
+  for (;;) {
+    const int n = wave_min_i32(cur >= 0 ? cur : 0x7fffffff);
+    if (n == 0x7fffffff) break;
+    if (++steps > step_bound || n < 0 || n >= S.n_nodes) {
+      status = DEV_ERR_TRAVERSAL_BOUND;
+      break;
+    }
+    const bool in = (cur == n);
+    const unsigned long long inmask = __ballot(in);
+    const MT_CONST NodeRec *N = nodes + n;
+    const int fc = N->first_child;
+    const int pb = N->prim_begin;
+    const int pc = N->prim_count;
+    if (STATS) {
+      st.wave_node_steps++;
+      st.wave_tri_steps += (unsigned)pc;
+    }
+    // wave-uniform mode choice for this node
+    int mode = 0;
+    int sx = 0, sy = 0, sz = 0;
+    if (all_regular) {
+      mode = 1;
+      if (S.force_mode != 2) {
+        const unsigned long long mxs = __ballot(in && sxl), mys = __ballot(in && syl),
+                                 mzs = __ballot(in && szl);
+        if ((mxs == 0 || mxs == inmask) && (mys == 0 || mys == inmask) &&
+            (mzs == 0 || mzs == inmask)) {
+          mode = 2;
+          sx = mxs != 0; sy = mys != 0; sz = mzs != 0;
+        }
+      }
+    }
+    if (in) {
+      int best = -1;
+      double best_t = 0.0;
+      if (STATS) {
+        st.v[ST_NODE_VISITS]++;
+        st.v[ST_TRI_TESTS] += (unsigned)pc;
+      }
+      if (mode == 2) scan_node_prims<2, STATS>(S, r, pb, pc, sx, sy, sz, best, best_t, st);
+      else if (mode == 1) scan_node_prims<1, STATS>(S, r, pb, pc, 0, 0, 0, best, best_t, st);
+      else scan_node_prims<0, STATS>(S, r, pb, pc, 0, 0, 0, best, best_t, st);
+
+      unsigned ordw = 0;
+      if (fc != 0) {
+        if (STATS) st.v[ST_BOX_TESTS] += 8;
+        ordw = (mode == 0) ? order_children<0>(N, r) : order_children<1>(N, r);
+      }
+      // Unwind / descend: the tail of PrimitiveIntersectRay (octtree.cc:219-256)
+      int my_fc = fc;
+      unsigned pos = 0;
+      for (int guard = 0;; guard++) {
+        if (guard > S.tree_depth + 1) {  // cannot happen: one pop per level at most
+          cur = -2;
+          break;
+        }
+        const unsigned cnt = (ordw >> 24) & 15u;
+        if (pos < cnt) {
+          const int child = my_fc + (int)((ordw >> (3 * pos)) & 7u);
+          pos++;
+          if (depth >= S.tree_depth) {  // cannot happen: stack sized for the validated depth
+            cur = -2;
+            break;
+          }
+          const int at = depth * 64 + lane;
+          stk.fc[at] = my_fc;
+          stk.bt[at] = best_t;
+          stk.bp[at] = best;
+          stk.ord[at] = (ordw & 0x0fffffffu) | (pos << 28);
+          depth++;
+          cur = child;
+          break;
+        }
+        if (depth == 0) {
+          out_prim = best;
+          out_t = best_t;
+          cur = -1;
+          break;
+        }
+        depth--;
+        const int at = depth * 64 + lane;
+        const unsigned po = stk.ord[at];
+        int pbp = stk.bp[at];
+        double pbt = stk.bt[at];
+        my_fc = stk.fc[at];
+        pos = po >> 28;
+        ordw = po & 0x0fffffffu;
+        if (best >= 0 && !(pbp >= 0 && best_t > pbt)) {  // :233-246 take it and break
+          pbp = best;
+          pbt = best_t;
+          pos = (po >> 24) & 15u;
+        }
+        best = pbp;
+        best_t = pbt;
+      }
+    }
+    if (__ballot(cur == -2) != 0ull) {
+      status = DEV_ERR_UNWIND_BOUND;
+      break;
+    }
+  }
+  if (status != DEV_OK) {
+    out_prim = -1;
+    out_t = 0.0;
+  }
+  return status;
+}
+
+}  // namespace mt
