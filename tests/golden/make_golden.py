@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ by running the REFERENCE
+ITSELF (oracle/_ref/ref_driver, compiled from /root/reference/VerStarting by
+oracle/Makefile).  Run in the build container only:
+
+    make -C oracle ref && python tests/golden/make_golden.py [--big]
+
+Outputs are data only (inputs + what the reference returned): .npz archives
+(numpy, no pickle) and frames.json.  --big also renders the BASELINE-sized
+frames (about two minutes of CPU).
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import orclib  # noqa: E402
+from mythtracer_amd import scenegen  # noqa: E402
+import quirk_files  # noqa: E402
+
+CORNELL = os.path.join(ROOT, "tests", "scenes", "cornell_n.obj")
+CORNELL_CAM = (50, 50, -120, 0, 0, 0, 60)
+CORNELL_LIGHTS = [(50, 90, 50, .3, .3, .3, 1, 1, 1, 1, 1, 1)]
+# second camera: inside the box, rolled and pitched, two lights
+CORNELL_CAM2 = (20, 70, 10, 25, 35, 10, 95)
+CORNELL_LIGHTS2 = [(50, 90, 50, .2, .2, .2, .8, .8, .8, 1, 1, 1), (10, 20, 90, 0, 0, .1, .3, .3, .6, .2, .2, .2)]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def render_case(td, name, obj, W, H, cam, lights, chunk=None):
+    r = orclib.run_ref(os.path.join(td, name), obj, (W, H), chunk=chunk, cam=cam, lights=lights,
+                       want_debug=True)
+    assert r["returncode"] == 0, r["stderr"]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), rgb=r["rgb"], line=r["line"],
+                        point=r["point"], cam=np.array(cam, dtype=np.float64),
+                        lights=np.array(lights, dtype=np.float64),
+                        image=np.array([W, H], dtype=np.int32),
+                        chunk=np.array(chunk if chunk else (0, 0, W, H), dtype=np.int32))
+    print(name, r["rgb"].shape, sha(r["rgb"]))
+    return r
+
+
+def random_rays(seed, n, lo, hi):
+    rnd = scenegen.SplitMix64(seed)
+    rays = np.zeros((n, 6))
+    for i in range(n):
+        o = [rnd.rng(lo[k] - 30, hi[k] + 30) for k in range(3)]
+        t = [rnd.rng(lo[k], hi[k]) for k in range(3)]
+        d = np.array(t) - np.array(o)
+        d /= np.sqrt((d * d).sum())
+        rays[i, :3], rays[i, 3:] = o, d
+    return rays
+
+
+def special_rays():
+    """Axis-parallel directions (1/0 = inf), origins on box planes (0*inf = NaN),
+    negative zero components, rays starting inside, rays pointing away."""
+    rays = []
+    for o in [(50, 50, -120), (50, 50, 50), (0, 50, 50), (100, 100, 100), (50, 0, 50), (30, 1, 30),
+              (50, 50, 200), (-10, -10, -10), (50, 1, 50), (70, 1, 70)]:
+        for d in [(0, 0, 1), (0, 0, -1), (1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0),
+                  (0.0, 0.6, 0.8), (-0.0, 0.6, 0.8), (0.6, -0.0, 0.8), (0.6, 0.8, 0.0),
+                  (0.6, 0.8, -0.0), (-0.6, 0.0, -0.8)]:
+            rays.append(o + d)
+    return np.array(rays, dtype=np.float64)
+
+
+def ray_case(td, name, obj, rays):
+    r = orclib.run_ref(os.path.join(td, name), obj, rays=rays)
+    assert r["returncode"] == 0, r["stderr"]
+    out = r["rays"]
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), rays=rays, line=out["line"], t=out["t"],
+                        point=out["point"], normal=out["normal"], uvw=out["uvw"])
+    print(name, len(rays), "rays,", int((out["line"] >= 0).sum()), "hits")
+
+
+def sensor_case(td):
+    cams = [CORNELL_CAM, CORNELL_CAM2, scenegen.ROOM_CAMERA, (300.0, 107.0, 40.0, 30.0, 214.0, 0.0, 110.0),
+            (1.5, -2.25, 3.0, -90.0, 180.0, 45.0, 60.0)]
+    sizes = [(256, 256), (320, 180), (1920, 1080), (480, 270), (7, 5)]
+    out = {}
+    for i, (cam, (W, H)) in enumerate(zip(cams, sizes)):
+        # corners + centre + a few interior pixels, as 1x1 chunks
+        pix = [(0, 0), (W - 1, 0), (0, H - 1), (W - 1, H - 1), (W // 2, H // 2), (W // 3, (2 * H) // 3)]
+        dirs = []
+        for (x, y) in pix:
+            r = orclib.run_ref(os.path.join(td, "sensor"), CORNELL, (W, H), chunk=(x, y, 1, 1), cam=cam,
+                               want_rgb=False, want_sensor=True)
+            assert r["returncode"] == 0, r["stderr"]
+            dirs.append(r["sensor"][0, 0])
+        out["cam%d" % i] = np.array(cam, dtype=np.float64)
+        out["size%d" % i] = np.array([W, H], dtype=np.int32)
+        out["pix%d" % i] = np.array(pix, dtype=np.int32)
+        out["dir%d" % i] = np.array(dirs)
+    np.savez_compressed(os.path.join(HERE, "sensor_rays.npz"), **out)
+    print("sensor_rays", len(cams), "cameras")
+
+
+def quirk_cases(td):
+    """OBJ/MTL parser behaviours: for each small file, does LoadObj succeed and
+    what does a 24x24 render (with first-hit line numbers) look like."""
+    qdir = os.path.join(ROOT, "tests", "scenes", "quirks")
+    quirk_files.write_all(qdir)
+    res = {}
+    for name in quirk_files.NAMES:
+        obj = os.path.join(qdir, name + ".obj")
+        r = orclib.run_ref(os.path.join(td, "q_" + name), obj, (24, 24), cam=quirk_files.CAM,
+                           lights=quirk_files.LIGHTS, want_debug=True)
+        ok = r["returncode"] == 0
+        res["ok_" + name] = np.array([1 if ok else 0], dtype=np.int32)
+        if ok:
+            res["rgb_" + name] = r["rgb"]
+            res["line_" + name] = r["line"]
+        print("quirk", name, "loads" if ok else "FAILS to load",
+              "" if not ok else "lines hit: %s" % sorted(set(r["line"].reshape(-1).tolist())))
+    np.savez_compressed(os.path.join(HERE, "obj_quirks.npz"), **res)
+
+
+def big_frames(td):
+    scenes = os.path.join(td, "scenes")
+    frames = {}
+    fpath = os.path.join(HERE, "frames.json")
+    if os.path.exists(fpath):
+        frames = json.load(open(fpath))
+    for name, (W, H) in [("room_nomtl", (1280, 720)), ("room", (1920, 1080))]:
+        info = scenegen.write_scene(name, scenes)
+        r = orclib.run_ref(os.path.join(td, name + "_big"), info["obj"], (W, H), cam=scenegen.ROOM_CAMERA,
+                           lights=scenegen.ROOM_LIGHTS, want_debug=True)
+        assert r["returncode"] == 0, r["stderr"]
+        key = "%s_%dx%d_d5" % (name, W, H)
+        frames[key] = {"sha256": sha(r["rgb"]), "line_sha256": sha(r["line"].astype("<i4")),
+                       "seconds_reference_here": r["time"]["seconds"], "threads": r["time"]["threads"],
+                       "scene_sha256": info["sha256"]}
+        np.savez_compressed(os.path.join(HERE, key + "_sub16.npz"), rgb=r["rgb"][::16, ::16],
+                            line=r["line"][::16, ::16], point=r["point"][::16, ::16])
+        print(key, frames[key])
+    json.dump(frames, open(fpath, "w"), indent=1, sort_keys=True)
+
+
+def main():
+    assert orclib.have_ref(), "build the reference first: make -C oracle ref"
+    with tempfile.TemporaryDirectory() as td:
+        scenes = os.path.join(td, "scenes")
+        mini = scenegen.write_scene("mini", scenes)
+        mini_n = scenegen.write_scene("mini_nomtl", scenes)
+        render_case(td, "cornell_256", CORNELL, 256, 256, CORNELL_CAM, CORNELL_LIGHTS)
+        render_case(td, "cornell_cam2_96x64", CORNELL, 96, 64, CORNELL_CAM2, CORNELL_LIGHTS2)
+        render_case(td, "cornell_nolights_64", CORNELL, 64, 64, CORNELL_CAM, [])
+        render_case(td, "mini_320x180", mini["obj"], 320, 180, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS)
+        render_case(td, "mini_nomtl_320x180", mini_n["obj"], 320, 180, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS)
+        render_case(td, "mini_chunk_101x67", mini["obj"], 320, 180, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS,
+                    chunk=(37, 21, 101, 67))
+        render_case(td, "mini_1x1", mini["obj"], 320, 180, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS,
+                    chunk=(160, 90, 1, 1))
+        ray_case(td, "rays_cornell", CORNELL,
+                 np.concatenate([random_rays(11, 600, (0, 0, 0), (100, 100, 100)), special_rays()]))
+        ray_case(td, "rays_mini", mini["obj"], random_rays(12, 800, (0, 0, 0), (400, 250, 400)))
+        sensor_case(td)
+        quirk_cases(td)
+        room = scenegen.write_scene("room", scenes)
+        render_case(td, "room_240x135", room["obj"], 240, 135, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS)
+        ray_case(td, "rays_room", room["obj"], random_rays(13, 400, (0, 0, 0), (400, 250, 400)))
+        meta = {"mini": mini["sha256"], "mini_nomtl": mini_n["sha256"], "room": room["sha256"]}
+        json.dump(meta, open(os.path.join(HERE, "scene_hashes.json"), "w"), indent=1, sort_keys=True)
+        if "--big" in sys.argv:
+            big_frames(td)
+
+
+if __name__ == "__main__":
+    main()

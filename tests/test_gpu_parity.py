@@ -1,0 +1,372 @@
+"""Parity of the HIP path with the reference, on a real MI355X (-m gpu).
+
+Checker: golden vectors produced by the reference itself (tests/golden/) and
+the CPU oracle on the same inputs.  Bars: first-hit primitive, hit point,
+distance and all work counters BIT-EXACT; RGB8 within 1 LSB per channel —
+`pow` (mythtracer.cc:174) is the one operation whose GPU implementation (ocml)
+is not bit-identical to glibc's, every other operation is IEEE-exact fp64 in
+the reference's order.  In practice the frames come out identical; the tests
+print the differing-pixel count and fail above 0.01 %.
+"""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+
+import orclib
+from conftest import GOLDEN, CORNELL
+
+pytestmark = pytest.mark.gpu
+
+import mythtracer_amd as M  # noqa: E402
+from mythtracer_amd import binding, scenegen, tiling  # noqa: E402
+
+CORNELL_CAM = (50, 50, -120, 0, 0, 0, 60)
+CORNELL_LIGHTS = [(50, 90, 50, .3, .3, .3, 1, 1, 1, 1, 1, 1)]
+RAY_KEYS = ("rays_primary", "rays_secondary", "rays_shadow")
+ALL_KEYS = RAY_KEYS + ("box_tests", "node_visits", "tri_tests", "mt_tests", "shaded_hits")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _libs(native_libs):
+    assert M.hip_abi().device_count() >= 1, "no GPU visible: the HIP path cannot run"
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def assert_rgb_close(got, want, what=""):
+    """RGB tolerance: 1 LSB (pow), on at most 0.01 % of the pixels."""
+    d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+    n_diff = int((d != 0).any(axis=-1).sum())
+    print("%s: %d of %d pixels differ, max |diff| %d" % (what, n_diff, d.shape[0] * d.shape[1], int(d.max(initial=0))))
+    assert d.max(initial=0) <= 1, what
+    assert n_diff <= max(1, d.shape[0] * d.shape[1] // 10000), what
+
+
+RENDER_CASES = [("cornell_256", "cornell"), ("cornell_cam2_96x64", "cornell"),
+                ("cornell_nolights_64", "cornell"), ("mini_320x180", "mini"),
+                ("mini_nomtl_320x180", "mini_nomtl"), ("mini_chunk_101x67", "mini"),
+                ("mini_1x1", "mini"), ("room_240x135", "room")]
+
+
+@pytest.mark.parametrize("case,scene", RENDER_CASES)
+def test_facade_render_matches_reference_golden(case, scene, scenes):
+    """MythTracer::RayTrace(WorkChunk*) through the facade vs the reference's output."""
+    g = load(case)
+    m = M.MythTracer(scenes[scene])
+    m.set_lights(g["lights"].reshape(-1, 12))
+    W, H = (int(v) for v in g["image"])
+    r = m.render(g["cam"], W, H, chunk=tuple(int(v) for v in g["chunk"]), debug=True)
+    assert_rgb_close(r["rgb"], g["rgb"], case)
+    assert np.array_equal(r["line"], g["line"])
+    assert np.array_equal(r["point"], g["point"], equal_nan=True)
+
+
+@pytest.mark.parametrize("scene,size", [("cornell", (128, 96)), ("mini", (160, 90)), ("room", (96, 54))])
+def test_counters_equal_the_oracle(scene, size, scenes):
+    """Every IntersectRay / box / triangle / Möller–Trumbore evaluation the
+    reference performs is performed, no more, no less."""
+    W, H = size
+    cam, lights = (CORNELL_CAM, CORNELL_LIGHTS) if scene == "cornell" else (scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS)
+    m = M.MythTracer(scenes[scene])
+    m.set_lights(lights)
+    o = orclib.OracleScene(scenes[scene])
+    o.set_lights(lights)
+    g, r = m.render(cam, W, H, debug=True), o.render(cam, W, H, debug=True)
+    assert g["counters"] == r["counters"]
+    assert np.array_equal(g["line"], r["line"])
+    assert np.array_equal(g["point"], r["point"], equal_nan=True)
+    assert_rgb_close(g["rgb"], r["rgb"], scene)
+
+
+@pytest.mark.parametrize("chunk", [(0, 0, 1, 1), (159, 89, 1, 1), (3, 5, 7, 5), (150, 0, 10, 90),
+                                   (0, 80, 160, 10), (8, 8, 8, 8), (13, 27, 65, 33)])
+def test_ragged_chunks(chunk, scenes):
+    m = M.MythTracer(scenes["mini"])
+    m.set_lights(scenegen.ROOM_LIGHTS)
+    o = orclib.OracleScene(scenes["mini"])
+    o.set_lights(scenegen.ROOM_LIGHTS)
+    g = m.render(scenegen.ROOM_CAMERA, 160, 90, chunk=chunk, debug=True)
+    r = o.render(scenegen.ROOM_CAMERA, 160, 90, chunk=chunk, debug=True)
+    assert g["rgb"].shape == (chunk[3], chunk[2], 3)
+    assert_rgb_close(g["rgb"], r["rgb"], str(chunk))
+    assert np.array_equal(g["line"], r["line"]) and g["counters"] == r["counters"]
+
+
+def test_bad_chunks_are_rejected(scenes):
+    m = M.MythTracer(scenes["cornell"])
+    for chunk in [(-1, 0, 4, 4), (0, 0, 0, 4), (60, 60, 8, 8), (0, 0, 65, 1)]:
+        with pytest.raises(RuntimeError):
+            m.render(CORNELL_CAM, 64, 64, chunk=chunk)
+
+
+def test_image_overload(scenes):
+    """MythTracer::RayTrace(int, int, Camera*, vector*) == the full-frame chunk."""
+    m = M.MythTracer(scenes["cornell"])
+    m.set_lights(CORNELL_LIGHTS)
+    a = m.render_image(CORNELL_CAM, 96, 80)
+    b = m.render(CORNELL_CAM, 96, 80)["rgb"]
+    assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("case,scene", [("rays_cornell", "cornell"), ("rays_mini", "mini"), ("rays_room", "room")])
+def test_c_abi_intersect_rays_match_reference(case, scene, scenes):
+    """mt_scene_create + mt_intersect_rays called directly (no facade in
+    between) vs OctTree::IntersectRay of the reference, including axis-parallel
+    rays and origins on box planes (the NaN / infinity paths)."""
+    g = load(case)
+    abi = M.hip_abi()
+    flat = M.MythTracer(scenes[scene]).flatten()
+    h = abi.scene_create(flat)
+    try:
+        for mode in (0, 1, 2):
+            abi.set_traversal_mode(h, mode)
+            r = abi.intersect_rays(h, g["rays"])
+            assert np.array_equal(r["line"], g["line"]), mode
+            hit = g["line"] >= 0
+            assert np.array_equal(r["t"][hit], g["t"][hit]), mode
+            assert np.array_equal(r["point"][hit], g["point"][hit]), mode
+            assert np.isnan(r["t"][~hit]).all()
+    finally:
+        abi.scene_destroy(h)
+
+
+def test_c_abi_render_direct_and_modes(scenes):
+    """mt_render_chunk called directly; the three slab-test modes are
+    indistinguishable (image, debug buffer, counters)."""
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["mini"])
+    h = abi.scene_create(m.flatten())
+    try:
+        abi.set_lights(h, scenegen.ROOM_LIGHTS)
+        sens = binding.sensor(scenegen.ROOM_CAMERA, 200, 112)
+        base = None
+        for mode in (0, 1, 2, 0):
+            abi.set_traversal_mode(h, mode)
+            r = abi.render_chunk(h, sens, 200, 112, debug=True)
+            key = {k: r["stats"][k] for k in ALL_KEYS}
+            if base is None:
+                base = (r["rgb"], r["line"], r["point"], key)
+            else:
+                assert np.array_equal(r["rgb"], base[0]) and np.array_equal(r["line"], base[1])
+                assert np.array_equal(r["point"], base[2], equal_nan=True) and key == base[3]
+        o = orclib.OracleScene(scenes["mini"])
+        o.set_lights(scenegen.ROOM_LIGHTS)
+        w = o.render(scenegen.ROOM_CAMERA, 200, 112, debug=True)
+        assert_rgb_close(base[0], w["rgb"], "direct")
+        assert base[3] == w["counters"] and np.array_equal(base[1], w["line"])
+    finally:
+        abi.scene_destroy(h)
+
+
+@pytest.mark.parametrize("depth", [0, 1, 2, 4, 5, 7])
+def test_recursion_depth_parameter(depth, scenes):
+    m = M.MythTracer(scenes["mini"])
+    m.set_lights(scenegen.ROOM_LIGHTS)
+    m.set_max_level(depth)
+    o = orclib.OracleScene(scenes["mini"])
+    o.set_lights(scenegen.ROOM_LIGHTS)
+    g = m.render(scenegen.ROOM_CAMERA, 128, 72)
+    r = o.render(scenegen.ROOM_CAMERA, 128, 72, max_level=depth)
+    assert g["counters"] == r["counters"]
+    assert_rgb_close(g["rgb"], r["rgb"], "depth %d" % depth)
+
+
+def test_lights_are_reread_every_frame(scenes):
+    """main_local.cc:79-110 rewrites scene.lights before every frame."""
+    m = M.MythTracer(scenes["cornell"])
+    o = orclib.OracleScene(scenes["cornell"])
+    for lights in (CORNELL_LIGHTS, [], [(20, 50, 20, .1, .1, .1, .5, .5, .9, 1, 1, 1), (80, 80, 30, 0, 0, 0, .9, .2, .2, .3, .3, .3)],
+                   [CORNELL_LIGHTS[0]] * 9):
+        m.set_lights(lights)
+        o.set_lights(lights)
+        g, r = m.render(CORNELL_CAM, 64, 64), o.render(CORNELL_CAM, 64, 64)
+        assert g["counters"] == r["counters"]
+        assert_rgb_close(g["rgb"], r["rgb"], "%d lights" % len(lights))
+
+
+def _both():
+    return M.MythTracer(), orclib.OracleScene()
+
+
+def _render_both(m, o, cam, W, H, lights):
+    m.set_lights(lights)
+    o.set_lights(lights)
+    g, r = m.render(cam, W, H, debug=True), o.render(cam, W, H, debug=True)
+    assert g["counters"] == r["counters"]
+    assert np.array_equal(g["line"], r["line"])
+    assert np.array_equal(g["point"], r["point"], equal_nan=True)
+    assert_rgb_close(g["rgb"], r["rgb"])
+    return g
+
+
+def test_reference_octtree_test_scenario():
+    """VerStarting/octtree_test.cc:14-73 (with the CacheAABB call it forgot):
+    front ray -> tr0, back ray -> tr1, far-away ray -> nothing."""
+    m = M.MythTracer()
+    m.add_triangle([[1, 1, 0], [1, 0, 0], [0, 0, 0]], line_no=0)
+    m.add_triangle([[1, 1, 1], [1, 0, 1], [0, 0, 1]], line_no=1)
+    r = m.intersect([[0.9, 0.9, -10, 0, 0, 1], [0.9, 0.9, 10, 0, 0, -1], [5, 5, 5, 0, 0, 1]])
+    assert list(r["tri"]) == [0, 1, -1]
+    assert r["t"][0] == 10.0 and r["t"][1] == 9.0 and np.isnan(r["t"][2])
+
+
+def test_empty_scene():
+    m, o = _both()
+    g = _render_both(m, o, (0, 0, -5, 0, 0, 0, 60), 16, 16, CORNELL_LIGHTS)
+    assert not g["rgb"].any() and (g["line"] == -1).all()
+
+
+def test_ties_degenerates_and_missing_normals():
+    """Coincident triangles (equal distance: the LATER one wins, octtree.cc:186-195),
+    zero-area triangles (NaN normal -> NaN colour -> 0), triangles without
+    normals (N = 0), and more than 16 of them so that the tree splits."""
+    m, o = _both()
+    mats = [("a", (.8, .2, .2)), ("b", (.2, .8, .2)), ("c", (.2, .2, .8))]
+    for s in (m, o):
+        for name, c in mats:
+            s.add_material(name, c, c, (.3, .3, .3), ns=8)
+        n = [[0, 0, -1]] * 3
+        k = 0
+        for j in range(5):
+            for i in range(5):
+                quad = [[i * 2.0, j * 2.0, 5], [i * 2.0 + 2, j * 2.0, 5], [i * 2.0, j * 2.0 + 2, 5]]
+                s.add_triangle(quad, n, mtl=k % 3, line_no=k)
+                s.add_triangle(quad, n, mtl=(k + 1) % 3, line_no=100 + k)  # coincident twin
+                k += 1
+        s.add_triangle([[1, 1, 4], [1, 1, 4], [1, 1, 4]], n, mtl=0, line_no=900)      # a point
+        s.add_triangle([[2, 2, 3], [4, 4, 3], [3, 3, 3]], n, mtl=1, line_no=901)      # a segment
+        s.add_triangle([[6, 1, 4.5], [9, 1, 4.5], [6, 4, 4.5]], None, mtl=2, line_no=902)  # no normals
+        s.add_triangle([[1, 6, 4.5], [4, 6, 4.5], [1, 9, 4.5]], n, mtl=-1, line_no=903)    # no material
+    lights = [(5, 5, -8, .2, .2, .2, .8, .8, .8, .5, .5, .5)]
+    g = _render_both(m, o, (5, 5, -6, 0, 0, 0, 80), 96, 96, lights)
+    assert (g["line"] >= 100).any()  # twins are visible: the later coincident triangle won
+
+
+def test_transparency_shadow_loop_and_refraction():
+    """Stacked glass panes between the floor and the light: the shadow loop
+    walks through them (mythtracer.cc:94-156), light power decays below the
+    0.001 threshold behind enough panes, refraction recurses with in_object."""
+    m, o = _both()
+    for s in (m, o):
+        s.add_material("floor", (.7, .7, .7), (.7, .7, .7), (.1, .1, .1), ns=5, refl=0.3)
+        s.add_material("glass", (.05, .05, .05), (.05, .05, .05), (.6, .6, .6), ns=40, tr=0.25, tf=(.5, .6, .7), ni=1.5)
+        s.add_material("dark", (.05, .05, .05), (.05, .05, .05), (.6, .6, .6), ns=40, tr=0.02, tf=(.5, .5, .5), ni=1.5)
+        up = [[0, 1, 0]] * 3
+        k = 0
+        for (x0, z0) in [(-20, -20)]:
+            s.add_triangle([[x0, 0, z0], [x0 + 40, 0, z0], [x0, 0, z0 + 40]], up, mtl=0, line_no=k); k += 1
+            s.add_triangle([[x0 + 40, 0, z0 + 40], [x0, 0, z0 + 40], [x0 + 40, 0, z0]], up, mtl=0, line_no=k); k += 1
+        for i, y in enumerate([2, 3, 4, 5, 6, 7, 8, 9]):
+            mt_ = 1 if i < 6 else 2
+            w = 10 - i
+            s.add_triangle([[-w, y, -w], [w, y, -w], [-w, y, w]], up, mtl=mt_, line_no=k); k += 1
+            s.add_triangle([[w, y, w], [-w, y, w], [w, y, -w]], up, mtl=mt_, line_no=k); k += 1
+    lights = [(0, 30, 0, .1, .1, .1, 1, 1, 1, 1, 1, 1), (15, 6, -15, 0, 0, 0, .4, .4, .4, .2, .2, .2)]
+    g = _render_both(m, o, (0, 14, -30, 22, 0, 0, 70), 128, 96, lights)
+    assert g["counters"]["rays_shadow"] > 3 * g["counters"]["shaded_hits"]  # loops iterated
+    assert g["counters"]["rays_secondary"] > 0
+
+
+def test_materialless_occluder_is_opaque():
+    """The reference dereferences shadow_primitive->mtl unconditionally
+    (mythtracer.cc:121) and crashes when a material-less triangle shadows a
+    material'd one; product and oracle both define that occluder as opaque."""
+    m, o = _both()
+    for s in (m, o):
+        s.add_material("w", (.8, .8, .8), (.8, .8, .8), (0, 0, 0), ns=1)
+        up = [[0, 1, 0]] * 3
+        s.add_triangle([[-10, 0, -10], [10, 0, -10], [-10, 0, 10]], up, mtl=0, line_no=1)
+        s.add_triangle([[10, 0, 10], [-10, 0, 10], [10, 0, -10]], up, mtl=0, line_no=2)
+        s.add_triangle([[-2, 3, -2], [2, 3, -2], [-2, 3, 2]], up, mtl=-1, line_no=3)
+    g = _render_both(m, o, (0, 8, -14, 30, 0, 0, 60), 64, 48, [(0, 10, 0, .1, .1, .1, 1, 1, 1, 0, 0, 0)])
+    assert g["counters"]["rays_shadow"] > 0
+
+
+def test_textured_material():
+    """map_Ka path: GetUVW + Texture::GetColorAt on the device, RGB8 and f64
+    texels.  Checked against the oracle's restatement of texture.cc:11-58,
+    which is itself UNPINNED (texture.cc cannot be built without SDL2)."""
+    rnd = np.random.RandomState(5)
+    tex8 = rnd.randint(0, 256, size=(5, 7, 3)).astype(np.float64) / 255.0
+    texf = rnd.rand(4, 4, 3)
+    m, o = _both()
+    for s in (m, o):
+        a = s.add_material("a", (1, 1, 1), (.9, .9, .9), (.1, .1, .1), ns=3)
+        b = s.add_material("b", (.9, .8, .7), (.5, .5, .5), (0, 0, 0), ns=1)
+        s.set_material_texture(a, s.add_texture("t8", tex8))
+        s.set_material_texture(b, s.add_texture("tf", texf))
+        n = [[0, 0, -1]] * 3
+        s.add_triangle([[-6, -4, 0], [0, -4, 0], [-6, 4, 0]], n, [[-0.5, -0.5, 0], [1.5, 0, 0], [0, 2.5, 0]], mtl=a, line_no=1)
+        s.add_triangle([[0, -4, 0], [6, -4, 0], [0, 4, 0]], n, [[0, 0, 0], [1, 0, 0], [0, 1, 0]], mtl=b, line_no=2)
+    flat = m.flatten()
+    assert sorted(t["texels"].dtype.name for t in flat["textures"]) == ["float64", "uint8"]
+    _render_both(m, o, (0, 0, -8, 0, 0, 0, 80), 96, 64, [(0, 0, -6, .4, .4, .4, .7, .7, .7, .2, .2, .2)])
+
+
+def test_axis_aligned_camera_hits_the_nan_paths():
+    """Camera on a node plane looking straight down an axis: odd image size puts
+    the centre pixel's ray exactly on (0,0,1); 1/0 = inf and 0*inf = NaN in
+    the slab tests must behave as in the reference (exact mode)."""
+    m = M.MythTracer(CORNELL)
+    o = orclib.OracleScene(CORNELL)
+    _render_both(m, o, (50, 50, -100, 0, 0, 0, 60), 33, 33, CORNELL_LIGHTS)
+    _render_both(m, o, (50, 50, 50, 0, 90, 0, 90), 17, 17, CORNELL_LIGHTS)
+    _render_both(m, o, (0, 0, 0, 0, 45, 0, 90), 9, 9, CORNELL_LIGHTS)
+
+
+def test_big_frames_identical_to_reference(scenes):
+    """BASELINE.json sizes: 1280x720 primary-only and 1920x1080 with 3 lights;
+    sha256 of the whole frame + of the first-hit line buffer (reference run)."""
+    import hashlib
+    frames = json.load(open(os.path.join(GOLDEN, "frames.json")))
+    for key, scene, (W, H) in [("room_nomtl_1280x720_d5", "room_nomtl", (1280, 720)),
+                               ("room_1920x1080_d5", "room", (1920, 1080))]:
+        m = M.MythTracer(scenes[scene])
+        m.set_lights(scenegen.ROOM_LIGHTS)
+        g = m.render(scenegen.ROOM_CAMERA, W, H, debug=True)
+        sub = load(key + "_sub16")
+        assert np.array_equal(g["line"][::16, ::16], sub["line"])
+        assert np.array_equal(g["point"][::16, ::16], sub["point"], equal_nan=True)
+        assert_rgb_close(g["rgb"][::16, ::16], sub["rgb"], key)
+        assert hashlib.sha256(g["line"].astype("<i4").tobytes()).hexdigest() == frames[key]["line_sha256"]
+        sha = hashlib.sha256(g["rgb"].tobytes()).hexdigest()
+        print(key, "frame sha256", sha, "reference", frames[key]["sha256"], "kernel ms", g["kernel_ms"])
+        if sha != frames[key]["sha256"]:
+            pytest.xfail("frame differs from the reference in some pixels' last bit (pow); "
+                         "sub-sampled comparison above passed")
+
+
+def test_tiles_and_blit_equal_single_launch(scenes):
+    """mt_render_tiles_device + mt_blit_tiles_device: three virtual ranks on one
+    GPU reproduce the single-launch frame byte for byte (the multi-GPU path
+    minus the RCCL gather, which the gloo test covers)."""
+    import torch
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["mini"])
+    m.set_lights(scenegen.ROOM_LIGHTS)
+    h = m.device_scene()
+    abi.set_lights(h, scenegen.ROOM_LIGHTS)
+    W, H, T = 200, 120, 32
+    sens = binding.sensor(scenegen.ROOM_CAMERA, W, H)
+    single = m.render(scenegen.ROOM_CAMERA, W, H)["rgb"]
+    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    world = 3
+    for rank in range(world):
+        f, s, n = tiling.rank_tiles(W, H, T, T, rank, world)
+        slots = torch.zeros(n * tiling.slot_bytes(T, T), dtype=torch.uint8, device="cuda")
+        abi.render_tiles_device(h, sens, W, H, T, T, f, s, n, 5, ctypes.c_void_p(slots.data_ptr()))
+        abi.blit_tiles_device(h, W, H, T, T, f, s, n, ctypes.c_void_p(slots.data_ptr()),
+                              ctypes.c_void_p(frame.data_ptr()))
+    torch.cuda.synchronize()
+    abi.read_stats(h)
+    assert np.array_equal(frame.cpu().numpy(), single)
+
+
+def test_smoke_entry():
+    import __graft_entry__ as g
+    g.smoke()

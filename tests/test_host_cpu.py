@@ -1,0 +1,372 @@
+"""Host side of the product (C++ facade + C ABI), no GPU needed: OBJ/MTL
+parsing, octree construction, sensor set-up, wire formats, library symbols and
+error behaviour.  The oracle / golden vectors are the checker."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import orclib
+import quirk_files
+from conftest import GOLDEN, ROOT
+
+import mythtracer_amd as M
+from mythtracer_amd import binding, scenegen, tiling
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _libs(native_libs):
+    return native_libs
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """Every function include/mythtracer_hip.h declares is exported."""
+    hdr = open(os.path.join(ROOT, "include", "mythtracer_hip.h")).read()
+    import re
+    declared = set(re.findall(r"\b(mt_[a-z_]+)\s*\(", hdr))
+    declared -= {"mt_scene_desc", "mt_scene"}
+    assert declared == set(M.HIP_SYMBOLS), declared ^ set(M.HIP_SYMBOLS)
+    abi = M.hip_abi()
+    for name in M.HIP_SYMBOLS:
+        assert getattr(abi.lib, name) is not None
+    assert abi.lib.mt_abi_version() == binding.MT_ABI_VERSION
+
+
+def test_struct_layouts_match_the_header():
+    """ctypes mirrors == sizeof() in C (compiled on the fly with gcc)."""
+    src = r'''
+#include <stdio.h>
+#include "mythtracer_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(mt_material), sizeof(mt_light), sizeof(mt_texture),
+         sizeof(mt_sensor), sizeof(mt_debug_px), sizeof(mt_stats), sizeof(mt_scene_desc));
+  return 0;
+}'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", exe, c])
+        sizes = [int(v) for v in subprocess.check_output([exe]).split()]
+    want = [ctypes.sizeof(t) for t in (binding.mt_material, binding.mt_light, binding.mt_texture,
+                                       binding.mt_sensor)]
+    want += [binding.DEBUG_PX_DTYPE.itemsize, ctypes.sizeof(binding.mt_stats),
+             ctypes.sizeof(binding.mt_scene_desc)]
+    assert sizes == want
+
+
+def test_no_gpu_means_loud_failure_not_fallback(scenes):
+    """Without a usable device every product entry point fails with an error."""
+    abi = M.hip_abi()
+    if abi.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    m = M.MythTracer(scenes["cornell"])
+    with pytest.raises(RuntimeError):
+        m.prepare()
+    with pytest.raises(RuntimeError):
+        m.render((50, 50, -120, 0, 0, 0, 60), 8, 8)
+    with pytest.raises(RuntimeError):
+        m.intersect([[0, 0, 0, 0, 0, 1]])
+
+
+def test_scene_create_rejects_malformed_descriptions(scenes):
+    """Validation happens before any device work, so it is testable on CPU."""
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["mini"])
+    flat = m.flatten()
+
+    def expect_arg_error(mutate, needle):
+        f = dict(flat)
+        mutate(f)
+        with pytest.raises(RuntimeError) as e:
+            abi.scene_create(f)
+        assert needle in str(e.value), str(e.value)
+
+    def bad_child(f):
+        f["node_first_child"] = f["node_first_child"].copy()
+        f["node_first_child"][0] = len(f["node_first_child"]) - 3
+    expect_arg_error(bad_child, "first_child")
+
+    def bad_range(f):
+        f["node_prim_count"] = f["node_prim_count"].copy()
+        f["node_prim_count"][1] += 5
+    expect_arg_error(bad_range, "primitive")
+
+    def bad_material(f):
+        f["tri_material"] = f["tri_material"].copy()
+        f["tri_material"][3] = 99
+    expect_arg_error(bad_material, "material index")
+
+    def self_loop(f):
+        f["node_first_child"] = f["node_first_child"].copy()
+        f["node_first_child"][9] = 1
+    expect_arg_error(self_loop, "first_child")
+
+    d = binding.mt_scene_desc()
+    d.struct_size = 8
+    assert not abi.lib.mt_scene_create(ctypes.byref(d))
+    assert "mismatch" in abi.last_error()
+
+
+@pytest.mark.parametrize("scene", ["cornell", "mini", "mini_nomtl", "room"])
+def test_octree_and_triangles_equal_the_oracle(scene, scenes):
+    m = M.MythTracer(scenes[scene])
+    o = orclib.OracleScene(scenes[scene])
+    tm, to = m.tree(), o.tree()
+    assert tm["depth"] == to["depth"]
+    for k in ("aabb", "first_child", "prim_begin", "prim_count", "prim_ids"):
+        assert np.array_equal(tm[k], to[k]), k
+    split = tm["first_child"] > 0
+    assert np.array_equal(tm["center"][split], to["center"][split])
+    dm, lm, hm = m.triangles()
+    do, mo, lo = o.triangles()
+    assert np.array_equal(dm, do) and np.array_equal(lm, lo)
+    assert np.array_equal(hm, (mo >= 0).astype(np.int32))
+    assert np.array_equal(m.root_aabb(), o.root_aabb())
+    # materials by name
+    for name, vals, tex in o.materials():
+        got = m.get_material(name)
+        assert got is not None and np.array_equal(got[0], vals) and got[1] == (tex >= 0)
+    # the flattened streams are the triangles in node-stream order
+    f = m.flatten()
+    assert np.array_equal(f["tri_vertex"], dm[tm["prim_ids"], 0:9])
+    assert np.array_equal(f["tri_aabb"], dm[tm["prim_ids"], 27:33])
+    assert np.array_equal(f["tri_line_no"], lm[tm["prim_ids"]])
+
+
+def test_root_box_always_contains_the_origin():
+    """OctTree's root box starts as {0,0,0}-{0,0,0} and only grows (octtree.cc:8-14)."""
+    m = M.MythTracer()
+    m.add_triangle([[5, 5, 5], [6, 5, 5], [5, 6, 5]])
+    assert np.array_equal(m.root_aabb(), [0, 0, 0, 6, 6, 5])
+    o = orclib.OracleScene()
+    o.add_triangle([[5, 5, 5], [6, 5, 5], [5, 6, 5]])
+    assert np.array_equal(o.root_aabb(), m.root_aabb())
+
+
+def test_split_boundary_and_straddlers():
+    """15 triangles stay in the root, 16 split; a straddler stays in the parent;
+    coincident triangles all go down together (no depth cap in the reference)."""
+    def grid(n):
+        tris = []
+        for i in range(n):
+            x = 1.0 + i
+            tris.append([[x, 1, 1], [x + 0.5, 1, 1], [x, 1.5, 1]])
+        return tris
+    for n, expect_split in ((15, False), (16, True)):
+        m, o = M.MythTracer(), orclib.OracleScene()
+        for t in grid(n):
+            m.add_triangle(t)
+            o.add_triangle(t)
+        tm, to = m.tree(), o.tree()
+        assert (tm["first_child"][0] != 0) == expect_split
+        for k in ("first_child", "prim_begin", "prim_count", "prim_ids", "aabb"):
+            assert np.array_equal(tm[k], to[k])
+    m, o = M.MythTracer(), orclib.OracleScene()
+    for t in grid(20) + [[[0.5, 0.5, 0.5], [20, 0.5, 0.5], [0.5, 1.4, 0.9]]] + [[[3, 1, 1], [3.25, 1, 1], [3, 1.25, 1]]] * 18:
+        m.add_triangle(t)
+        o.add_triangle(t)
+    tm, to = m.tree(), o.tree()
+    assert tm["depth"] == to["depth"] and tm["depth"] >= 3
+    for k in ("first_child", "prim_begin", "prim_count", "prim_ids", "aabb"):
+        assert np.array_equal(tm[k], to[k])
+    assert 20 in tm["prim_ids"][:tm["prim_count"][0]]  # the straddler stayed at the root
+
+
+def test_sensor_matches_reference_vectors():
+    g = np.load(os.path.join(GOLDEN, "sensor_rays.npz"), allow_pickle=False)
+    i = 0
+    while "cam%d" % i in g:
+        W, H = (int(v) for v in g["size%d" % i])
+        cam = g["cam%d" % i]
+        assert np.array_equal(binding.sensor(cam, W, H), orclib.sensor(cam, W, H))
+        for (x, y), want in zip(g["pix%d" % i], g["dir%d" % i]):
+            assert np.array_equal(binding.sensor_ray(cam, W, H, int(x), int(y)), want)
+        i += 1
+
+
+@pytest.mark.parametrize("name", quirk_files.NAMES)
+def test_obj_reader_quirks(name, quirk_dir):
+    """Same accept/reject decisions as the reference (golden), same triangles as
+    the oracle (which is pinned to the reference's renders of these files)."""
+    g = np.load(os.path.join(GOLDEN, "obj_quirks.npz"), allow_pickle=False)
+    path = os.path.join(quirk_dir, name + ".obj")
+    m = M.MythTracer()
+    ok = m.load_obj(path)
+    assert int(ok) == int(g["ok_" + name][0])
+    if ok:
+        o = orclib.OracleScene(path)
+        dm, lm, hm = m.triangles()
+        do, mo, lo = o.triangles()
+        assert np.array_equal(dm, do) and np.array_equal(lm, lo)
+        assert np.array_equal(hm, (mo >= 0).astype(np.int32))
+        for mname, vals, tex in o.materials():
+            got = m.get_material(mname)
+            assert got is not None and np.array_equal(got[0], vals)
+
+
+def test_missing_file_and_bounds(tmp_path):
+    m = M.MythTracer()
+    assert not m.load_obj(str(tmp_path / "nope.obj"))
+    p = tmp_path / "oob.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 7 \n")
+    assert not M.MythTracer().load_obj(str(p))  # reference: undefined behaviour; here: an error
+    assert not orclib.OracleScene().load_obj(str(p))
+
+
+def test_texture_loaders(tmp_path):
+    """PPM / BMP / TGA decode to byte/255.0 texels, rows top to bottom."""
+    rgb = (np.arange(2 * 3 * 3) * 13 % 256).astype(np.uint8).reshape(2, 3, 3)
+    ppm = tmp_path / "t.ppm"
+    ppm.write_bytes(b"P6\n# c\n3 2\n255\n" + rgb.tobytes())
+    bmp = tmp_path / "t.bmp"
+    row = lambda y: rgb[y, :, ::-1].tobytes() + b"\0" * ((4 - 9 % 4) % 4)
+    pix = row(1) + row(0)
+    hdr = (b"BM" + (54 + len(pix)).to_bytes(4, "little") + b"\0\0\0\0" + (54).to_bytes(4, "little") +
+           (40).to_bytes(4, "little") + (3).to_bytes(4, "little") + (2).to_bytes(4, "little") +
+           (1).to_bytes(2, "little") + (24).to_bytes(2, "little") + b"\0" * 24)
+    bmp.write_bytes(hdr + pix)
+    tga = tmp_path / "t.tga"
+    tga.write_bytes(bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 3, 0, 2, 0, 24, 0x20]) + rgb[:, :, ::-1].tobytes())
+    for f in (ppm, bmp, tga):
+        (tmp_path / "m.mtl").write_text("newmtl a\nKa 1 1 1\nmap_Ka %s\n" % f.name)
+        (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nusemtl a\nf 1/1 2/1 3/1 \n")
+        m = M.MythTracer(str(tmp_path / "m.obj"))
+        fl = m.flatten()
+        assert len(fl["textures"]) == 1
+        tex = fl["textures"][0]["texels"]
+        assert tex.dtype == np.uint8 and np.array_equal(tex, rgb), f.name
+    (tmp_path / "m.mtl").write_text("newmtl a\nmap_Ka missing.ppm\n")
+    assert not M.MythTracer().load_obj(str(tmp_path / "m.obj"))
+
+
+def test_wire_formats():
+    """WorkChunk / Camera (de)serialisation, mythtracer.cc:314-429, camera.cc:71-96."""
+    L = M.host_lib()
+    f6 = np.array([1920, 1080, 128, 256, 128, 128], dtype=np.int32)
+    buf = np.zeros(24, dtype=np.uint8)
+    assert L.mth_chunk_serialize_input(f6.ctypes.data, buf.ctypes.data) == 24
+    assert buf.tobytes() == f6.astype("<u4").tobytes()
+    back = np.zeros(6, dtype=np.int32)
+    assert L.mth_chunk_deserialize_input(buf.ctypes.data, 24, back.ctypes.data) == 1
+    assert np.array_equal(back, f6)
+    bad = [[0, 10, 0, 0, 1, 1], [10, 10, 0, 0, 0, 1], [10, 10, 5, 5, 6, 1], [100001, 10, 0, 0, 1, 1],
+           [10, 10, 11, 0, 1, 1], [10, 10, 0, 0, 11, 1]]
+    for b in bad:
+        raw = np.array(b, dtype="<u4").view(np.uint8)
+        assert L.mth_chunk_deserialize_input(raw.ctypes.data, 24, back.ctypes.data) == 0, b
+    assert L.mth_chunk_deserialize_input(buf.ctypes.data, 23, back.ctypes.data) == 0
+    rgb = (np.arange(5 * 3 * 3) % 251).astype(np.uint8)
+    packet = np.zeros(4 + rgb.size, dtype=np.uint8)
+    out = np.zeros(rgb.size, dtype=np.uint8)
+    n = L.mth_chunk_output_roundtrip(5, 3, rgb.ctypes.data, rgb.size, packet.ctypes.data, packet.size,
+                                     out.ctypes.data)
+    assert n == 4 + rgb.size and np.array_equal(out, rgb)
+    assert packet[:4].view("<u4")[0] == rgb.size and np.array_equal(packet[4:], rgb)
+    assert L.mth_chunk_deserialize_output(5, 4, packet.ctypes.data, n) == 0   # size mismatch
+    assert L.mth_chunk_deserialize_output(5, 3, packet.ctypes.data, 3) == 0   # shorter than the header
+    cam = np.array([300.0, 107.0, 40.0, 30.0, 214.0, 0.0, 110.0])
+    blob = np.zeros(56, dtype=np.uint8)
+    back7 = np.zeros(7)
+    assert L.mth_camera_roundtrip(cam.ctypes.data, blob.ctypes.data, back7.ctypes.data) == 56
+    assert blob.tobytes() == cam.tobytes() and np.array_equal(back7, cam)
+
+
+def test_tile_bookkeeping_matches_generatework():
+    """tiling.* reproduces main_net_master.cc:195-221 (row-major 128x128
+    chunks, clipped at the right/bottom edge) and BlitWorkChunk."""
+    W, H, T = 480, 270, 128
+    tx, ty = tiling.tile_grid(W, H, T, T)
+    assert (tx, ty) == (4, 3)
+    rects = [tiling.tile_rect(k, W, H, T, T) for k in range(tx * ty)]
+    want = []
+    for j in range(0, H, T):
+        for i in range(0, W, T):
+            want.append((i, j, min(T, W - i), min(T, H - j)))
+    assert rects == want
+    for world in (1, 2, 3, 5, 8, 16):
+        seen = []
+        for r in range(world):
+            f, s, n = tiling.rank_tiles(W, H, T, T, r, world)
+            seen += [f + j * s for j in range(n)]
+        assert sorted(seen) == list(range(tx * ty))
+    img = np.zeros((H, W, 3), dtype=np.uint8)
+    ref = (np.arange(H * W * 3) % 253).astype(np.uint8).reshape(H, W, 3)
+    for r in range(3):
+        f, s, n = tiling.rank_tiles(W, H, T, T, r, 3)
+        slots = np.zeros(n * tiling.slot_bytes(T, T), dtype=np.uint8)
+        for j in range(n):
+            x, y, cw, ch = tiling.tile_rect(f + j * s, W, H, T, T)
+            slots[j * T * T * 3: j * T * T * 3 + cw * ch * 3] = ref[y:y + ch, x:x + cw].reshape(-1)
+        tiling.blit_tiles(img, slots, T, T, f, s, n)
+    assert np.array_equal(img, ref)
+
+
+def _compile(tmp_path, src_name, text, extra=()):
+    src = tmp_path / src_name
+    src.write_text(text)
+    exe = tmp_path / (src_name + ".exe")
+    inc = os.path.join(ROOT, "mythtracer_amd", "host", "include")
+    lib = os.path.join(ROOT, "mythtracer_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", inc, "-I", os.path.join(ROOT, "include"),
+                           "-o", str(exe), str(src), "-L", lib, "-lmythtracer_host", "-lmythtracer_hip",
+                           "-Wl,-rpath," + lib] + list(extra))
+    return exe
+
+
+def test_math3d_known_answers(tmp_path):
+    """The V3D known answers the reference's own unit test checks
+    (VerStarting/math3d_test.cc:13-89), as a real asserting program against
+    OUR math3d.h."""
+    text = r'''
+#include <cassert>
+#include <cmath>
+#include "math3d.h"
+using math3d::V3D;
+static bool eq(double a, double b) { return std::fabs(a - b) < 1e-7; }
+static bool veq(V3D a, V3D b) { return eq(a.v[0], b.v[0]) && eq(a.v[1], b.v[1]) && eq(a.v[2], b.v[2]); }
+int main() {
+  V3D a{1.0, 2.0, 3.0}, b;
+  assert(veq(b, V3D{0, 0, 0}));
+  b.x() = 4.0; b.y() = 5.0; b.z() = 6.0;
+  V3D c(a); c = b; assert(veq(c, V3D{4, 5, 6}));
+  c = a; assert(veq(c += a, V3D{2, 4, 6}));
+  c = a; assert(veq(c -= a, V3D{0, 0, 0}));
+  c = a; assert(veq(c *= a, V3D{1, 4, 9}));
+  c = a; assert(veq(c /= a, V3D{1, 1, 1}));
+  c = a; assert(veq(c *= 3.0, V3D{3, 6, 9}));
+  c = a;
+  assert(veq(c + a, V3D{2, 4, 6}) && veq(c - a, V3D{0, 0, 0}) && veq(c * a, V3D{1, 4, 9}) && veq(c / a, V3D{1, 1, 1}));
+  assert(veq(-c, V3D{-1, -2, -3}) && veq(+c, V3D{1, 2, 3}));
+  assert(eq((V3D{1, 0, 0}).Length(), 1.0) && eq((V3D{0, 0, 1}).SqrLength(), 1.0));
+  c = V3D{1, 2, 3};
+  assert(eq(c.Length(), 3.7416573867739413) && eq(c.SqrLength(), 14.0));
+  a = V3D{1, 1, 1}; b = V3D{2, 2, 2};
+  assert(eq(a.Distance(b), b.Distance(a)) && eq(a.Distance(b), 1.7320508075688772));
+  a = V3D{1, 2, 3}; b = V3D{5, 4, 3};
+  assert(eq(a.Dot(b), 22.0) && eq(a.Dot(b), b.Dot(a)));
+  assert(veq(a.Cross(b), V3D{-6, 12, -6}) && veq(b.Cross(a), V3D{6, -12, 6}));
+  b = a; a.Norm();
+  assert(veq(a, V3D{0.2672612419124, 0.5345224838248, 0.8017837257372}) && veq(b.DupNorm(), a));
+  assert(eq(math3d::Deg2Rad(180.0), M_PI));
+  math3d::M4D rx = math3d::M4D::RotationXDeg(90.0);
+  V3D r = rx * V3D{0, 1, 0};
+  assert(veq(r, V3D{0, 0, 1}));
+  return 0;
+}'''
+    exe = _compile(tmp_path, "m3d.cc", text)
+    subprocess.check_call([str(exe)])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/VerStarting"), reason="reference tree not present")
+def test_reference_drivers_compile_against_our_headers(tmp_path):
+    """Drop-in check: the reference's own drivers build, unmodified, against the
+    facade headers (syntax + semantic check only; nothing from them is linked or run)."""
+    inc = os.path.join(ROOT, "mythtracer_amd", "host", "include")
+    for drv in ("main_local.cc",):
+        subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", inc,
+                               "/root/reference/VerStarting/" + drv])
