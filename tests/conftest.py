@@ -14,6 +14,15 @@ CORNELL = os.path.join(ROOT, "tests", "scenes", "cornell_n.obj")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch ships its own copy of the HIP runtime.  If libmythtracer_hip.so pulls
+    # in /opt/rocm's first, torch.cuda later reports "No HIP GPUs": let torch
+    # initialise the runtime first whenever it is going to be used at all
+    # (tests only; the product libraries do not depend on torch).
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
