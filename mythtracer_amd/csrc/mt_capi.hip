@@ -154,6 +154,14 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (rc != MT_OK) return rc;
   }
   P.frames = s->d_frames;
+  P.item_cycles = nullptr;
+  unsigned long long *d_item = nullptr;
+  const char *item_dump = getenv("MT_DEBUG_ITEM_CYCLES");
+  if (item_dump && P.n_items > 0) {
+    HIP_TRY(hipMalloc((void **)&d_item, (size_t)P.n_items * 16));
+    HIP_TRY(hipMemset(d_item, 0, (size_t)P.n_items * 16));
+    P.item_cycles = d_item;
+  }
   HIP_TRY(hipMemsetAsync(s->d_work, 0, sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
@@ -163,6 +171,15 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     hipLaunchKernelGGL(render_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
   }
   HIP_TRY(hipGetLastError());
+  if (d_item) {  // debug: dump per-item durations (synchronises!)
+    std::vector<unsigned long long> host((size_t)P.n_items * 2);
+    HIP_TRY(hipMemcpy(host.data(), d_item, host.size() * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d_item));
+    if (FILE *f = fopen(item_dump, "wb")) {
+      fwrite(host.data(), 8, host.size(), f);
+      fclose(f);
+    }
+  }
   if (s->hb_host) {
     // Debug mode: watch the launch from the host and report where it is stuck.
     const auto t0 = std::chrono::steady_clock::now();

@@ -89,6 +89,7 @@ struct RenderParams {
   unsigned long long *counters;  // ST_COUNT
   unsigned int *work_counter;
   double *frames;          // recursion frames scratch
+  unsigned long long *item_cycles;  // debug (MT_DEBUG_ITEM_CYCLES): s_memtime ticks per work item
 };
 
 // Bytes of LDS one wave needs for its traversal stack.

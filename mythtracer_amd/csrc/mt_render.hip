@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene S, RenderParams P)
     }
     if (item >= P.n_items) break;
 
+    const unsigned long long item_t0 = P.item_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
     // work item -> tile slot j, 8x8 block (bx, by) inside the tile
     const int j = (int)(item / (unsigned)items_per_tile);
     const int b = (int)(item % (unsigned)items_per_tile);
@@ -342,6 +343,10 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene S, RenderParams P)
     }
 
     if (S.hb && lane == 0) S.hb[wave_id * 4 + 0] = 4;
+    if (P.item_cycles && lane == 0) {
+      P.item_cycles[(size_t)item * 2] = __builtin_amdgcn_s_memtime() - item_t0;
+      P.item_cycles[(size_t)item * 2 + 1] = ((unsigned long long)passes << 32) | st.wave_tri_steps;
+    }
     if (STATS) {  // one atomic per counter per work item (64 pixels)
       for (int i = 0; i < ST_WAVE_NODE_STEPS; i++) {
         const unsigned s = wave_sum_u32(st.v[i]);

@@ -190,76 +190,128 @@ __device__ __forceinline__ void flush_candidates(const DevScene &S, const RayReg
 }
 
 // Slab pre-filter of Triangle::IntersectRay (primitive_triangle.cc:83-108) for
-// one wave-uniform box `a` (min xyz, max xyz) against each lane's ray.
-template <int MODE>
-__device__ __forceinline__ bool slab_pass(const double (&a)[6], const RayRegs &r, bool sx, bool sy,
-                                          bool sz) {
+// one wave-uniform box a[0..5] (min xyz, max xyz) against each lane's ray.
+// MODE 2: OCT = compile-time sign octant (bit0 x, bit1 y, bit2 z negative).
+// Returns the WAVE MASK of lanes whose ray passes (v_cmp straight into an
+// SGPR pair; inactive lanes read 0), so that the common "nobody passed" case
+// costs no vector instruction beyond the two compares.
+template <int MODE, int OCT>
+__device__ __forceinline__ unsigned long long slab_pass(const double *a, const RayRegs &r) {
+  constexpr int kOGE = 3, kOLE = 5, kUGE = 11, kULE = 13;  // llvm FCmp predicates
   constexpr bool EX = (MODE == 0);
   if constexpr (MODE == 2) {
     // near/far plane per axis picked by the (wave-uniform) direction sign
-    const double nx = sx ? a[3] : a[0], fx = sx ? a[0] : a[3];
-    const double ny = sy ? a[4] : a[1], fy = sy ? a[1] : a[4];
-    const double nz = sz ? a[5] : a[2], fz = sz ? a[2] : a[5];
-    const double tnx = (nx - r.ox) * r.ix, tfx = (fx - r.ox) * r.ix;
-    const double tny = (ny - r.oy) * r.iy, tfy = (fy - r.oy) * r.iy;
-    const double tnz = (nz - r.oz) * r.iz, tfz = (fz - r.oz) * r.iz;
+    constexpr int NX = (OCT & 1) ? 3 : 0, FX = (OCT & 1) ? 0 : 3;
+    constexpr int NY = (OCT & 2) ? 4 : 1, FY = (OCT & 2) ? 1 : 4;
+    constexpr int NZ = (OCT & 4) ? 5 : 2, FZ = (OCT & 4) ? 2 : 5;
+    const double tnx = (a[NX] - r.ox) * r.ix, tfx = (a[FX] - r.ox) * r.ix;
+    const double tny = (a[NY] - r.oy) * r.iy, tfy = (a[FY] - r.oy) * r.iy;
+    const double tnz = (a[NZ] - r.oz) * r.iz, tfz = (a[FZ] - r.oz) * r.iz;
     const double tmax = __builtin_fmin(__builtin_fmin(tfx, tfy), tfz);
     const double tmin = __builtin_fmax(__builtin_fmax(tnx, tny), tnz);
     // no NaN can occur in this mode, so this equals !(tmax < 0) && !(tmin > tmax)
-    return (tmax >= 0.0) & (tmin <= tmax);
+    return __builtin_amdgcn_fcmp(tmax, 0.0, kOGE) & __builtin_amdgcn_fcmp(tmin, tmax, kOLE);
   } else {
     const double t1 = (a[0] - r.ox) * r.ix, t2 = (a[3] - r.ox) * r.ix;
     const double t3 = (a[1] - r.oy) * r.iy, t4 = (a[4] - r.oy) * r.iy;
     const double t5 = (a[2] - r.oz) * r.iz, t6 = (a[5] - r.oz) * r.iz;
     const double tmax = mn3<EX>(mx<EX>(t1, t2), mx<EX>(t3, t4), mx<EX>(t5, t6));
     const double tmin = mx3<EX>(mn<EX>(t1, t2), mn<EX>(t3, t4), mn<EX>(t5, t6));
-    if constexpr (EX) return !(tmax < 0.0) && !(tmin > tmax);
-    else return (tmax >= 0.0) & (tmin <= tmax);
+    if constexpr (EX) {  // !(tmax < 0) && !(tmin > tmax), NaN-aware: "unordered or ..."
+      return __builtin_amdgcn_fcmp(tmax, 0.0, kUGE) & __builtin_amdgcn_fcmp(tmin, tmax, kULE);
+    } else {
+      return __builtin_amdgcn_fcmp(tmax, 0.0, kOGE) & __builtin_amdgcn_fcmp(tmin, tmax, kOLE);
+    }
+  }
+}
+
+// A zero that the compiler must treat as depending on `v` (an SGPR value that
+// came from a scalar load).  Added to the address of the NEXT scalar load it
+// forces "wait for the pair in flight, THEN issue the next fetch": scalar
+// loads return out of order, so only s_waitcnt lgkmcnt(0) exists, and a fetch
+// issued before that wait would be waited for as well (no overlap at all).
+__device__ __forceinline__ long after_arrival_of(double v) {
+  long z;
+  asm volatile("s_mov_b64 %0, 0" : "=s"(z) : "s"(v));
+  return z;
+}
+
+__device__ __forceinline__ void load_pair(double (&b)[12], const MT_CONST double *p) {
+#pragma unroll
+  for (int i = 0; i < 12; i++) b[i] = p[i];
+}
+
+// Evaluates the two boxes of `b` (stream positions k, k+1 of the node) for the
+// calling lanes and parks / resolves the candidates in stream order.
+template <int MODE, int OCT, bool STATS>
+__device__ __forceinline__ void scan_pair(const DevScene &S, const RayRegs &r, const double (&b)[12],
+                                          int pb, int k, int pc, int &pend,
+                                          unsigned long long &pmask, int &best, double &best_t,
+                                          LaneStats &st) {
+  const unsigned long long pm0 = slab_pass<MODE, OCT>(&b[0], r);
+  const unsigned long long pm1 = (k + 1 < pc) ? slab_pass<MODE, OCT>(&b[6], r) : 0ull;
+  if (pm0 | pm1) {
+    const unsigned long long me = 1ull << (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+    const bool pass0 = (pm0 & me) != 0, pass1 = (pm1 & me) != 0;
+    if (pm0 & pmask) {  // some lane would need a second slot: resolve first
+      flush_candidates<STATS>(S, r, pend, best, best_t, st);
+      pmask = 0;
+    }
+    if (pass0) pend = pb + k;
+    pmask |= pm0;
+    if (pm1 & pmask) {
+      flush_candidates<STATS>(S, r, pend, best, best_t, st);
+      pmask = 0;
+    }
+    if (pass1) pend = pb + k + 1;
+    pmask |= pm1;
   }
 }
 
 // Scans the triangle list [pb, pb+pc) of one node for the calling lanes.
-// MODE: 0 exact, 1 regular, 2 octant-uniform (sx/sy/sz = shared sign bits).
-// Two boxes per step; the next pair is fetched (scalar loads) while the
-// current one is evaluated.  The box stream is padded by two boxes at its end
-// so the look-ahead never leaves the allocation.
-template <int MODE, bool STATS>
+// MODE: 0 exact, 1 regular, 2 octant-uniform (OCT = the shared sign octant).
+// Boxes are consumed in pairs from two SGPR buffers: while one pair is being
+// evaluated the next one is in flight (scalar loads).  The box stream is
+// padded at its end so the look-ahead never leaves the allocation.
+template <int MODE, int OCT, bool STATS>
 __device__ __forceinline__ void scan_node_prims(const DevScene &S, const RayRegs &r, int pb,
-                                                int pc, int sx, int sy, int sz, int &best,
-                                                double &best_t, LaneStats &st) {
-  const MT_CONST double *boxes = as_const(S.tri_aabb) + (size_t)pb * 6;
+                                                int pc, int &best, double &best_t,
+                                                LaneStats &st) {
+  const MT_CONST double *p = as_const(S.tri_aabb) + (size_t)pb * 6;
   int pend = -1;
   unsigned long long pmask = 0;  // lanes holding a parked candidate
-  double cur0[6], cur1[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) { cur0[i] = boxes[i]; cur1[i] = boxes[6 + i]; }
-  for (int k = 0; k < pc; k += 2) {
-    double nxt0[6], nxt1[6];
-    const MT_CONST double *nb = boxes + (size_t)(k + 2) * 6;
-#pragma unroll
-    for (int i = 0; i < 6; i++) { nxt0[i] = nb[i]; nxt1[i] = nb[6 + i]; }
-    const bool pass0 = slab_pass<MODE>(cur0, r, sx, sy, sz);
-    const bool pass1 = slab_pass<MODE>(cur1, r, sx, sy, sz) && (k + 1 < pc);
-    const unsigned long long pm0 = __ballot(pass0);
-    const unsigned long long pm1 = __ballot(pass1);
-    if (pm0 | pm1) {
-      if (pm0 & pmask) {  // some lane would need a second slot: resolve first
-        flush_candidates<STATS>(S, r, pend, best, best_t, st);
-        pmask = 0;
-      }
-      if (pass0) pend = pb + k;
-      pmask |= pm0;
-      if (pm1 & pmask) {
-        flush_candidates<STATS>(S, r, pend, best, best_t, st);
-        pmask = 0;
-      }
-      if (pass1) pend = pb + k + 1;
-      pmask |= pm1;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) { cur0[i] = nxt0[i]; cur1[i] = nxt1[i]; }
+  double A[12], B[12];
+  load_pair(A, p);
+  for (int k = 0; k < pc;) {
+    load_pair(B, p + 12 + after_arrival_of(A[11]));
+    __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead of the evaluation
+    scan_pair<MODE, OCT, STATS>(S, r, A, pb, k, pc, pend, pmask, best, best_t, st);
+    k += 2;
+    if (k >= pc) break;
+    p += 24;
+    load_pair(A, p + after_arrival_of(B[11]));
+    __builtin_amdgcn_sched_barrier(0);
+    scan_pair<MODE, OCT, STATS>(S, r, B, pb, k, pc, pend, pmask, best, best_t, st);
+    k += 2;
   }
   if (pmask) flush_candidates<STATS>(S, r, pend, best, best_t, st);
+}
+
+// Octant dispatch for mode 2 (eight specialised loops: the near/far planes
+// become fixed registers instead of scalar selects).
+template <bool STATS>
+__device__ __forceinline__ void scan_node_octant(const DevScene &S, const RayRegs &r, int pb, int pc,
+                                                 int oct, int &best, double &best_t, LaneStats &st) {
+  switch (oct) {
+    case 0: scan_node_prims<2, 0, STATS>(S, r, pb, pc, best, best_t, st); break;
+    case 1: scan_node_prims<2, 1, STATS>(S, r, pb, pc, best, best_t, st); break;
+    case 2: scan_node_prims<2, 2, STATS>(S, r, pb, pc, best, best_t, st); break;
+    case 3: scan_node_prims<2, 3, STATS>(S, r, pb, pc, best, best_t, st); break;
+    case 4: scan_node_prims<2, 4, STATS>(S, r, pb, pc, best, best_t, st); break;
+    case 5: scan_node_prims<2, 5, STATS>(S, r, pb, pc, best, best_t, st); break;
+    case 6: scan_node_prims<2, 6, STATS>(S, r, pb, pc, best, best_t, st); break;
+    default: scan_node_prims<2, 7, STATS>(S, r, pb, pc, best, best_t, st); break;
+  }
 }
 
 // Child slab tests + ordering of the hit children, octtree.cc:204-216.
@@ -451,9 +503,9 @@ __device__ __forceinline__ int trace_wave(const DevScene &S, const WaveStack &st
         st.v[ST_NODE_VISITS]++;
         st.v[ST_TRI_TESTS] += (unsigned)pc;
       }
-      if (mode == 2) scan_node_prims<2, STATS>(S, r, pb, pc, sx, sy, sz, best, best_t, st);
-      else if (mode == 1) scan_node_prims<1, STATS>(S, r, pb, pc, 0, 0, 0, best, best_t, st);
-      else scan_node_prims<0, STATS>(S, r, pb, pc, 0, 0, 0, best, best_t, st);
+      if (mode == 2) scan_node_octant<STATS>(S, r, pb, pc, sx | (sy << 1) | (sz << 2), best, best_t, st);
+      else if (mode == 1) scan_node_prims<1, 0, STATS>(S, r, pb, pc, best, best_t, st);
+      else scan_node_prims<0, 0, STATS>(S, r, pb, pc, best, best_t, st);
 
       unsigned ordw = 0;
       if (fc != 0) {

@@ -68,7 +68,10 @@ class MythTracer {
   // --- extensions (not in the reference)
   void SetDevice(int hip_device) { device_ = hip_device; }
   void SetMaxRecursionLevel(int level) { max_level_ = level; }  // default MAX_RECURSION_LEVEL
-  void SetQuiet(bool quiet) { quiet_ = quiet; }                 // no progress text on stdout
+  void SetQuiet(bool quiet) {                                   // no progress text on stdout
+    quiet_ = quiet;
+    scene.tree.SetQuiet(quiet);
+  }
   const RenderStats& LastStats() const { return stats_; }
   const char* LastError() const { return error_.c_str(); }
   // Finalizes the tree if needed and uploads the scene; RayTrace does this

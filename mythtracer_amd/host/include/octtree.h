@@ -46,6 +46,8 @@ class OctTree {
   // Builds the tree.  Prints "Triangles: N" like the reference.
   void Finalize();
   bool IsFinalized() const { return finalized_; }
+  // extension: no "Triangles: N" line on stdout
+  void SetQuiet(bool quiet) { quiet_ = quiet; }
 
   // Closest hit of one ray, on the GPU (a batch of one; see IntersectRays for
   // the efficient form).  nullptr when nothing is hit or no GPU is usable (the
@@ -71,6 +73,7 @@ class OctTree {
   std::vector<std::unique_ptr<Primitive>> prims_;
   FlatTree flat_;
   bool finalized_ = false;
+  bool quiet_ = false;
   mutable mt_scene* geometry_only_ = nullptr;  // for standalone IntersectRay
   mutable std::string error_;
 };

@@ -66,7 +66,7 @@ const int kBuilderDepthLimit = 4096;
 
 void OctTree::Finalize() {
   if (finalized_) return;
-  printf("Triangles: %u\n", (unsigned int)prims_.size());
+  if (!quiet_) printf("Triangles: %u\n", (unsigned int)prims_.size());
 
   // Breadth-first construction.  A node's split depends only on its own box
   // and member list, so the result equals the reference's depth-first

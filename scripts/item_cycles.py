@@ -1,0 +1,24 @@
+import os, sys, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+out = os.path.join(ROOT, "gpurun_out", "items.bin")
+os.environ["MT_DEBUG_ITEM_CYCLES"] = out
+import mythtracer_amd as M
+from mythtracer_amd import scenegen as sg
+info = sg.write_scene("room", "/tmp/mt_scenes")
+m = M.MythTracer(info["obj"]); m.set_lights(sg.ROOM_LIGHTS)
+W, H = 1920, 1080
+g = m.render(sg.ROOM_CAMERA, W, H)
+a = np.fromfile(out, dtype=np.uint64).reshape(-1, 2)
+d = a[:, 0].astype(np.float64)
+passes = (a[:, 1] >> np.uint64(32)).astype(np.float64); steps = (a[:, 1] & np.uint64(0xffffffff)).astype(np.float64)
+print("items", len(d), "kernel_ms", g["kernel_ms"])
+print("ticks: sum %.3e mean %.0f median %.0f p90 %.0f p99 %.0f max %.0f" % (d.sum(), d.mean(), np.median(d), np.percentile(d, 90), np.percentile(d, 99), d.max()))
+print("passes: mean %.1f median %.0f p99 %.0f max %.0f ; tri-steps/pass mean %.0f" % (passes.mean(), np.median(passes), np.percentile(passes, 99), passes.max(), steps.sum() / passes.sum()))
+print("cycles per tri-step overall %.1f" % (d.sum() / steps.sum()))
+order = np.argsort(-d)[:8]
+for i in order: print(" item", i, "row", (i // 240), "col", i % 240, "cycles %.3e passes %d steps %.3e steps/pass %.0f cyc/step %.0f" % (d[i], passes[i], steps[i], steps[i] / passes[i], d[i] / steps[i]))
+med = np.argsort(np.abs(d - np.median(d)))[:3]
+for i in med: print(" median-ish item", i, "cycles %.3e passes %d steps %.3e steps/pass %.0f cyc/step %.0f" % (d[i], passes[i], steps[i], steps[i] / passes[i], d[i] / steps[i]))
+c = np.sort(d)[::-1]
+print("share of total cycles in top 1%% items: %.3f ; top 10%%: %.3f" % (c[:324].sum() / c.sum(), c[:3240].sum() / c.sum()))
