@@ -53,6 +53,12 @@ struct mt_scene {
   unsigned int *d_work = nullptr;
   double *d_frames = nullptr;
   size_t frames_bytes = 0;
+  int32_t *d_hit_prim = nullptr;   // launch 1 -> launch 2 hand-off (per pixel)
+  size_t hit_prim_bytes = 0;
+  double *d_hit_t = nullptr;
+  size_t hit_t_bytes = 0;
+  unsigned int *d_class_list = nullptr;  // [3][n_items]
+  size_t class_list_bytes = 0;
   uint8_t *d_rgb = nullptr;
   size_t rgb_bytes = 0;
   mt_debug_px *d_debug = nullptr;
@@ -100,6 +106,10 @@ int configure_launch(mt_scene *s) {
   HIP_TRY(hipFuncSetAttribute((const void *)render_kernel<true>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
   HIP_TRY(hipFuncSetAttribute((const void *)render_kernel<false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+  HIP_TRY(hipFuncSetAttribute((const void *)primary_kernel<true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+  HIP_TRY(hipFuncSetAttribute((const void *)primary_kernel<false>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
   HIP_TRY(hipFuncSetAttribute((const void *)intersect_kernel,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
@@ -154,25 +164,42 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (rc != MT_OK) return rc;
   }
   P.frames = s->d_frames;
+  {
+    const size_t slots_px = (size_t)n_tiles * (size_t)tile_w * (size_t)tile_h;
+    int rc = ensure_bytes((void **)&s->d_hit_prim, &s->hit_prim_bytes, slots_px * sizeof(int32_t));
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_hit_t, &s->hit_t_bytes, slots_px * sizeof(double));
+    if (rc == MT_OK) {
+      rc = ensure_bytes((void **)&s->d_class_list, &s->class_list_bytes,
+                        3 * (size_t)P.n_items * sizeof(unsigned int));
+    }
+    if (rc != MT_OK) return rc;
+  }
+  P.hit_prim = s->d_hit_prim;
+  P.hit_t = s->d_hit_t;
+  P.class_list = s->d_class_list;
+  P.class_count = s->d_work + 4;  // d_work: [0..1] work counters, [4..6] class counts
   P.item_cycles = nullptr;
   unsigned long long *d_item = nullptr;
   const char *item_dump = getenv("MT_DEBUG_ITEM_CYCLES");
   if (item_dump && P.n_items > 0) {
-    HIP_TRY(hipMalloc((void **)&d_item, (size_t)P.n_items * 16));
-    HIP_TRY(hipMemset(d_item, 0, (size_t)P.n_items * 16));
+    HIP_TRY(hipMalloc((void **)&d_item, (size_t)P.n_items * 4 * 16));
+    HIP_TRY(hipMemset(d_item, 0, (size_t)P.n_items * 4 * 16));
     P.item_cycles = d_item;
   }
-  HIP_TRY(hipMemsetAsync(s->d_work, 0, sizeof(unsigned), stream));
+  HIP_TRY(hipMemsetAsync(s->d_work, 0, 8 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
+  // launch 1: primary rays + cost classes; launch 2: shading, heavy blocks first
   if (s->stats_enabled) {
+    hipLaunchKernelGGL(primary_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
     hipLaunchKernelGGL(render_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
   } else {
+    hipLaunchKernelGGL(primary_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
     hipLaunchKernelGGL(render_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
   }
   HIP_TRY(hipGetLastError());
   if (d_item) {  // debug: dump per-item durations (synchronises!)
-    std::vector<unsigned long long> host((size_t)P.n_items * 2);
+    std::vector<unsigned long long> host((size_t)P.n_items * 4 * 2);
     HIP_TRY(hipMemcpy(host.data(), d_item, host.size() * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d_item));
     if (FILE *f = fopen(item_dump, "wb")) {
@@ -254,6 +281,9 @@ void mt_scene_destroy(mt_scene *s) {
   (void)hipSetDevice(s->device);
   for (void *p : s->allocs) (void)hipFree(p);
   if (s->d_frames) (void)hipFree(s->d_frames);
+  if (s->d_hit_prim) (void)hipFree(s->d_hit_prim);
+  if (s->d_hit_t) (void)hipFree(s->d_hit_t);
+  if (s->d_class_list) (void)hipFree(s->d_class_list);
   if (s->d_rgb) (void)hipFree(s->d_rgb);
   if (s->d_debug) (void)hipFree(s->d_debug);
   if (s->d_lights) (void)hipFree(s->d_lights);
@@ -451,7 +481,7 @@ int mt_scene_set_lights(mt_scene *s, const mt_light *lights, int n) {
 }
 
 int mt_scene_set_traversal_mode(mt_scene *s, int mode) {
-  if (!s || mode < 0 || mode > 2) return fail(MT_ERR_ARG, "mode must be 0, 1 or 2");
+  if (!s || mode < 0 || mode > 3) return fail(MT_ERR_ARG, "mode must be 0..3");
   s->dev.force_mode = mode;
   return MT_OK;
 }

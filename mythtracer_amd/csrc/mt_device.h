@@ -87,7 +87,11 @@ struct RenderParams {
   uint8_t *out_rgb;
   mt_debug_px *out_debug;  // nullable; same slot layout as out_rgb
   unsigned long long *counters;  // ST_COUNT
-  unsigned int *work_counter;
+  unsigned int *work_counter;     // [0] launch 1, [1] launch 2
+  int32_t *hit_prim;              // primary hit per pixel (slot layout of out_rgb)
+  double *hit_t;
+  unsigned int *class_count;      // [3] blocks per cost class
+  unsigned int *class_list;       // [3][n_items] block ids per class
   double *frames;          // recursion frames scratch
   unsigned long long *item_cycles;  // debug (MT_DEBUG_ITEM_CYCLES): s_memtime ticks per work item
 };

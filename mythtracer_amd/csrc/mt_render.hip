@@ -35,8 +35,149 @@ struct FrameIO {
   }
 };
 
+// Work item -> pixel of the calling lane.  An item is an 8x8-pixel block of a
+// tile slot; `sub` < 0 means all 64 lanes (8x8), sub = 0..3 means only the
+// 4x4 quadrant `sub` of it, on lanes 0..15 (used to cut heavy blocks).
+struct ItemGeom {
+  int px, py;        // image coordinates of this lane's pixel
+  bool inside;       // lane has a pixel
+  size_t px_index;   // position in the output / hit buffers
+};
+__device__ __forceinline__ ItemGeom item_geometry(const RenderParams &P, unsigned item, int sub, int lane) {
+  const int items_per_tile = P.blocks_x * P.blocks_y;
+  const int j = (int)(item / (unsigned)items_per_tile);
+  const int b = (int)(item % (unsigned)items_per_tile);
+  const int tile = P.first_tile + j * P.tile_stride;
+  const int tx0 = P.region_x + (tile % P.tiles_x) * P.tile_w;
+  const int ty0 = P.region_y + (tile / P.tiles_x) * P.tile_h;
+  const int cw = min(P.tile_w, P.region_x + P.region_w - tx0);  // edge clipping as
+  const int ch = min(P.tile_h, P.region_y + P.region_h - ty0);  // main_net_master.cc:205-206
+  int ox, oy;
+  bool lane_used = true;
+  if (sub < 0) {
+    ox = lane & 7;
+    oy = lane >> 3;
+  } else {
+    ox = (sub & 1) * 4 + (lane & 3);
+    oy = (sub >> 1) * 4 + ((lane >> 2) & 3);
+    lane_used = lane < 16;
+  }
+  const int lx = (b % P.blocks_x) * 8 + ox;
+  const int ly = (b / P.blocks_x) * 8 + oy;
+  ItemGeom g;
+  g.px = tx0 + lx;
+  g.py = ty0 + ly;
+  g.inside = lane_used && (lx < cw) && (ly < ch);
+  g.px_index = (size_t)j * (size_t)P.tile_w * (size_t)P.tile_h + (size_t)ly * (size_t)cw + (size_t)lx;
+  return g;
+}
+
+// Work fetch.  Written WITHOUT a divergent branch: every lane issues the add
+// (lane 0 adds 1, the others 0; hipcc merges them into one atomic per wave) and
+// lane 0's return value is broadcast.  The obvious form
+// `if (lane == 0) v = atomicAdd(..); v = readfirstlane(v);` was miscompiled by
+// hipcc 7.2 (the broadcast was folded per control-flow path, so lanes 1..63
+// kept looping on item 0 for ever).
+__device__ __forceinline__ unsigned fetch_work(unsigned int *counter, int lane) {
+  const unsigned v = atomicAdd(counter, lane == 0 ? 1u : 0u);
+  return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 template <bool STATS>
-__global__ __launch_bounds__(256) void render_kernel(DevScene S, RenderParams P) {
+__device__ __forceinline__ void flush_item_stats(LaneStats &st, unsigned long long *counters, int lane) {
+  if (STATS) {  // one atomic per counter per work item
+    for (int i = 0; i < ST_WAVE_NODE_STEPS; i++) {
+      const unsigned s = wave_sum_u32(st.v[i]);
+      if (lane == 0 && s) atomicAdd(counters + i, (unsigned long long)s);
+    }
+    if (lane == 0) {
+      atomicAdd(counters + ST_WAVE_NODE_STEPS, (unsigned long long)st.wave_node_steps);
+      atomicAdd(counters + ST_WAVE_TRI_STEPS, (unsigned long long)st.wave_tri_steps);
+    }
+    st.clear();
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Launch 1 of a frame: the primary ray of every pixel (Sensor::GetRay +
+// the level-0 OctTree::IntersectRay of TraceRayWorker, mythtracer.cc:18-36).
+// Stores the hit (primitive, distance) per pixel, fills the optional debug
+// buffer, and files every 8x8 block under a cost class judged from the
+// materials it sees, so that launch 2 can start with the expensive blocks:
+//   class 2: some pixel hit a transparent material (deep refraction trees),
+//   class 1: some pixel hit a reflective one, class 0: everything else.
+template <bool STATS>
+__global__ __launch_bounds__(256, 3) void primary_kernel(DevScene S, RenderParams P) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave_in_block = threadIdx.x >> 6;
+  WaveStack stk;
+  stk.bind(smem + (size_t)wave_in_block * wave_stack_bytes(S.tree_depth), S.tree_depth);
+  const MT_CONST mt_material *mtls = as_const(S.mtls);
+  LaneStats st;
+  st.clear();
+  const V3 cam_origin = v3_load(P.sensor.origin);
+  const V3 s_start = v3_load(P.sensor.start_point);
+  const V3 s_ds = v3_load(P.sensor.delta_scanline);
+  const V3 s_dp = v3_load(P.sensor.delta_pixel);
+  for (;;) {
+    const unsigned item = fetch_work(P.work_counter, lane);
+    if (item >= P.n_items) break;
+    const ItemGeom g = item_geometry(P, item, -1, lane);
+    V3 rd = v3(0, 0, 1);
+    if (g.inside) {  // Sensor::GetRay, camera.cc:65-69
+      const V3 d = s_start + (s_ds * (double)g.py) + (s_dp * (double)g.px);
+      rd = normalized(d);
+    }
+    int prim;
+    double t;
+    const int trc = trace_wave<STATS>(S, stk, lane, g.inside, cam_origin.x, cam_origin.y, cam_origin.z,
+                                      rd.x, rd.y, rd.z, prim, t, st);
+    if (trc != DEV_OK) {
+      if (lane == 0) atomicMax(P.counters + ST_STATUS, (unsigned long long)trc);
+      break;
+    }
+    int cls = 0;
+    if (g.inside) {
+      if (STATS) st.v[ST_RAYS_PRIMARY]++;
+      P.hit_prim[g.px_index] = prim;
+      P.hit_t[g.px_index] = t;
+      if (prim >= 0) {
+        const int m = S.tri_mtl[prim];
+        if (m >= 0) {
+          const MT_CONST mt_material *mm = mtls + m;
+          cls = mm->transparency > 0.0 ? 2 : (mm->reflectance > 0.0 ? 1 : 0);
+        }
+      }
+      if (P.out_debug != nullptr) {  // mythtracer.cc:23-36
+        mt_debug_px *dbg = P.out_debug + g.px_index;
+        dbg->reserved = 0;
+        if (prim < 0) {
+          dbg->line_no = -1;
+          dbg->point[0] = dbg->point[1] = dbg->point[2] = __builtin_nan("");
+        } else {
+          dbg->line_no = S.tri_line[prim];
+          dbg->point[0] = cam_origin.x + rd.x * t;  // primitive_triangle.cc:141
+          dbg->point[1] = cam_origin.y + rd.y * t;
+          dbg->point[2] = cam_origin.z + rd.z * t;
+        }
+      }
+    }
+    const int item_cls = __builtin_amdgcn_readfirstlane(
+        (__builtin_amdgcn_ballot_w64(cls == 2) != 0ull) ? 2 : ((__builtin_amdgcn_ballot_w64(cls == 1) != 0ull) ? 1 : 0));
+    const unsigned slot = atomicAdd(P.class_count + item_cls, lane == 0 ? 1u : 0u);
+    if (lane == 0) P.class_list[(size_t)item_cls * P.n_items + slot] = item;
+    flush_item_stats<STATS>(st, P.counters, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Launch 2: everything of TraceRayWorker after the primary hit (shading,
+// shadow loops, reflection/refraction recursion) and the pixel store.  Work
+// order: class-2 blocks first, then class 1, then class 0 (the frame cannot
+// finish before its slowest work item, so the long ones must not start last).
+template <bool STATS>
+__global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
@@ -58,37 +199,31 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene S, RenderParams P)
   const V3 s_start = v3_load(P.sensor.start_point);
   const V3 s_ds = v3_load(P.sensor.delta_scanline);
   const V3 s_dp = v3_load(P.sensor.delta_pixel);
-  const int items_per_tile = P.blocks_x * P.blocks_y;
+  const unsigned n2 = P.class_count[2], n1 = P.class_count[1], n0 = P.class_count[0];
+  const unsigned n_work = n2 + n1 + n0;
 
   for (;;) {
-    // Work fetch.  Written WITHOUT a divergent branch: every lane issues the
-    // add (lane 0 adds 1, the others 0; hipcc merges them into one atomic per
-    // wave) and lane 0's return value is broadcast.  The obvious form
-    // `if (lane == 0) v = atomicAdd(..); v = readfirstlane(v);` was miscompiled
-    // by hipcc 7.2 (the broadcast was folded per control-flow path, so lanes
-    // 1..63 kept looping on item 0 for ever).
-    unsigned item = atomicAdd(P.work_counter, lane == 0 ? 1u : 0u);
-    item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
+    const unsigned w = fetch_work(P.work_counter + 1, lane);
     if (S.hb) {
       const unsigned long long ex = __builtin_amdgcn_read_exec();
-      if (lane == 0) { S.hb[wave_id * 4 + 0] = 1 | ((unsigned long long)item << 8); S.hb[wave_id * 4 + 1] = ex; }
+      if (lane == 0) { S.hb[wave_id * 4 + 0] = 1 | ((unsigned long long)w << 8); S.hb[wave_id * 4 + 1] = ex; }
     }
-    if (item >= P.n_items) break;
+    if (w >= n_work) break;
+    unsigned item;
+    int sub = -1;
+    if (w < n2) {
+      item = P.class_list[(size_t)2 * P.n_items + w];
+    } else if (w < n2 + n1) {
+      item = P.class_list[(size_t)1 * P.n_items + (w - n2)];
+    } else {
+      item = P.class_list[w - n2 - n1];
+    }
+    item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
 
     const unsigned long long item_t0 = P.item_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
-    // work item -> tile slot j, 8x8 block (bx, by) inside the tile
-    const int j = (int)(item / (unsigned)items_per_tile);
-    const int b = (int)(item % (unsigned)items_per_tile);
-    const int tile = P.first_tile + j * P.tile_stride;
-    const int tx0 = P.region_x + (tile % P.tiles_x) * P.tile_w;
-    const int ty0 = P.region_y + (tile / P.tiles_x) * P.tile_h;
-    const int cw = min(P.tile_w, P.region_x + P.region_w - tx0);  // edge clipping as
-    const int ch = min(P.tile_h, P.region_y + P.region_h - ty0);  // main_net_master.cc:205-206
-    const int lx = (b % P.blocks_x) * 8 + (lane & 7);
-    const int ly = (b / P.blocks_x) * 8 + (lane >> 3);
-    bool alive = (lx < cw) && (ly < ch);
-    const size_t slot_px = (size_t)j * (size_t)P.tile_w * (size_t)P.tile_h;
-    const size_t px_index = slot_px + (size_t)ly * (size_t)cw + (size_t)lx;
+    const ItemGeom g = item_geometry(P, item, sub, lane);
+    bool alive = g.inside;
+    const size_t px_index = g.px_index;
 
     // ---- per-lane state of TraceRayWorker
     int mode = MODE_RADIANCE;
@@ -96,8 +231,8 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene S, RenderParams P)
     bool in_object = false;
     double coef = 1.0;
     V3 ro = cam_origin, rd = v3(0, 0, 1);
-    if (alive) {  // Sensor::GetRay, camera.cc:65-69
-      const V3 d = s_start + (s_ds * (double)(ty0 + ly)) + (s_dp * (double)(tx0 + lx));
+    if (alive) {  // Sensor::GetRay, camera.cc:65-69 (same arithmetic as launch 1)
+      const V3 d = s_start + (s_ds * (double)g.py) + (s_dp * (double)g.px);
       rd = normalized(d);
     }
     V3 Pt = v3(0, 0, 0), Nn = Pt, surf = Pt, color = Pt, Rd = Pt, dir = Pt, L = Pt, start = Pt,
@@ -123,8 +258,13 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene S, RenderParams P)
           S.hb[wave_id * 4 + 3] = ex;
         }
       }
-      const int trc =
-          trace_wave<STATS>(S, stk, lane, alive, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, prim, t, st);
+      int trc = DEV_OK;
+      if (passes == 0) {  // the primary hit was found by launch 1
+        prim = alive ? P.hit_prim[px_index] : -1;
+        t = alive ? P.hit_t[px_index] : 0.0;
+      } else {
+        trc = trace_wave<STATS>(S, stk, lane, alive, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, prim, t, st);
+      }
       if (S.hb) {
         const unsigned long long ex = __builtin_amdgcn_read_exec();
         if (lane == 0) { S.hb[wave_id * 4 + 0] = 3 | ((unsigned long long)passes << 8); S.hb[wave_id * 4 + 3] = ex; }
@@ -138,25 +278,13 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene S, RenderParams P)
         bool next_light = false, after_lights = false, do_return = false;
         V3 retval = v3(0, 0, 0);
         if (mode == MODE_RADIANCE) {
-          if (STATS) st.v[level == 0 ? ST_RAYS_PRIMARY : ST_RAYS_SECONDARY]++;
+          if (STATS && level > 0) st.v[ST_RAYS_SECONDARY]++;  // level 0 was counted by launch 1
           if (prim < 0) {  // mythtracer.cc:23-31
-            if (level == 0 && P.out_debug != nullptr) {
-              mt_debug_px *dbg = P.out_debug + px_index;
-              dbg->line_no = -1;
-              dbg->reserved = 0;
-              dbg->point[0] = dbg->point[1] = dbg->point[2] = __builtin_nan("");
-            }
             do_return = true;
           } else {
             if (STATS) st.v[ST_SHADED_HITS]++;
             Pt = ro + rd * t;  // primitive_triangle.cc:141
             dir = rd;
-            if (level == 0 && P.out_debug != nullptr) {  // :33-36
-              mt_debug_px *dbg = P.out_debug + px_index;
-              dbg->line_no = S.tri_line[prim];
-              dbg->reserved = 0;
-              dbg->point[0] = Pt.x; dbg->point[1] = Pt.y; dbg->point[2] = Pt.z;
-            }
             const double *vtx = S.tri_vertex + (size_t)prim * 9;
             const Bary w = barycentric(vtx, Pt);
             Nn = interpolate(S.tri_normal + (size_t)prim * 9, w);  // :38
@@ -344,20 +472,10 @@ __global__ __launch_bounds__(256) void render_kernel(DevScene S, RenderParams P)
 
     if (S.hb && lane == 0) S.hb[wave_id * 4 + 0] = 4;
     if (P.item_cycles && lane == 0) {
-      P.item_cycles[(size_t)item * 2] = __builtin_amdgcn_s_memtime() - item_t0;
-      P.item_cycles[(size_t)item * 2 + 1] = ((unsigned long long)passes << 32) | st.wave_tri_steps;
+      P.item_cycles[(size_t)w * 2] = __builtin_amdgcn_s_memtime() - item_t0;
+      P.item_cycles[(size_t)w * 2 + 1] = ((unsigned long long)passes << 32) | st.wave_tri_steps;
     }
-    if (STATS) {  // one atomic per counter per work item (64 pixels)
-      for (int i = 0; i < ST_WAVE_NODE_STEPS; i++) {
-        const unsigned s = wave_sum_u32(st.v[i]);
-        if (lane == 0 && s) atomicAdd(P.counters + i, (unsigned long long)s);
-      }
-      if (lane == 0) {
-        atomicAdd(P.counters + ST_WAVE_NODE_STEPS, (unsigned long long)st.wave_node_steps);
-        atomicAdd(P.counters + ST_WAVE_TRI_STEPS, (unsigned long long)st.wave_tri_steps);
-      }
-      st.clear();
-    }
+    flush_item_stats<STATS>(st, P.counters, lane);
   }
   if (S.hb && lane == 0) S.hb[wave_id * 4 + 0] = 5;
 }
@@ -433,5 +551,7 @@ __global__ void blit_tiles_kernel(int image_w, int image_h, int tile_w, int tile
 
 template __global__ void render_kernel<true>(DevScene, RenderParams);
 template __global__ void render_kernel<false>(DevScene, RenderParams);
+template __global__ void primary_kernel<true>(DevScene, RenderParams);
+template __global__ void primary_kernel<false>(DevScene, RenderParams);
 
 }  // namespace mt

@@ -81,6 +81,24 @@ __device__ __forceinline__ double mx3(double a, double b, double c) {
   else return __builtin_fmax(__builtin_fmax(a, b), c);
 }
 
+// Arguments of a non-inlined device function arrive in VGPRs; these put a
+// wave-uniform value back into SGPRs so that it can feed scalar loads.
+__device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p) {
+  const unsigned long long v = (unsigned long long)(uintptr_t)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (T *)(uintptr_t)(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane_id) {
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)bits, lane_id);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lane_id);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // Wave-wide minimum of a 32-bit value; every lane must be active.
 __device__ __forceinline__ int wave_min_i32(int v) {
   // all-reduce inside each row of 16 lanes with row rotations ...
@@ -225,31 +243,49 @@ __device__ __forceinline__ unsigned long long slab_pass(const double *a, const R
   }
 }
 
-// A zero that the compiler must treat as depending on `v` (an SGPR value that
-// came from a scalar load).  Added to the address of the NEXT scalar load it
-// forces "wait for the pair in flight, THEN issue the next fetch": scalar
-// loads return out of order, so only s_waitcnt lgkmcnt(0) exists, and a fetch
-// issued before that wait would be waited for as well (no overlap at all).
-__device__ __forceinline__ long after_arrival_of(double v) {
-  long z;
-  asm volatile("s_mov_b64 %0, 0" : "=s"(z) : "s"(v));
-  return z;
+// ---- box fetch ------------------------------------------------------------
+// Two boxes (96 bytes) travel as one s_load_dwordx16 + one s_load_dwordx8 into
+// 24 SGPRs.  The loads are issued by hand (inline asm) because the fetch of the
+// NEXT pair has to be in flight while the current pair is evaluated, and hipcc
+// sinks its own scalar loads down to their first use (no overlap at all).
+// Rules that make this safe (see cdna_hip_programming.md 5.7):
+//   * scalar loads return out of order, so the only usable wait is
+//     lgkmcnt(0); exactly ONE pair is in flight at any time and it is awaited
+//     (await_pair) before the next one is issued;
+//   * nothing reads a PairRegs between issue_pair and await_pair: the data is
+//     only reachable through await_pair's "+s" outputs;
+//   * no fetch is left in flight when the loop exits (the last iteration does
+//     not issue one), so the registers are free to be reused afterwards.
+// tools/check_asm_prefetch.py verifies on the generated ISA that the
+// destination registers are untouched between each load and its wait.
+typedef double d8v __attribute__((ext_vector_type(8)));
+typedef double d4v __attribute__((ext_vector_type(4)));
+struct PairRegs {
+  d8v lo;  // box0: min xyz, max xyz ; box1: min x, min y
+  d4v hi;  // box1: min z, max xyz
+  __device__ __forceinline__ double at(int i) const { return i < 8 ? lo[i] : hi[i - 8]; }
+};
+
+__device__ __forceinline__ void issue_pair(PairRegs &q, const MT_CONST double *p) {
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40"
+               : "=&s"(q.lo), "=&s"(q.hi)
+               : "s"(p));
+}
+__device__ __forceinline__ void await_pair(PairRegs &q) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.lo), "+s"(q.hi));
 }
 
-__device__ __forceinline__ void load_pair(double (&b)[12], const MT_CONST double *p) {
-#pragma unroll
-  for (int i = 0; i < 12; i++) b[i] = p[i];
-}
-
-// Evaluates the two boxes of `b` (stream positions k, k+1 of the node) for the
+// Evaluates the two boxes of `q` (stream positions k, k+1 of the node) for the
 // calling lanes and parks / resolves the candidates in stream order.
 template <int MODE, int OCT, bool STATS>
-__device__ __forceinline__ void scan_pair(const DevScene &S, const RayRegs &r, const double (&b)[12],
+__device__ __forceinline__ void scan_pair(const DevScene &S, const RayRegs &r, const PairRegs &q,
                                           int pb, int k, int pc, int &pend,
                                           unsigned long long &pmask, int &best, double &best_t,
                                           LaneStats &st) {
-  const unsigned long long pm0 = slab_pass<MODE, OCT>(&b[0], r);
-  const unsigned long long pm1 = (k + 1 < pc) ? slab_pass<MODE, OCT>(&b[6], r) : 0ull;
+  const double b0[6] = {q.lo[0], q.lo[1], q.lo[2], q.lo[3], q.lo[4], q.lo[5]};
+  const double b1[6] = {q.lo[6], q.lo[7], q.hi[0], q.hi[1], q.hi[2], q.hi[3]};
+  const unsigned long long pm0 = slab_pass<MODE, OCT>(b0, r);
+  const unsigned long long pm1 = (k + 1 < pc) ? slab_pass<MODE, OCT>(b1, r) : 0ull;
   if (pm0 | pm1) {
     const unsigned long long me = 1ull << (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
     const bool pass0 = (pm0 & me) != 0, pass1 = (pm1 & me) != 0;
@@ -270,31 +306,91 @@ __device__ __forceinline__ void scan_pair(const DevScene &S, const RayRegs &r, c
 
 // Scans the triangle list [pb, pb+pc) of one node for the calling lanes.
 // MODE: 0 exact, 1 regular, 2 octant-uniform (OCT = the shared sign octant).
-// Boxes are consumed in pairs from two SGPR buffers: while one pair is being
-// evaluated the next one is in flight (scalar loads).  The box stream is
-// padded at its end so the look-ahead never leaves the allocation.
 template <int MODE, int OCT, bool STATS>
 __device__ __forceinline__ void scan_node_prims(const DevScene &S, const RayRegs &r, int pb,
                                                 int pc, int &best, double &best_t,
                                                 LaneStats &st) {
+  if (pc <= 0) return;
   const MT_CONST double *p = as_const(S.tri_aabb) + (size_t)pb * 6;
   int pend = -1;
   unsigned long long pmask = 0;  // lanes holding a parked candidate
-  double A[12], B[12];
-  load_pair(A, p);
-  for (int k = 0; k < pc;) {
-    load_pair(B, p + 12 + after_arrival_of(A[11]));
-    __builtin_amdgcn_sched_barrier(0);  // keep the fetch ahead of the evaluation
+  PairRegs A, B;
+  issue_pair(A, p);
+  await_pair(A);
+  for (int k = 0;;) {
+    const bool more_b = k + 2 < pc;
+    if (more_b) issue_pair(B, p + 12);
     scan_pair<MODE, OCT, STATS>(S, r, A, pb, k, pc, pend, pmask, best, best_t, st);
+    if (!more_b) break;
+    await_pair(B);
     k += 2;
-    if (k >= pc) break;
+    const bool more_a = k + 2 < pc;
     p += 24;
-    load_pair(A, p + after_arrival_of(B[11]));
-    __builtin_amdgcn_sched_barrier(0);
+    if (more_a) issue_pair(A, p);
     scan_pair<MODE, OCT, STATS>(S, r, B, pb, k, pc, pend, pmask, best, best_t, st);
+    if (!more_a) break;
+    await_pair(A);
     k += 2;
   }
   if (pmask) flush_candidates<STATS>(S, r, pend, best, best_t, st);
+}
+
+// Transposed scan: ONE ray at a time, 64 TRIANGLES per step (lane = triangle).
+// Used when only a few lanes want a node: scanning a 90-triangle list for 2
+// rays costs 4 of these steps instead of 90 ray-parallel ones.  All 64 lanes
+// of the wave take part, whatever node they themselves are waiting for.
+// Equivalence with the reference's sequential loop (octtree.cc:177-196): the
+// hits of a chunk are folded in ascending triangle order with the same
+// "keep the old one only if it is strictly closer" rule, chunk after chunk.
+template <bool EX, bool STATS>
+__device__ __forceinline__ void scan_node_transposed(const DevScene &S, const RayRegs &r, int lane,
+                                                     unsigned long long inmask, int pb, int pc,
+                                                     int &best, double &best_t, LaneStats &st) {
+  const double *boxes = S.tri_aabb + (size_t)pb * 6;
+  unsigned long long todo = inmask;
+  while (todo != 0ull) {
+    const int L = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    RayRegs u;  // lane L's ray, wave-uniform
+    u.ox = readlane_f64(r.ox, L); u.oy = readlane_f64(r.oy, L); u.oz = readlane_f64(r.oz, L);
+    u.dx = readlane_f64(r.dx, L); u.dy = readlane_f64(r.dy, L); u.dz = readlane_f64(r.dz, L);
+    u.ix = readlane_f64(r.ix, L); u.iy = readlane_f64(r.iy, L); u.iz = readlane_f64(r.iz, L);
+    int ubest = -1;
+    double ubest_t = 0.0;
+    unsigned mt_count = 0;
+    for (int base = 0; base < pc; base += 64) {
+      const int tri = base + lane;
+      const int tri_c = tri < pc ? tri : pc - 1;
+      const double *bp = boxes + (size_t)tri_c * 6;
+      const double b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
+      const unsigned long long pm =
+          slab_pass<EX ? 0 : 1, 0>(b, u) & __builtin_amdgcn_ballot_w64(tri < pc);
+      if (pm != 0ull) {
+        if (STATS) mt_count += (unsigned)__builtin_popcountll(pm);
+        const bool mine = ((pm >> lane) & 1ull) != 0;
+        double t = 0.0;
+        bool hit = false;
+        if (mine) {
+          hit = moller_trumbore(S.tri_vertex + (size_t)(pb + tri_c) * 9, u.ox, u.oy, u.oz, u.dx, u.dy, u.dz, &t);
+        }
+        unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+        while (hm != 0ull) {  // ascending triangle order
+          const int i = __builtin_ctzll(hm);
+          hm &= hm - 1;
+          const double ti = readlane_f64(t, i);
+          if (!(ubest >= 0 && ti > ubest_t)) {
+            ubest = pb + base + i;
+            ubest_t = ti;
+          }
+        }
+      }
+    }
+    if (lane == L) {
+      best = ubest;
+      best_t = ubest_t;
+      if (STATS) st.v[ST_MT_TESTS] += mt_count;
+    }
+  }
 }
 
 // Octant dispatch for mode 2 (eight specialised loops: the near/far planes
@@ -421,11 +517,34 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
 
 // One closest-hit query per lane.  Must be called by all 64 lanes of the wave
 // (want = false for lanes without a ray).  out_prim = stream index or -1.
+// NOT inlined on purpose: as a function of its own the traversal gets its own
+// register allocation, free of the shading kernel's SGPR/VGPR pressure.  That
+// is what keeps the in-flight box registers of the scan loop from being
+// spilled (tools/check_asm_prefetch.py) and the inner loop free of spill code.
 template <bool STATS>
-__device__ __forceinline__ int trace_wave(const DevScene &S, const WaveStack &stk, int lane,
+__device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const WaveStack &stk_arg, int lane,
                                           bool want, double ox, double oy, double oz,
                                           double dx, double dy, double dz, int &out_prim,
                                           double &out_t, LaneStats &st) {
+  // re-establish uniformity of everything scalar loads are addressed with
+  DevScene S;
+  S.nodes = uniform_ptr(S_arg.nodes);
+  S.tri_aabb = uniform_ptr(S_arg.tri_aabb);
+  S.tri_vertex = uniform_ptr(S_arg.tri_vertex);
+  S.tri_normal = nullptr; S.tri_uvw = nullptr; S.tri_mtl = nullptr; S.tri_line = nullptr;
+  S.mtls = nullptr; S.texs = nullptr; S.lights = nullptr;
+  S.n_lights = 0;
+  S.n_tris = uniform_i32(S_arg.n_tris);
+  S.n_nodes = uniform_i32(S_arg.n_nodes);
+  S.tree_depth = uniform_i32(S_arg.tree_depth);
+  S.force_mode = uniform_i32(S_arg.force_mode);
+  S.scene_regular = uniform_i32(S_arg.scene_regular);
+  S.hb = nullptr;
+  WaveStack stk;
+  stk.bt = uniform_ptr(stk_arg.bt);
+  stk.fc = uniform_ptr(stk_arg.fc);
+  stk.bp = uniform_ptr(stk_arg.bp);
+  stk.ord = uniform_ptr(stk_arg.ord);
   RayRegs r;
   r.ox = ox; r.oy = oy; r.oz = oz;
   r.dx = dx; r.dy = dy; r.dz = dz;
@@ -496,16 +615,29 @@ __device__ __forceinline__ int trace_wave(const DevScene &S, const WaveStack &st
         }
       }
     }
+    // Few lanes on this node?  Then go triangle-parallel (cost model in
+    // instruction counts: a ray-parallel step ~20, a transposed chunk ~45 plus
+    // ~30 to broadcast each ray).
+    const int n_in = __builtin_popcountll(inmask);
+    const int chunks = (pc + 63) >> 6;
+    const bool transposed = (S.force_mode < 3) && pc > 0 && (n_in * (30 + 45 * chunks) < 20 * pc);
+    int best = -1;
+    double best_t = 0.0;
+    if (transposed) {
+      if (STATS) st.wave_tri_steps += (unsigned)(n_in * chunks) - (unsigned)pc;  // replaces the pc counted above
+      if (mode == 0) scan_node_transposed<true, STATS>(S, r, lane, inmask, pb, pc, best, best_t, st);
+      else scan_node_transposed<false, STATS>(S, r, lane, inmask, pb, pc, best, best_t, st);
+    }
     if (in) {
-      int best = -1;
-      double best_t = 0.0;
       if (STATS) {
         st.v[ST_NODE_VISITS]++;
         st.v[ST_TRI_TESTS] += (unsigned)pc;
       }
-      if (mode == 2) scan_node_octant<STATS>(S, r, pb, pc, sx | (sy << 1) | (sz << 2), best, best_t, st);
-      else if (mode == 1) scan_node_prims<1, 0, STATS>(S, r, pb, pc, best, best_t, st);
-      else scan_node_prims<0, 0, STATS>(S, r, pb, pc, best, best_t, st);
+      if (!transposed) {
+        if (mode == 2) scan_node_octant<STATS>(S, r, pb, pc, sx | (sy << 1) | (sz << 2), best, best_t, st);
+        else if (mode == 1) scan_node_prims<1, 0, STATS>(S, r, pb, pc, best, best_t, st);
+        else scan_node_prims<0, 0, STATS>(S, r, pb, pc, best, best_t, st);
+      }
 
       unsigned ordw = 0;
       if (fc != 0) {

@@ -10,6 +10,7 @@ m = M.MythTracer(info["obj"]); m.set_lights(sg.ROOM_LIGHTS)
 W, H = 1920, 1080
 g = m.render(sg.ROOM_CAMERA, W, H)
 a = np.fromfile(out, dtype=np.uint64).reshape(-1, 2)
+a = a[a[:, 0] > 0]
 d = a[:, 0].astype(np.float64)
 passes = (a[:, 1] >> np.uint64(32)).astype(np.float64); steps = (a[:, 1] & np.uint64(0xffffffff)).astype(np.float64)
 print("items", len(d), "kernel_ms", g["kernel_ms"])
@@ -17,7 +18,7 @@ print("ticks: sum %.3e mean %.0f median %.0f p90 %.0f p99 %.0f max %.0f" % (d.su
 print("passes: mean %.1f median %.0f p99 %.0f max %.0f ; tri-steps/pass mean %.0f" % (passes.mean(), np.median(passes), np.percentile(passes, 99), passes.max(), steps.sum() / passes.sum()))
 print("cycles per tri-step overall %.1f" % (d.sum() / steps.sum()))
 order = np.argsort(-d)[:8]
-for i in order: print(" item", i, "row", (i // 240), "col", i % 240, "cycles %.3e passes %d steps %.3e steps/pass %.0f cyc/step %.0f" % (d[i], passes[i], steps[i], steps[i] / passes[i], d[i] / steps[i]))
+for i in order: print(" work", i, "cycles %.3e passes %d steps %.3e steps/pass %.0f cyc/step %.0f" % (d[i], passes[i], steps[i], steps[i] / max(passes[i],1), d[i] / max(steps[i],1)))
 med = np.argsort(np.abs(d - np.median(d)))[:3]
 for i in med: print(" median-ish item", i, "cycles %.3e passes %d steps %.3e steps/pass %.0f cyc/step %.0f" % (d[i], passes[i], steps[i], steps[i] / passes[i], d[i] / steps[i]))
 c = np.sort(d)[::-1]
