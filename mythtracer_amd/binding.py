@@ -104,8 +104,8 @@ def _i32(x):
 class HipAbi:
     """libmythtracer_hip.so — the C ABI, one method per entry point."""
 
-    def __init__(self):
-        L = self.lib = _load(HIP_LIB)
+    def __init__(self, lib_path=None):
+        L = self.lib = _load(lib_path or HIP_LIB)
         vp, ci = C.c_void_p, C.c_int
         L.mt_last_error.restype = C.c_char_p
         L.mt_scene_create.restype = vp

@@ -59,6 +59,15 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return HIP_LIB
 
 
+def build_prof(verbose: bool = False) -> str:
+    """Diagnostic variant with phase stamps (-DMT_PROF); never used by tests or bench."""
+    out = os.path.join(LIB, "libmythtracer_hip_prof.so")
+    cmd = [HIPCC] + HIP_FLAGS + ["-DMT_PROF", "-I", INC, "-I", CSRC, "-o", out,
+                                 os.path.join(CSRC, "mt_capi.hip")]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_host(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB, exist_ok=True)
     srcs = _files(os.path.join(HOST, "src"), (".cc",))
@@ -80,5 +89,8 @@ def build_all(force: bool = False, verbose: bool = False):
 
 
 if __name__ == "__main__":
+    if "--prof" in sys.argv:
+        print("built:", build_prof())
+        sys.exit(0)
     build_all(force="--force" in sys.argv, verbose=True)
     print("built:", HIP_LIB, HOST_LIB)

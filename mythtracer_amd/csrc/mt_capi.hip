@@ -70,6 +70,7 @@ struct mt_scene {
   int n_cu = 0;
   bool stats_enabled = true;
   unsigned long long *hb_host = nullptr;  // MT_DEBUG_HEARTBEAT: pinned, device-visible
+  unsigned long long *d_prof = nullptr;   // -DMT_PROF build: phase cycle sums
 };
 
 namespace {
@@ -441,6 +442,13 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   HIP_TRY(hipEventCreate(&s->ev1));
   if ((rc = mt_scene_set_lights(s, nullptr, 0)) != MT_OK) return rc;
   s->dev.hb = nullptr;
+  s->dev.prof = nullptr;
+#ifdef MT_PROF
+  HIP_TRY(hipMalloc((void **)&s->d_prof, PROF_COUNT * sizeof(unsigned long long)));
+  s->allocs.push_back(s->d_prof);
+  HIP_TRY(hipMemset(s->d_prof, 0, PROF_COUNT * sizeof(unsigned long long)));
+  s->dev.prof = s->d_prof;
+#endif
   if (getenv("MT_DEBUG_HEARTBEAT")) {
     HIP_TRY(hipHostMalloc((void **)&s->hb_host, 65536 * sizeof(unsigned long long), hipHostMallocMapped));
     memset(s->hb_host, 0, 65536 * sizeof(unsigned long long));
@@ -494,6 +502,19 @@ int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
   HIP_TRY(hipMemset(s->d_counters, 0, sizeof c));
   memset(st, 0, sizeof *st);
   fill_stats(c, st);
+#ifdef MT_PROF
+  {
+    unsigned long long pr[PROF_COUNT];
+    HIP_TRY(hipMemcpy(pr, s->d_prof, sizeof pr, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(s->d_prof, 0, sizeof pr));
+    static const char *names[PROF_COUNT] = {"trace_cycles", "scan_raypar_cycles", "scan_transposed_cycles",
+                                            "children_unwind_cycles", "n_raypar_scans", "n_transposed_scans",
+                                            "n_transposed_chunks", "n_raypar_tris", "n_traces", "shade_cycles"};
+    fprintf(stderr, "[mt prof]");
+    for (int i = 0; i < PROF_COUNT; i++) fprintf(stderr, " %s=%llu", names[i], pr[i]);
+    fprintf(stderr, "\n");
+  }
+#endif
   return check_status(c);
 }
 

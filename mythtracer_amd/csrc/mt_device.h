@@ -50,7 +50,12 @@ struct DevScene {
   // Debug heartbeat (normally NULL): host-visible words the kernel updates so
   // that a stuck launch can be diagnosed from the host (MT_DEBUG_HEARTBEAT=1).
   volatile unsigned long long *hb;
+  // Phase profile (only in the -DMT_PROF build): cycle and event sums.
+  unsigned long long *prof;
 };
+
+enum { PROF_TRACE = 0, PROF_SCAN_RAYPAR, PROF_SCAN_TRANSPOSED, PROF_CHILDREN_UNWIND, PROF_N_RAYPAR,
+       PROF_N_TRANSPOSED, PROF_N_CHUNKS, PROF_N_RAYPAR_TRIS, PROF_N_TRACES, PROF_SHADE, PROF_COUNT };
 
 enum {
   ST_RAYS_PRIMARY = 0,

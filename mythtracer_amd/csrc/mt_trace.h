@@ -39,6 +39,21 @@ namespace mt {
 
 #define MT_CONST __attribute__((address_space(4)))
 
+// Phase profiling (diagnostic build only: python -m mythtracer_amd.build --prof).
+#ifdef MT_PROF
+#define MT_PROF_DECL unsigned long long prof_acc[PROF_COUNT] = {0}; unsigned long long prof_t0 = 0, prof_t1 = 0
+#define MT_PROF_BEGIN(var) var = __builtin_amdgcn_s_memtime()
+#define MT_PROF_END(slot, var) prof_acc[slot] += __builtin_amdgcn_s_memtime() - var
+#define MT_PROF_COUNT(slot, n) prof_acc[slot] += (unsigned long long)(n)
+#define MT_PROF_FLUSH(ptr, lane) do { if ((ptr) && (lane) == 0) { for (int pi_ = 0; pi_ < PROF_COUNT; pi_++) if (prof_acc[pi_]) atomicAdd((ptr) + pi_, prof_acc[pi_]); } } while (0)
+#else
+#define MT_PROF_DECL
+#define MT_PROF_BEGIN(var)
+#define MT_PROF_END(slot, var)
+#define MT_PROF_COUNT(slot, n)
+#define MT_PROF_FLUSH(ptr, lane)
+#endif
+
 template <typename T>
 __device__ __forceinline__ const MT_CONST T *as_const(const T *p) {
   return (const MT_CONST T *)(uintptr_t)p;
@@ -540,6 +555,10 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
   S.force_mode = uniform_i32(S_arg.force_mode);
   S.scene_regular = uniform_i32(S_arg.scene_regular);
   S.hb = nullptr;
+  S.prof = uniform_ptr(S_arg.prof);
+  MT_PROF_DECL;
+  MT_PROF_BEGIN(prof_t0);
+  MT_PROF_COUNT(PROF_N_TRACES, 1);
   WaveStack stk;
   stk.bt = uniform_ptr(stk_arg.bt);
   stk.fc = uniform_ptr(stk_arg.fc);
@@ -623,10 +642,17 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
     const bool transposed = (S.force_mode < 3) && pc > 0 && (n_in * (30 + 45 * chunks) < 20 * pc);
     int best = -1;
     double best_t = 0.0;
+    MT_PROF_BEGIN(prof_t1);
     if (transposed) {
+      MT_PROF_COUNT(PROF_N_TRANSPOSED, 1);
+      MT_PROF_COUNT(PROF_N_CHUNKS, n_in * chunks);
       if (STATS) st.wave_tri_steps += (unsigned)(n_in * chunks) - (unsigned)pc;  // replaces the pc counted above
       if (mode == 0) scan_node_transposed<true, STATS>(S, r, lane, inmask, pb, pc, best, best_t, st);
       else scan_node_transposed<false, STATS>(S, r, lane, inmask, pb, pc, best, best_t, st);
+      MT_PROF_END(PROF_SCAN_TRANSPOSED, prof_t1);
+    } else {
+      MT_PROF_COUNT(PROF_N_RAYPAR, 1);
+      MT_PROF_COUNT(PROF_N_RAYPAR_TRIS, pc);
     }
     if (in) {
       if (STATS) {
@@ -638,6 +664,12 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
         else if (mode == 1) scan_node_prims<1, 0, STATS>(S, r, pb, pc, best, best_t, st);
         else scan_node_prims<0, 0, STATS>(S, r, pb, pc, best, best_t, st);
       }
+#ifdef MT_PROF
+    }
+    if (!transposed) MT_PROF_END(PROF_SCAN_RAYPAR, prof_t1);
+    MT_PROF_BEGIN(prof_t1);
+    if (in) {
+#endif
 
       unsigned ordw = 0;
       if (fc != 0) {
@@ -692,11 +724,14 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
         best_t = pbt;
       }
     }
+    MT_PROF_END(PROF_CHILDREN_UNWIND, prof_t1);
     if (__ballot(cur == -2) != 0ull) {
       status = DEV_ERR_UNWIND_BOUND;
       break;
     }
   }
+  MT_PROF_END(PROF_TRACE, prof_t0);
+  MT_PROF_FLUSH(S.prof, lane);
   if (status != DEV_OK) {
     out_prim = -1;
     out_t = 0.0;
