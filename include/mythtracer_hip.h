@@ -200,7 +200,8 @@ int mt_intersect_rays(mt_scene *scene, int n, const double *rays,
 /* Test hook: 0 = automatic (default), 1 = always use the exact
  * std::min/std::max comparison path, 2 = allow min/max instructions but not
  * the octant-uniform path, 3 = automatic but never the triangle-parallel
- * (transposed) node scan.  Results are identical in every mode. */
+ * (transposed) node scan, 4 = automatic but without the fp32 conservative
+ * pre-filter.  Results are identical in every mode. */
 int mt_scene_set_traversal_mode(mt_scene *scene, int mode);
 
 #ifdef __cplusplus

@@ -71,6 +71,7 @@ struct mt_scene {
   bool stats_enabled = true;
   unsigned long long *hb_host = nullptr;  // MT_DEBUG_HEARTBEAT: pinned, device-visible
   unsigned long long *d_prof = nullptr;   // -DMT_PROF build: phase cycle sums
+  DevScene *d_dev = nullptr;              // device copy of `dev` (DevScene::self)
 };
 
 namespace {
@@ -190,6 +191,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   HIP_TRY(hipMemsetAsync(s->d_work, 0, 8 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
+  HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
   // launch 1: primary rays + cost classes; launch 2: shading, heavy blocks first
   if (s->stats_enabled) {
     hipLaunchKernelGGL(primary_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
@@ -407,6 +409,17 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     std::vector<double> boxes(nt * 6 + 4 * 6, 0.0);
     if (nt) memcpy(boxes.data(), d->tri_aabb, nt * 6 * sizeof(double));
     if ((rc = upload(s, boxes.data(), boxes.size(), &s->dev.tri_aabb)) != MT_OK) return rc;
+    // fp32 copy for the conservative pre-filter (mt_trace.h Filter32); padded by
+    // 8 boxes because that loop looks four boxes ahead.
+    std::vector<float> boxes32(nt * 6 + 8 * 6, 0.0f);
+    double bmax[3] = {0.0, 0.0, 0.0};
+    for (size_t i = 0; i < nt * 6; i++) {
+      boxes32[i] = (float)boxes[i];
+      const double a = std::fabs(boxes[i]);
+      if (a > bmax[i % 3]) bmax[i % 3] = a;
+    }
+    if ((rc = upload(s, boxes32.data(), boxes32.size(), &s->dev.tri_aabb32)) != MT_OK) return rc;
+    for (int k = 0; k < 3; k++) s->dev.bmax[k] = bmax[k];
   }
   if ((rc = upload(s, d->tri_vertex, nt * 9, &s->dev.tri_vertex)) != MT_OK) return rc;
   if ((rc = upload(s, d->tri_normal, nt * 9, &s->dev.tri_normal)) != MT_OK) return rc;
@@ -443,6 +456,9 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   if ((rc = mt_scene_set_lights(s, nullptr, 0)) != MT_OK) return rc;
   s->dev.hb = nullptr;
   s->dev.prof = nullptr;
+  HIP_TRY(hipMalloc((void **)&s->d_dev, sizeof(DevScene)));
+  s->allocs.push_back(s->d_dev);
+  s->dev.self = s->d_dev;
 #ifdef MT_PROF
   HIP_TRY(hipMalloc((void **)&s->d_prof, PROF_COUNT * sizeof(unsigned long long)));
   s->allocs.push_back(s->d_prof);
@@ -489,7 +505,7 @@ int mt_scene_set_lights(mt_scene *s, const mt_light *lights, int n) {
 }
 
 int mt_scene_set_traversal_mode(mt_scene *s, int mode) {
-  if (!s || mode < 0 || mode > 3) return fail(MT_ERR_ARG, "mode must be 0..3");
+  if (!s || mode < 0 || mode > 4) return fail(MT_ERR_ARG, "mode must be 0..4");
   s->dev.force_mode = mode;
   return MT_OK;
 }
@@ -645,6 +661,7 @@ int mt_intersect_rays(mt_scene *s, int n, const double *rays, int32_t *tri, int3
   TRY_OR_CLEAN(hipMemset(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long)));
   const int block = s->waves_per_block * 64;
   const int grid = (n + block - 1) / block;
+  TRY_OR_CLEAN(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, nullptr));
   TRY_OR_CLEAN(hipEventRecord(s->ev0, nullptr));
   hipLaunchKernelGGL(intersect_kernel, dim3(grid), dim3(block), s->lds_bytes, nullptr, s->dev, n,
                      d_rays, d_tri, d_line, d_t, d_point, s->d_counters);

@@ -33,6 +33,8 @@ struct DevTexture {
 struct DevScene {
   const NodeRec *nodes;
   const double *tri_aabb;    // 6 per triangle, node-stream order
+  const float *tri_aabb32;   // the same boxes rounded to fp32 (conservative pre-filter)
+  double bmax[3];            // max |coordinate| of any triangle box, per axis
   const double *tri_vertex;  // 9 per triangle
   const double *tri_normal;  // 9 per triangle
   const double *tri_uvw;     // 9 per triangle
@@ -52,6 +54,9 @@ struct DevScene {
   volatile unsigned long long *hb;
   // Phase profile (only in the -DMT_PROF build): cycle and event sums.
   unsigned long long *prof;
+  // Copy of this struct in device memory (refreshed before every launch): the
+  // non-inlined traversal takes this one pointer instead of a by-value struct.
+  const DevScene *self;
 };
 
 enum { PROF_TRACE = 0, PROF_SCAN_RAYPAR, PROF_SCAN_TRANSPOSED, PROF_CHILDREN_UNWIND, PROF_N_RAYPAR,
@@ -103,7 +108,7 @@ struct RenderParams {
 
 // Bytes of LDS one wave needs for its traversal stack.
 __host__ __device__ inline size_t wave_stack_bytes(int depth) {
-  return (size_t)depth * 64 * 20;
+  return (size_t)depth * 64 * 20 + 4 * 64 * 4;  // stack frames + four per-lane work counters
 }
 
 constexpr int kFrameSlots = 11;  // 10 doubles + 1 packed meta word per frame

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, 3) void primary_kernel(DevScene S, RenderParam
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
-  stk.bind(smem + (size_t)wave_in_block * wave_stack_bytes(S.tree_depth), S.tree_depth);
+  stk.bind(smem, wave_in_block, S.tree_depth);
   const MT_CONST mt_material *mtls = as_const(S.mtls);
   LaneStats st;
   st.clear();
@@ -131,8 +131,12 @@ __global__ __launch_bounds__(256, 3) void primary_kernel(DevScene S, RenderParam
     }
     int prim;
     double t;
-    const int trc = trace_wave<STATS>(S, stk, lane, g.inside, cam_origin.x, cam_origin.y, cam_origin.z,
-                                      rd.x, rd.y, rd.z, prim, t, st);
+    const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, g.inside, cam_origin.x, cam_origin.y,
+                                          cam_origin.z, rd.x, rd.y, rd.z);
+    add_trace_stats<STATS>(st, to);
+    prim = to.prim;
+    t = to.t;
+    const int trc = to.status;
     if (trc != DEV_OK) {
       if (lane == 0) atomicMax(P.counters + ST_STATUS, (unsigned long long)trc);
       break;
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
   const int waves_per_block = blockDim.x >> 6;
   const int wave_id = blockIdx.x * waves_per_block + wave_in_block;
   WaveStack stk;
-  stk.bind(smem + (size_t)wave_in_block * wave_stack_bytes(S.tree_depth), S.tree_depth);
+  stk.bind(smem, wave_in_block, S.tree_depth);
   FrameIO fio;
   fio.base = P.frames + (size_t)wave_id * (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64;
   fio.lane = lane;
@@ -263,7 +267,11 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
         prim = alive ? P.hit_prim[px_index] : -1;
         t = alive ? P.hit_t[px_index] : 0.0;
       } else {
-        trc = trace_wave<STATS>(S, stk, lane, alive, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z, prim, t, st);
+        const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, alive, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+        add_trace_stats<STATS>(st, to);
+        prim = to.prim;
+        t = to.t;
+        trc = to.status;
       }
       if (S.hb) {
         const unsigned long long ex = __builtin_amdgcn_read_exec();
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
 
 // OctTree::IntersectRay for a batch of arbitrary rays: lane i of the grid
 // traces ray i.
-__global__ __launch_bounds__(256) void intersect_kernel(DevScene S, int n, const double *rays,
+__global__ __launch_bounds__(256, 3) void intersect_kernel(DevScene S, int n, const double *rays,
                                                         int *out_tri, int *out_line,
                                                         double *out_t, double *out_point,
                                                         unsigned long long *counters) {
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(256) void intersect_kernel(DevScene S, int n, const
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
-  stk.bind(smem + (size_t)wave_in_block * wave_stack_bytes(S.tree_depth), S.tree_depth);
+  stk.bind(smem, wave_in_block, S.tree_depth);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool want = i < n;
   double o[3] = {0, 0, 0}, d[3] = {0, 0, 1};
@@ -504,7 +512,11 @@ __global__ __launch_bounds__(256) void intersect_kernel(DevScene S, int n, const
   st.clear();
   int prim;
   double t;
-  const int trc = trace_wave<true>(S, stk, lane, want, o[0], o[1], o[2], d[0], d[1], d[2], prim, t, st);
+  const TraceOut to = trace_wave<true>(S.self, stk.base, lane, want, o[0], o[1], o[2], d[0], d[1], d[2]);
+  add_trace_stats<true>(st, to);
+  prim = to.prim;
+  t = to.t;
+  const int trc = to.status;
   if (trc != DEV_OK && counters && lane == 0) atomicMax(counters + ST_STATUS, (unsigned long long)trc);
   if (want) {
     if (out_tri) out_tri[i] = prim;

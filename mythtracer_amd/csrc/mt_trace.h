@@ -152,17 +152,24 @@ struct LaneStats {
 };
 
 // The per-wave traversal stack in LDS, structure-of-arrays over [depth][lane]
-// so that every access is bank-conflict free.
+// so that every access is bank-conflict free.  Held as a byte offset into the
+// block's LDS allocation (not as generic pointers, which would turn every
+// access into a flat_* instruction inside the non-inlined traversal).
+#define MT_LDS __attribute__((address_space(3)))
 struct WaveStack {
-  double *bt;      // best distance so far in that node
-  int *fc;         // first child of that node
-  int *bp;         // best primitive so far in that node (-1 none)
-  unsigned *ord;   // bits 0-23: child order (3 bits each), 24-27 count, 28-31 pos
-  __device__ __forceinline__ void bind(char *base, int depth) {
-    bt = (double *)base;
-    fc = (int *)(base + (size_t)depth * 64 * 8);
-    bp = (int *)(base + (size_t)depth * 64 * 12);
-    ord = (unsigned *)(base + (size_t)depth * 64 * 16);
+  unsigned base;   // byte offset of this wave's region in LDS
+  int depth;       // frames per lane
+  // bt: best distance so far in that node; fc: first child of that node;
+  // bp: best primitive so far (-1 none); ord: bits 0-23 child order (3 bits
+  // each), 24-27 count, 28-31 position.
+  __device__ __forceinline__ MT_LDS double *bt() const { return (MT_LDS double *)(uintptr_t)base; }
+  __device__ __forceinline__ MT_LDS int *fc() const { return (MT_LDS int *)(uintptr_t)(base + (unsigned)depth * 64u * 8u); }
+  __device__ __forceinline__ MT_LDS int *bp() const { return (MT_LDS int *)(uintptr_t)(base + (unsigned)depth * 64u * 12u); }
+  __device__ __forceinline__ MT_LDS unsigned *ord() const { return (MT_LDS unsigned *)(uintptr_t)(base + (unsigned)depth * 64u * 16u); }
+  __device__ __forceinline__ void bind(char *smem_base, int wave_in_block, int tree_depth) {
+    (void)smem_base;  // dynamic LDS starts at offset 0 of the block's allocation (no static LDS is declared)
+    depth = tree_depth;
+    base = (unsigned)wave_in_block * (unsigned)wave_stack_bytes(tree_depth);
   }
 };
 
@@ -350,6 +357,201 @@ __device__ __forceinline__ void scan_node_prims(const DevScene &S, const RayRegs
   if (pmask) flush_candidates<STATS>(S, r, pend, best, best_t, st);
 }
 
+// ---- fp32 conservative pre-filter ------------------------------------------
+// The exact test needs 18 fp64 instructions per box and rejects 99.8 % of the
+// boxes, nearly all of them by a wide margin.  Filter32 rejects most of those
+// with 10 fp32 instructions and NEVER rejects a box the exact test accepts;
+// survivors go through the exact fp64 test, so results cannot change.
+//
+// Exact quantities (per axis, NaN-free mode): t = fl64(fl64(x - o) * i) for a
+// box plane x, the ray's o and i = 1/d; the box passes iff max(near t) <=
+// min(far t) and min(far t) >= 0.
+// Filter: X = fl32(x) (host), I = fl32(i), F = fma32(X, I, C) with a per-ray
+// constant C.  With u = 2^-24, |x| <= bmax and M = (bmax + |o|) * |i|:
+//   |X*I - x*i| <= 2.01 u |x||i|,   |F - (X*I + C)| <= u (|X*I| + |C|),
+//   |t - (x - o) i| <= 2^-51 M,     |C| <= M + E
+// so |F - C - (-o*i) - t| <= 5 u M whenever E <= 8 u M.  Choosing
+//   E = 2^-21 M + 2^-100,  Cn <= -o*i - E (rounded down),  Cf >= -o*i + E (up)
+// gives  fma(X, I, Cn) <= t <= fma(X, I, Cf)  for every plane of the scene:
+// lower bounds of the near values, upper bounds of the far values.  Hence
+//   max3(lower near) > min3(upper far)  or  min3(upper far) < 0   =>  exact test fails.
+// Preconditions (else the filter is off for the wave): M <= 2^120 on every
+// axis (no fp32 overflow) and the NaN-free mode.  2^-100 covers fp32 underflow.
+struct Filter32 {
+  float ix, iy, iz;
+  float cnx, cny, cnz;
+  float cfx, cfy, cfz;
+};
+
+// next representable fp32 below / above a finite value
+__device__ __forceinline__ float f32_pred(float f) {
+  unsigned b = __builtin_bit_cast(unsigned, f);
+  if ((b & 0x7fffffffu) == 0u) return __builtin_bit_cast(float, 0x80000001u);  // below +-0: -denorm_min
+  b = (b & 0x80000000u) ? b + 1u : b - 1u;
+  return __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float f32_succ(float f) {
+  unsigned b = __builtin_bit_cast(unsigned, f);
+  if ((b & 0x7fffffffu) == 0u) return __builtin_bit_cast(float, 0x00000001u);
+  b = (b & 0x80000000u) ? b - 1u : b + 1u;
+  return __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float f32_not_above(double c) {
+  float f = (float)c;
+  if ((double)f > c) f = f32_pred(f);
+  return f;
+}
+__device__ __forceinline__ float f32_not_below(double c) {
+  float f = (float)c;
+  if ((double)f < c) f = f32_succ(f);
+  return f;
+}
+
+// Returns false when the filter must not be used for this ray.
+__device__ __forceinline__ bool make_filter32(const DevScene &S, const RayRegs &r, Filter32 &f) {
+  const double o[3] = {r.ox, r.oy, r.oz}, iv[3] = {r.ix, r.iy, r.iz};
+  float I[3], Cn[3], Cf[3];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const double M = (S.bmax[k] + __builtin_fabs(o[k])) * __builtin_fabs(iv[k]);
+    ok = ok && (M <= 0x1p120);  // false for NaN/inf as well
+    const double E = M * 0x1p-21 + 0x1p-100;
+    const double oi = o[k] * iv[k];
+    I[k] = (float)iv[k];
+    Cn[k] = f32_not_above(-oi - E);
+    Cf[k] = f32_not_below(-oi + E);
+  }
+  f.ix = I[0]; f.iy = I[1]; f.iz = I[2];
+  f.cnx = Cn[0]; f.cny = Cn[1]; f.cnz = Cn[2];
+  f.cfx = Cf[0]; f.cfy = Cf[1]; f.cfz = Cf[2];
+  return ok;
+}
+
+// fp32 verdict for one wave-uniform box b[0..5] (min xyz, max xyz): mask of
+// lanes for which the exact test MAY pass.  NaN compares as "may pass".
+template <int OCT>
+__device__ __forceinline__ unsigned long long filter32_pass(const float *b, const Filter32 &f) {
+  constexpr int kUGE = 11, kULE = 13;
+  constexpr int NX = (OCT & 1) ? 3 : 0, FX = (OCT & 1) ? 0 : 3;
+  constexpr int NY = (OCT & 2) ? 4 : 1, FY = (OCT & 2) ? 1 : 4;
+  constexpr int NZ = (OCT & 4) ? 5 : 2, FZ = (OCT & 4) ? 2 : 5;
+  const float tnx = __builtin_fmaf(b[NX], f.ix, f.cnx), tfx = __builtin_fmaf(b[FX], f.ix, f.cfx);
+  const float tny = __builtin_fmaf(b[NY], f.iy, f.cny), tfy = __builtin_fmaf(b[FY], f.iy, f.cfy);
+  const float tnz = __builtin_fmaf(b[NZ], f.iz, f.cnz), tfz = __builtin_fmaf(b[FZ], f.iz, f.cfz);
+  const float lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+  const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+  return __builtin_amdgcn_fcmpf(hi, 0.0f, kUGE) & __builtin_amdgcn_fcmpf(lo, hi, kULE);
+}
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef float f8v __attribute__((ext_vector_type(8)));
+struct QuadRegs {  // four fp32 boxes = 96 bytes
+  f16v lo;
+  f8v hi;
+};
+__device__ __forceinline__ void issue_quad(QuadRegs &q, const MT_CONST float *p) {
+  asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx8 %1, %2, 0x40"
+               : "=&s"(q.lo), "=&s"(q.hi)
+               : "s"(p));
+}
+__device__ __forceinline__ void await_quad(QuadRegs &q) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.lo), "+s"(q.hi));
+}
+
+// Four boxes (stream positions k..k+3): fp32 verdicts, then the exact fp64
+// test for the boxes some lane survived, in stream order.
+template <int OCT, bool STATS>
+__device__ __forceinline__ void scan_quad(const DevScene &S, const RayRegs &r, const Filter32 &f,
+                                          const QuadRegs &q, QuadRegs &next, bool next_in_flight,
+                                          int pb, int k, int pc, int &pend,
+                                          unsigned long long &pmask, int &best, double &best_t,
+                                          LaneStats &st) {
+  const float b0[6] = {q.lo[0], q.lo[1], q.lo[2], q.lo[3], q.lo[4], q.lo[5]};
+  const float b1[6] = {q.lo[6], q.lo[7], q.lo[8], q.lo[9], q.lo[10], q.lo[11]};
+  const float b2[6] = {q.lo[12], q.lo[13], q.lo[14], q.lo[15], q.hi[0], q.hi[1]};
+  const float b3[6] = {q.hi[2], q.hi[3], q.hi[4], q.hi[5], q.hi[6], q.hi[7]};
+  unsigned long long m[4];
+  m[0] = filter32_pass<OCT>(b0, f);
+  m[1] = (k + 1 < pc) ? filter32_pass<OCT>(b1, f) : 0ull;
+  m[2] = (k + 2 < pc) ? filter32_pass<OCT>(b2, f) : 0ull;
+  m[3] = (k + 3 < pc) ? filter32_pass<OCT>(b3, f) : 0ull;
+#ifdef MT_PROF
+  st.v[ST_BOX_TESTS] += 1;           // (prof build only) quads evaluated, reported via ScanOut
+#endif
+  if ((m[0] | m[1] | m[2] | m[3]) == 0ull) return;
+#ifdef MT_PROF
+  st.v[ST_NODE_VISITS] += 1;         // quads that took the slow path
+  st.v[ST_TRI_TESTS] += (unsigned)(__builtin_popcountll(m[0] | m[1] | m[2] | m[3]));  // lanes involved
+#endif
+  // Slow path (a few per cent of the quads).  It needs many more registers
+  // (fp64 box, Möller–Trumbore), so first let the look-ahead fetch land: from
+  // here on nothing is in flight and the compiler may spill what it likes.
+  if (next_in_flight) await_quad(next);
+  const unsigned long long me = 1ull << (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+  const MT_CONST double *boxes = as_const(S.tri_aabb) + (size_t)(pb + k) * 6;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (m[j] == 0ull) continue;  // wave-uniform
+    const MT_CONST double *a = boxes + j * 6;
+    const double b[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
+    const unsigned long long pm = slab_pass<2, OCT>(b, r) & m[j];
+    if (pm == 0ull) continue;
+    if (pm & pmask) {  // some lane would need a second slot: resolve first
+      flush_candidates<STATS>(S, r, pend, best, best_t, st);
+      pmask = 0;
+    }
+    if ((pm & me) != 0) pend = pb + k + j;
+    pmask |= pm;
+  }
+}
+
+// Ray-parallel scan with the fp32 pre-filter (octant-uniform mode only).
+template <int OCT, bool STATS>
+__device__ __forceinline__ void scan_node_filtered(const DevScene &S, const RayRegs &r,
+                                                   const Filter32 &f, int pb, int pc, int &best,
+                                                   double &best_t, LaneStats &st) {
+  if (pc <= 0) return;
+  const MT_CONST float *p = as_const(S.tri_aabb32) + (size_t)pb * 6;
+  int pend = -1;
+  unsigned long long pmask = 0;
+  QuadRegs A, B;
+  issue_quad(A, p);
+  await_quad(A);
+  for (int k = 0;;) {
+    const bool more_b = k + 4 < pc;
+    if (more_b) issue_quad(B, p + 24);
+    scan_quad<OCT, STATS>(S, r, f, A, B, more_b, pb, k, pc, pend, pmask, best, best_t, st);
+    if (!more_b) break;
+    await_quad(B);
+    k += 4;
+    const bool more_a = k + 4 < pc;
+    p += 48;
+    if (more_a) issue_quad(A, p);
+    scan_quad<OCT, STATS>(S, r, f, B, A, more_a, pb, k, pc, pend, pmask, best, best_t, st);
+    if (!more_a) break;
+    await_quad(A);
+    k += 4;
+  }
+  if (pmask) flush_candidates<STATS>(S, r, pend, best, best_t, st);
+}
+
+template <bool STATS>
+__device__ __forceinline__ void scan_node_filtered_octant(const DevScene &S, const RayRegs &r,
+                                                          const Filter32 &f, int pb, int pc, int oct,
+                                                          int &best, double &best_t, LaneStats &st) {
+  switch (oct) {
+    case 0: scan_node_filtered<0, STATS>(S, r, f, pb, pc, best, best_t, st); break;
+    case 1: scan_node_filtered<1, STATS>(S, r, f, pb, pc, best, best_t, st); break;
+    case 2: scan_node_filtered<2, STATS>(S, r, f, pb, pc, best, best_t, st); break;
+    case 3: scan_node_filtered<3, STATS>(S, r, f, pb, pc, best, best_t, st); break;
+    case 4: scan_node_filtered<4, STATS>(S, r, f, pb, pc, best, best_t, st); break;
+    case 5: scan_node_filtered<5, STATS>(S, r, f, pb, pc, best, best_t, st); break;
+    case 6: scan_node_filtered<6, STATS>(S, r, f, pb, pc, best, best_t, st); break;
+    default: scan_node_filtered<7, STATS>(S, r, f, pb, pc, best, best_t, st); break;
+  }
+}
+
 // Transposed scan: ONE ray at a time, 64 TRIANGLES per step (lane = triangle).
 // Used when only a few lanes want a node: scanning a 90-triangle list for 2
 // rays costs 4 of these steps instead of 90 ray-parallel ones.  All 64 lanes
@@ -530,40 +732,171 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
   return (ord & 0x00ffffffu) | (cnt << 24);
 }
 
+// Non-inlined entry of order_children (its exact-mode variant alone needs ~60
+// registers; as a function of its own it does not inflate the traversal).
+template <int MODE>
+__device__ __attribute__((noinline)) unsigned order_children_call(const NodeRec *N, double ox, double oy,
+                                                                  double oz, double ix, double iy,
+                                                                  double iz) {
+  RayRegs r;
+  r.ox = ox; r.oy = oy; r.oz = oz;
+  r.dx = 0.0; r.dy = 0.0; r.dz = 0.0;
+  r.ix = ix; r.iy = iy; r.iz = iz;
+  return order_children<MODE>(as_const(uniform_ptr(N)), r);
+}
+
+// ---- non-inlined entry points of the node scans ------------------------------
+// Each scan loop is a function of its own: own register allocation, so that the
+// SGPR box buffers (48 registers, partly in flight) never compete with the
+// traversal's own state.  Arguments arrive in VGPRs and are made uniform again.
+struct ScanOut {
+  int best;
+  double best_t;
+  unsigned mt_tests;
+#ifdef MT_PROF
+  unsigned quads = 0, slow_quads = 0, slow_lanes = 0;
+#endif
+};
+
+__device__ __forceinline__ DevScene scan_ctx(const float *b32, const double *b64, const double *vtx) {
+  DevScene S;
+  S.tri_aabb32 = uniform_ptr(b32);
+  S.tri_aabb = uniform_ptr(b64);
+  S.tri_vertex = uniform_ptr(vtx);
+  return S;
+}
+
+template <int OCT, bool STATS>
+__device__ __attribute__((noinline)) ScanOut scan_filtered_call(const float *b32, const double *b64,
+                                                                const double *vtx, int pb, int pc,
+                                                                RayRegs r, Filter32 f) {
+  const DevScene S = scan_ctx(b32, b64, vtx);
+  LaneStats st;
+  st.clear();
+  ScanOut o{-1, 0.0, 0u};
+  scan_node_filtered<OCT, STATS>(S, r, f, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
+  o.mt_tests = st.v[ST_MT_TESTS];
+#ifdef MT_PROF
+  o.quads = st.v[ST_BOX_TESTS]; o.slow_quads = st.v[ST_NODE_VISITS]; o.slow_lanes = st.v[ST_TRI_TESTS];
+#endif
+  return o;
+}
+
+template <int MODE, int OCT, bool STATS>
+__device__ __attribute__((noinline)) ScanOut scan_exact_call(const double *b64, const double *vtx, int pb,
+                                                             int pc, RayRegs r) {
+  const DevScene S = scan_ctx(nullptr, b64, vtx);
+  LaneStats st;
+  st.clear();
+  ScanOut o{-1, 0.0, 0u};
+  scan_node_prims<MODE, OCT, STATS>(S, r, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
+  o.mt_tests = st.v[ST_MT_TESTS];
+  return o;
+}
+
+template <bool EX, bool STATS>
+__device__ __attribute__((noinline)) ScanOut scan_transposed_call(const double *b64, const double *vtx,
+                                                                  int pb, int pc, int lane,
+                                                                  unsigned inmask_lo, unsigned inmask_hi,
+                                                                  RayRegs r) {
+  const DevScene S = scan_ctx(nullptr, b64, vtx);
+  const unsigned long long inmask =
+      ((unsigned long long)(unsigned)uniform_i32((int)inmask_hi) << 32) | (unsigned)uniform_i32((int)inmask_lo);
+  LaneStats st;
+  st.clear();
+  ScanOut o{-1, 0.0, 0u};
+  scan_node_transposed<EX, STATS>(S, r, lane, inmask, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
+  o.mt_tests = st.v[ST_MT_TESTS];
+  return o;
+}
+
+template <bool STATS>
+__device__ __forceinline__ ScanOut scan_filtered_dispatch(const DevScene &S, int oct, int pb, int pc,
+                                                          const RayRegs &r, const Filter32 &f) {
+  switch (oct) {
+    case 0: return scan_filtered_call<0, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
+    case 1: return scan_filtered_call<1, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
+    case 2: return scan_filtered_call<2, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
+    case 3: return scan_filtered_call<3, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
+    case 4: return scan_filtered_call<4, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
+    case 5: return scan_filtered_call<5, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
+    case 6: return scan_filtered_call<6, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
+    default: return scan_filtered_call<7, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
+  }
+}
+
+template <bool STATS>
+__device__ __forceinline__ ScanOut scan_octant_dispatch(const DevScene &S, int oct, int pb, int pc,
+                                                        const RayRegs &r) {
+  switch (oct) {
+    case 0: return scan_exact_call<2, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+    case 1: return scan_exact_call<2, 1, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+    case 2: return scan_exact_call<2, 2, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+    case 3: return scan_exact_call<2, 3, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+    case 4: return scan_exact_call<2, 4, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+    case 5: return scan_exact_call<2, 5, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+    case 6: return scan_exact_call<2, 6, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+    default: return scan_exact_call<2, 7, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+  }
+}
+
 // One closest-hit query per lane.  Must be called by all 64 lanes of the wave
 // (want = false for lanes without a ray).  out_prim = stream index or -1.
+// Result of one traversal, returned by value (in registers).
+struct TraceOut {
+  int status;   // DEV_OK or DEV_ERR_*
+  int prim;     // stream index of the closest hit, -1 none
+  double t;
+  unsigned box_tests, node_visits, tri_tests, mt_tests;  // per lane
+  unsigned wave_node_steps, wave_tri_steps;              // wave-uniform
+};
+
 // NOT inlined on purpose: as a function of its own the traversal gets its own
-// register allocation, free of the shading kernel's SGPR/VGPR pressure.  That
-// is what keeps the in-flight box registers of the scan loop from being
-// spilled (tools/check_asm_prefetch.py) and the inner loop free of spill code.
+// register allocation, free of the shading kernel's SGPR/VGPR pressure.  It
+// takes ONE pointer to the scene description in device memory (read with
+// scalar loads) and returns its result in registers: nothing goes through the
+// stack.  Must be called by all 64 lanes (want = false for lanes without a ray).
 template <bool STATS>
-__device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const WaveStack &stk_arg, int lane,
-                                          bool want, double ox, double oy, double oz,
-                                          double dx, double dy, double dz, int &out_prim,
-                                          double &out_t, LaneStats &st) {
-  // re-establish uniformity of everything scalar loads are addressed with
+__device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, unsigned stack_base, int lane,
+                                                         bool want, double ox, double oy, double oz,
+                                                         double dx, double dy, double dz) {
+  const MT_CONST DevScene *G = as_const(uniform_ptr(scene));
   DevScene S;
-  S.nodes = uniform_ptr(S_arg.nodes);
-  S.tri_aabb = uniform_ptr(S_arg.tri_aabb);
-  S.tri_vertex = uniform_ptr(S_arg.tri_vertex);
-  S.tri_normal = nullptr; S.tri_uvw = nullptr; S.tri_mtl = nullptr; S.tri_line = nullptr;
-  S.mtls = nullptr; S.texs = nullptr; S.lights = nullptr;
-  S.n_lights = 0;
-  S.n_tris = uniform_i32(S_arg.n_tris);
-  S.n_nodes = uniform_i32(S_arg.n_nodes);
-  S.tree_depth = uniform_i32(S_arg.tree_depth);
-  S.force_mode = uniform_i32(S_arg.force_mode);
-  S.scene_regular = uniform_i32(S_arg.scene_regular);
+  S.nodes = G->nodes;
+  S.tri_aabb = G->tri_aabb;
+  S.tri_aabb32 = G->tri_aabb32;
+  S.tri_vertex = G->tri_vertex;
+  S.bmax[0] = G->bmax[0]; S.bmax[1] = G->bmax[1]; S.bmax[2] = G->bmax[2];
+  S.n_tris = G->n_tris;
+  S.n_nodes = G->n_nodes;
+  S.tree_depth = G->tree_depth;
+  S.force_mode = G->force_mode;
+  S.scene_regular = G->scene_regular;
   S.hb = nullptr;
-  S.prof = uniform_ptr(S_arg.prof);
+  S.prof = G->prof;
+  LaneStats st;
+  st.clear();
+  int out_prim;
+  double out_t;
   MT_PROF_DECL;
+#ifdef MT_PROF
+  unsigned long long prof_quads = 0, prof_slow = 0;
+#endif
   MT_PROF_BEGIN(prof_t0);
   MT_PROF_COUNT(PROF_N_TRACES, 1);
   WaveStack stk;
-  stk.bt = uniform_ptr(stk_arg.bt);
-  stk.fc = uniform_ptr(stk_arg.fc);
-  stk.bp = uniform_ptr(stk_arg.bp);
-  stk.ord = uniform_ptr(stk_arg.ord);
+  stk.base = (unsigned)uniform_i32((int)stack_base);
+  stk.depth = S.tree_depth;
+  MT_LDS double *const stk_bt = stk.bt();
+  MT_LDS int *const stk_fc = stk.fc();
+  MT_LDS int *const stk_bp = stk.bp();
+  MT_LDS unsigned *const stk_ord = stk.ord();
+  // per-lane work counters of this traversal live in LDS (behind the stack),
+  // not in registers: four ds_add per node step instead of four live VGPRs
+  MT_LDS unsigned *const cnt = (MT_LDS unsigned *)(uintptr_t)(stk.base + (unsigned)stk.depth * 64u * 20u);
+  if (STATS) {
+    cnt[0 * 64 + lane] = 0; cnt[1 * 64 + lane] = 0; cnt[2 * 64 + lane] = 0; cnt[3 * 64 + lane] = 0;
+  }
   RayRegs r;
   r.ox = ox; r.oy = oy; r.oz = oz;
   r.dx = dx; r.dy = dy; r.dz = dz;
@@ -578,13 +911,17 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
                    r.ix != 0.0 && r.iy != 0.0 && r.iz != 0.0;
   const bool all_regular = (S.scene_regular != 0) && (S.force_mode != 1) &&
                            (__ballot(want && !fin) == 0ull);
+  Filter32 f32;
+  const bool f32_ok = make_filter32(S, r, f32);
+  const bool use_filter = all_regular && (S.force_mode != 4) && (S.force_mode != 2) &&
+                          (__ballot(want && !f32_ok) == 0ull);
 
   const MT_CONST NodeRec *nodes = as_const(S.nodes);
   int cur = -1;
   if (want) {
     // root box test, octtree.cc:35-37 (exact form; once per ray)
     const MT_CONST NodeRec *R = nodes;
-    if (STATS) st.v[ST_BOX_TESTS]++;
+    if (STATS) cnt[0 * 64 + lane] = 1;
     const double t1 = (R->lo[0] - ox) * r.ix, t2 = (R->hi[0] - ox) * r.ix;
     const double t3 = (R->lo[1] - oy) * r.iy, t4 = (R->hi[1] - oy) * r.iy;
     const double t5 = (R->lo[2] - oz) * r.iz, t6 = (R->hi[2] - oz) * r.iz;
@@ -647,8 +984,12 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
       MT_PROF_COUNT(PROF_N_TRANSPOSED, 1);
       MT_PROF_COUNT(PROF_N_CHUNKS, n_in * chunks);
       if (STATS) st.wave_tri_steps += (unsigned)(n_in * chunks) - (unsigned)pc;  // replaces the pc counted above
-      if (mode == 0) scan_node_transposed<true, STATS>(S, r, lane, inmask, pb, pc, best, best_t, st);
-      else scan_node_transposed<false, STATS>(S, r, lane, inmask, pb, pc, best, best_t, st);
+      const ScanOut o = (mode == 0)
+          ? scan_transposed_call<true, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), r)
+          : scan_transposed_call<false, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), r);
+      best = o.best;
+      best_t = o.best_t;
+      if (STATS && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       MT_PROF_END(PROF_SCAN_TRANSPOSED, prof_t1);
     } else {
       MT_PROF_COUNT(PROF_N_RAYPAR, 1);
@@ -656,13 +997,27 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
     }
     if (in) {
       if (STATS) {
-        st.v[ST_NODE_VISITS]++;
-        st.v[ST_TRI_TESTS] += (unsigned)pc;
+        __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
       if (!transposed) {
-        if (mode == 2) scan_node_octant<STATS>(S, r, pb, pc, sx | (sy << 1) | (sz << 2), best, best_t, st);
-        else if (mode == 1) scan_node_prims<1, 0, STATS>(S, r, pb, pc, best, best_t, st);
-        else scan_node_prims<0, 0, STATS>(S, r, pb, pc, best, best_t, st);
+        const int oct = sx | (sy << 1) | (sz << 2);
+        ScanOut o;
+        if (mode == 2 && use_filter) {
+          o = scan_filtered_dispatch<STATS>(S, oct, pb, pc, r, f32);
+#ifdef MT_PROF
+          MT_PROF_COUNT(PROF_SHADE, 0);
+          prof_acc[PROF_N_CHUNKS + 0] += 0;
+          prof_quads += (unsigned long long)__builtin_amdgcn_readfirstlane((int)o.quads);
+          prof_slow += (unsigned long long)__builtin_amdgcn_readfirstlane((int)o.slow_quads);
+#endif
+        }
+        else if (mode == 2) o = scan_octant_dispatch<STATS>(S, oct, pb, pc, r);
+        else if (mode == 1) o = scan_exact_call<1, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+        else o = scan_exact_call<0, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+        best = o.best;
+        best_t = o.best_t;
+        if (STATS && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
 #ifdef MT_PROF
     }
@@ -673,8 +1028,10 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
 
       unsigned ordw = 0;
       if (fc != 0) {
-        if (STATS) st.v[ST_BOX_TESTS] += 8;
-        ordw = (mode == 0) ? order_children<0>(N, r) : order_children<1>(N, r);
+        if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const NodeRec *Np = S.nodes + n;
+        ordw = (mode == 0) ? order_children_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz)
+                           : order_children_call<1>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz);
       }
       // Unwind / descend: the tail of PrimitiveIntersectRay (octtree.cc:219-256)
       int my_fc = fc;
@@ -693,10 +1050,10 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
             break;
           }
           const int at = depth * 64 + lane;
-          stk.fc[at] = my_fc;
-          stk.bt[at] = best_t;
-          stk.bp[at] = best;
-          stk.ord[at] = (ordw & 0x0fffffffu) | (pos << 28);
+          stk_fc[at] = my_fc;
+          stk_bt[at] = best_t;
+          stk_bp[at] = best;
+          stk_ord[at] = (ordw & 0x0fffffffu) | (pos << 28);
           depth++;
           cur = child;
           break;
@@ -709,10 +1066,10 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
         }
         depth--;
         const int at = depth * 64 + lane;
-        const unsigned po = stk.ord[at];
-        int pbp = stk.bp[at];
-        double pbt = stk.bt[at];
-        my_fc = stk.fc[at];
+        const unsigned po = stk_ord[at];
+        int pbp = stk_bp[at];
+        double pbt = stk_bt[at];
+        my_fc = stk_fc[at];
         pos = po >> 28;
         ordw = po & 0x0fffffffu;
         if (best >= 0 && !(pbp >= 0 && best_t > pbt)) {  // :233-246 take it and break
@@ -731,12 +1088,38 @@ __device__ __attribute__((noinline)) int trace_wave(const DevScene &S_arg, const
     }
   }
   MT_PROF_END(PROF_TRACE, prof_t0);
+#ifdef MT_PROF
+  prof_acc[PROF_SHADE] = (prof_quads << 32) | (prof_slow & 0xffffffffull);  // packed: quads | slow quads
+#endif
   MT_PROF_FLUSH(S.prof, lane);
   if (status != DEV_OK) {
     out_prim = -1;
     out_t = 0.0;
   }
-  return status;
+  TraceOut o;
+  o.status = status;
+  o.prim = out_prim;
+  o.t = out_t;
+  o.box_tests = STATS ? cnt[0 * 64 + lane] : 0u;
+  o.node_visits = STATS ? cnt[1 * 64 + lane] : 0u;
+  o.tri_tests = STATS ? cnt[2 * 64 + lane] : 0u;
+  o.mt_tests = STATS ? cnt[3 * 64 + lane] : 0u;
+  o.wave_node_steps = st.wave_node_steps;
+  o.wave_tri_steps = st.wave_tri_steps;
+  return o;
+}
+
+// Folds a traversal's counters into the caller's.
+template <bool STATS>
+__device__ __forceinline__ void add_trace_stats(LaneStats &st, const TraceOut &o) {
+  if (STATS) {
+    st.v[ST_BOX_TESTS] += o.box_tests;
+    st.v[ST_NODE_VISITS] += o.node_visits;
+    st.v[ST_TRI_TESTS] += o.tri_tests;
+    st.v[ST_MT_TESTS] += o.mt_tests;
+    st.wave_node_steps += (unsigned)__builtin_amdgcn_readfirstlane((int)o.wave_node_steps);
+    st.wave_tri_steps += (unsigned)__builtin_amdgcn_readfirstlane((int)o.wave_tri_steps);
+  }
 }
 
 }  // namespace mt

@@ -370,3 +370,12 @@ def test_reference_drivers_compile_against_our_headers(tmp_path):
     for drv in ("main_local.cc",):
         subprocess.check_call(["g++", "-std=c++17", "-fsyntax-only", "-I", inc,
                                "/root/reference/VerStarting/" + drv])
+
+
+def test_hand_issued_scalar_prefetch_is_safe_on_the_isa():
+    """The scan loop issues its box fetches from inline asm; hipcc does not model
+    them.  tools/check_asm_prefetch.py compiles the library to ISA and proves that
+    nothing touches the in-flight SGPRs before the matching s_waitcnt."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_prefetch.py")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0, r.stdout.decode()
