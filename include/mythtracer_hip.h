@@ -201,7 +201,8 @@ int mt_intersect_rays(mt_scene *scene, int n, const double *rays,
  * std::min/std::max comparison path, 2 = allow min/max instructions but not
  * the octant-uniform path, 3 = automatic but never the triangle-parallel
  * (transposed) node scan, 4 = automatic but without the fp32 conservative
- * pre-filter.  Results are identical in every mode. */
+ * pre-filter, 5 = automatic but every node through a wave step (no
+ * lane-parallel scan of small nodes).  Results are identical in every mode. */
 int mt_scene_set_traversal_mode(mt_scene *scene, int mode);
 
 #ifdef __cplusplus

@@ -505,7 +505,7 @@ int mt_scene_set_lights(mt_scene *s, const mt_light *lights, int n) {
 }
 
 int mt_scene_set_traversal_mode(mt_scene *s, int mode) {
-  if (!s || mode < 0 || mode > 4) return fail(MT_ERR_ARG, "mode must be 0..4");
+  if (!s || mode < 0 || mode > 5) return fail(MT_ERR_ARG, "mode must be 0..5");
   s->dev.force_mode = mode;
   return MT_OK;
 }
@@ -525,7 +525,7 @@ int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
     HIP_TRY(hipMemset(s->d_prof, 0, sizeof pr));
     static const char *names[PROF_COUNT] = {"trace_cycles", "scan_raypar_cycles", "scan_transposed_cycles",
                                             "children_unwind_cycles", "n_raypar_scans", "n_transposed_scans",
-                                            "n_transposed_chunks", "n_raypar_tris", "n_traces", "shade_cycles"};
+                                            "n_transposed_chunks", "n_raypar_tris", "n_traces", "lane_phase_cycles"};
     fprintf(stderr, "[mt prof]");
     for (int i = 0; i < PROF_COUNT; i++) fprintf(stderr, " %s=%llu", names[i], pr[i]);
     fprintf(stderr, "\n");

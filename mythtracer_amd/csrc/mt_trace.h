@@ -151,6 +151,13 @@ struct LaneStats {
   }
 };
 
+// Result of scanning one node's triangle list for a lane.
+struct ScanOut {
+  int best;           // stream index of the closest hit in the list, -1 none
+  double best_t;
+  unsigned mt_tests;  // Möller–Trumbore evaluations performed for this lane
+};
+
 // The per-wave traversal stack in LDS, structure-of-arrays over [depth][lane]
 // so that every access is bank-conflict free.  Held as a byte offset into the
 // block's LDS allocation (not as generic pointers, which would turn every
@@ -476,14 +483,7 @@ __device__ __forceinline__ void scan_quad(const DevScene &S, const RayRegs &r, c
   m[1] = (k + 1 < pc) ? filter32_pass<OCT>(b1, f) : 0ull;
   m[2] = (k + 2 < pc) ? filter32_pass<OCT>(b2, f) : 0ull;
   m[3] = (k + 3 < pc) ? filter32_pass<OCT>(b3, f) : 0ull;
-#ifdef MT_PROF
-  st.v[ST_BOX_TESTS] += 1;           // (prof build only) quads evaluated, reported via ScanOut
-#endif
   if ((m[0] | m[1] | m[2] | m[3]) == 0ull) return;
-#ifdef MT_PROF
-  st.v[ST_NODE_VISITS] += 1;         // quads that took the slow path
-  st.v[ST_TRI_TESTS] += (unsigned)(__builtin_popcountll(m[0] | m[1] | m[2] | m[3]));  // lanes involved
-#endif
   // Slow path (a few per cent of the quads).  It needs many more registers
   // (fp64 box, Möller–Trumbore), so first let the look-ahead fetch land: from
   // here on nothing is in flight and the compiler may spill what it likes.
@@ -732,6 +732,55 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
   return (ord & 0x00ffffffu) | (cnt << 24);
 }
 
+// ---- lane-parallel scan of a SMALL node ---------------------------------------
+// A leaf of the reference's octree holds fewer than SPLIT_BOUNDARY = 16
+// triangles and deep split nodes keep only a few straddlers; streaming such a
+// list wave-uniformly costs a whole wave step (node record, scalar fetch
+// latency, call) for a handful of tests.  Instead every lane scans ITS OWN small
+// node here, all lanes at once, with per-lane loads: the same tests in the same
+// order (octtree.cc:177-196), so the same result.
+template <bool EX>
+__device__ __forceinline__ bool slab_pass_lane(const double *b, const RayRegs &r) {
+  const double t1 = (b[0] - r.ox) * r.ix, t2 = (b[3] - r.ox) * r.ix;
+  const double t3 = (b[1] - r.oy) * r.iy, t4 = (b[4] - r.oy) * r.iy;
+  const double t5 = (b[2] - r.oz) * r.iz, t6 = (b[5] - r.oz) * r.iz;
+  const double tmax = mn3<EX>(mx<EX>(t1, t2), mx<EX>(t3, t4), mx<EX>(t5, t6));
+  const double tmin = mx3<EX>(mn<EX>(t1, t2), mn<EX>(t3, t4), mn<EX>(t5, t6));
+  return !(tmax < 0.0) && !(tmin > tmax);
+}
+
+template <bool EX, bool STATS>
+__device__ __attribute__((noinline)) ScanOut scan_small_lane_call(const double *b64, const double *vtx,
+                                                                  int pb, int pc, RayRegs r) {
+  ScanOut o{-1, 0.0, 0u};
+  for (int k = 0; k < pc; k++) {
+    const double *bp = b64 + (size_t)(pb + k) * 6;
+    const double b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
+    if (!slab_pass_lane<EX>(b, r)) continue;
+    if (STATS) o.mt_tests++;
+    double t;
+    if (moller_trumbore(vtx + (size_t)(pb + k) * 9, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &t)) {
+      if (!(o.best >= 0 && t > o.best_t)) {
+        o.best = pb + k;
+        o.best_t = t;
+      }
+    }
+  }
+  return o;
+}
+
+// order_children for a per-lane node (no uniformisation of the pointer)
+template <int MODE>
+__device__ __attribute__((noinline)) unsigned order_children_lane_call(const NodeRec *N, double ox, double oy,
+                                                                       double oz, double ix, double iy,
+                                                                       double iz) {
+  RayRegs r;
+  r.ox = ox; r.oy = oy; r.oz = oz;
+  r.dx = 0.0; r.dy = 0.0; r.dz = 0.0;
+  r.ix = ix; r.iy = iy; r.iz = iz;
+  return order_children<MODE>(as_const(N), r);
+}
+
 // Non-inlined entry of order_children (its exact-mode variant alone needs ~60
 // registers; as a function of its own it does not inflate the traversal).
 template <int MODE>
@@ -749,14 +798,6 @@ __device__ __attribute__((noinline)) unsigned order_children_call(const NodeRec 
 // Each scan loop is a function of its own: own register allocation, so that the
 // SGPR box buffers (48 registers, partly in flight) never compete with the
 // traversal's own state.  Arguments arrive in VGPRs and are made uniform again.
-struct ScanOut {
-  int best;
-  double best_t;
-  unsigned mt_tests;
-#ifdef MT_PROF
-  unsigned quads = 0, slow_quads = 0, slow_lanes = 0;
-#endif
-};
 
 __device__ __forceinline__ DevScene scan_ctx(const float *b32, const double *b64, const double *vtx) {
   DevScene S;
@@ -776,9 +817,6 @@ __device__ __attribute__((noinline)) ScanOut scan_filtered_call(const float *b32
   ScanOut o{-1, 0.0, 0u};
   scan_node_filtered<OCT, STATS>(S, r, f, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
   o.mt_tests = st.v[ST_MT_TESTS];
-#ifdef MT_PROF
-  o.quads = st.v[ST_BOX_TESTS]; o.slow_quads = st.v[ST_NODE_VISITS]; o.slow_lanes = st.v[ST_TRI_TESTS];
-#endif
   return o;
 }
 
@@ -879,9 +917,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   int out_prim;
   double out_t;
   MT_PROF_DECL;
-#ifdef MT_PROF
-  unsigned long long prof_quads = 0, prof_slow = 0;
-#endif
   MT_PROF_BEGIN(prof_t0);
   MT_PROF_COUNT(PROF_N_TRACES, 1);
   WaveStack stk;
@@ -934,12 +969,114 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   const int syl = __builtin_signbit(r.iy) ? 1 : 0;
   const int szl = __builtin_signbit(r.iz) ? 1 : 0;
 
-  // Each step retires at least one (lane, node) visit and a lane visits a node
-  // at most once per query, so 64 * n_nodes steps can never be exceeded.
+  // Record of the node a lane has to process next (valid while cur >= 0).
+  int cur_fc = 0, cur_pb = 0, cur_pc = 0;
+  auto load_record = [&](int node) {
+    const int *q = (const int *)(S.nodes + node) + 18;  // NodeRec: first_child, prim_begin, prim_count
+    cur_fc = q[0];
+    cur_pb = q[1];
+    cur_pc = q[2];
+  };
+  if (cur >= 0) load_record(cur);
+
+  // The tail of PrimitiveIntersectRay for one node (octtree.cc:199-256): order
+  // the children the ray enters, then descend into the next one or hand the
+  // node's result up, as often as that completes parents.  Ends with the lane's
+  // next node in `cur` (+ its record) or with cur = -1 and the final result.
+  auto finish_node = [&](int fc, unsigned ordw, int best, double best_t) {
+    int my_fc = fc;
+    unsigned pos = 0;
+    for (int guard = 0;; guard++) {
+      if (guard > S.tree_depth + 1) {  // cannot happen: one pop per level at most
+        cur = -2;
+        break;
+      }
+      const unsigned n_ord = (ordw >> 24) & 15u;
+      if (pos < n_ord) {
+        const int child = my_fc + (int)((ordw >> (3 * pos)) & 7u);
+        pos++;
+        if (depth >= S.tree_depth) {  // cannot happen: stack sized for the validated depth
+          cur = -2;
+          break;
+        }
+        const int at = depth * 64 + lane;
+        stk_fc[at] = my_fc;
+        stk_bt[at] = best_t;
+        stk_bp[at] = best;
+        stk_ord[at] = (ordw & 0x0fffffffu) | (pos << 28);
+        depth++;
+        cur = child;
+        load_record(child);
+        break;
+      }
+      if (depth == 0) {
+        out_prim = best;
+        out_t = best_t;
+        cur = -1;
+        break;
+      }
+      depth--;
+      const int at = depth * 64 + lane;
+      const unsigned po = stk_ord[at];
+      int pbp = stk_bp[at];
+      double pbt = stk_bt[at];
+      my_fc = stk_fc[at];
+      pos = po >> 28;
+      ordw = po & 0x0fffffffu;
+      if (best >= 0 && !(pbp >= 0 && best_t > pbt)) {  // :233-246 take it and break
+        pbp = best;
+        pbt = best_t;
+        pos = (po >> 24) & 15u;
+      }
+      best = pbp;
+      best_t = pbt;
+    }
+  };
+
+  // Nodes with fewer than kBigNode triangles are scanned lane-parallel, larger
+  // ones wave-uniformly.  (Every leaf is small: the reference splits at 16.)
+  constexpr int kBigNode = 16;
+  const bool lane_phase = (S.force_mode != 5);
+  // Each wave step retires at least one (lane, node) visit and a lane visits a
+  // node at most once per query, so 64 * n_nodes steps can never be exceeded.
   const long long step_bound = 64ll * (long long)S.n_nodes + 64;
   long long steps = 0;
   int status = DEV_OK;
   for (;;) {
+    // ---- phase A: every lane works through its own small nodes
+    if (lane_phase) {
+      MT_PROF_BEGIN(prof_t1);
+      for (int guard = 0; cur >= 0 && cur_pc < kBigNode; guard++) {
+        if (guard > S.n_nodes) {
+          cur = -2;
+          break;
+        }
+        const ScanOut o = all_regular
+            ? scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r)
+            : scan_small_lane_call<true, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r);
+        if (STATS) {
+          __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)cur_pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        unsigned ordw = 0;
+        const int fc = cur_fc;
+        if (fc != 0) {
+          if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          const NodeRec *Np = S.nodes + cur;
+          ordw = all_regular ? order_children_lane_call<1>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz)
+                             : order_children_lane_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz);
+        }
+        finish_node(fc, ordw, o.best, o.best_t);
+      }
+      MT_PROF_END(PROF_SHADE, prof_t1);
+      if (__ballot(cur == -2) != 0ull) {
+        status = DEV_ERR_UNWIND_BOUND;
+        break;
+      }
+    }
+
+    // ---- phase B: one BIG node, wave-uniform
     const int n = wave_min_i32(cur >= 0 ? cur : 0x7fffffff);
     if (n == 0x7fffffff) break;
     if (++steps > step_bound || n < 0 || n >= S.n_nodes) {
@@ -948,10 +1085,11 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     }
     const bool in = (cur == n);
     const unsigned long long inmask = __ballot(in);
-    const MT_CONST NodeRec *N = nodes + n;
-    const int fc = N->first_child;
-    const int pb = N->prim_begin;
-    const int pc = N->prim_count;
+    // the node's record, from a lane that holds it (no memory round trip)
+    const int src = __builtin_ctzll(inmask);
+    const int fc = __builtin_amdgcn_readlane(cur_fc, src);
+    const int pb = __builtin_amdgcn_readlane(cur_pb, src);
+    const int pc = __builtin_amdgcn_readlane(cur_pc, src);
     if (STATS) {
       st.wave_node_steps++;
       st.wave_tri_steps += (unsigned)pc;
@@ -976,7 +1114,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // ~30 to broadcast each ray).
     const int n_in = __builtin_popcountll(inmask);
     const int chunks = (pc + 63) >> 6;
-    const bool transposed = (S.force_mode < 3) && pc > 0 && (n_in * (30 + 45 * chunks) < 20 * pc);
+    const bool transposed = (S.force_mode != 3) && pc > 0 && (n_in * (30 + 45 * chunks) < 20 * pc);
     int best = -1;
     double best_t = 0.0;
     MT_PROF_BEGIN(prof_t1);
@@ -1003,15 +1141,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       if (!transposed) {
         const int oct = sx | (sy << 1) | (sz << 2);
         ScanOut o;
-        if (mode == 2 && use_filter) {
-          o = scan_filtered_dispatch<STATS>(S, oct, pb, pc, r, f32);
-#ifdef MT_PROF
-          MT_PROF_COUNT(PROF_SHADE, 0);
-          prof_acc[PROF_N_CHUNKS + 0] += 0;
-          prof_quads += (unsigned long long)__builtin_amdgcn_readfirstlane((int)o.quads);
-          prof_slow += (unsigned long long)__builtin_amdgcn_readfirstlane((int)o.slow_quads);
-#endif
-        }
+        if (mode == 2 && use_filter) o = scan_filtered_dispatch<STATS>(S, oct, pb, pc, r, f32);
         else if (mode == 2) o = scan_octant_dispatch<STATS>(S, oct, pb, pc, r);
         else if (mode == 1) o = scan_exact_call<1, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
         else o = scan_exact_call<0, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
@@ -1025,7 +1155,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     MT_PROF_BEGIN(prof_t1);
     if (in) {
 #endif
-
       unsigned ordw = 0;
       if (fc != 0) {
         if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1033,53 +1162,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         ordw = (mode == 0) ? order_children_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz)
                            : order_children_call<1>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz);
       }
-      // Unwind / descend: the tail of PrimitiveIntersectRay (octtree.cc:219-256)
-      int my_fc = fc;
-      unsigned pos = 0;
-      for (int guard = 0;; guard++) {
-        if (guard > S.tree_depth + 1) {  // cannot happen: one pop per level at most
-          cur = -2;
-          break;
-        }
-        const unsigned cnt = (ordw >> 24) & 15u;
-        if (pos < cnt) {
-          const int child = my_fc + (int)((ordw >> (3 * pos)) & 7u);
-          pos++;
-          if (depth >= S.tree_depth) {  // cannot happen: stack sized for the validated depth
-            cur = -2;
-            break;
-          }
-          const int at = depth * 64 + lane;
-          stk_fc[at] = my_fc;
-          stk_bt[at] = best_t;
-          stk_bp[at] = best;
-          stk_ord[at] = (ordw & 0x0fffffffu) | (pos << 28);
-          depth++;
-          cur = child;
-          break;
-        }
-        if (depth == 0) {
-          out_prim = best;
-          out_t = best_t;
-          cur = -1;
-          break;
-        }
-        depth--;
-        const int at = depth * 64 + lane;
-        const unsigned po = stk_ord[at];
-        int pbp = stk_bp[at];
-        double pbt = stk_bt[at];
-        my_fc = stk_fc[at];
-        pos = po >> 28;
-        ordw = po & 0x0fffffffu;
-        if (best >= 0 && !(pbp >= 0 && best_t > pbt)) {  // :233-246 take it and break
-          pbp = best;
-          pbt = best_t;
-          pos = (po >> 24) & 15u;
-        }
-        best = pbp;
-        best_t = pbt;
-      }
+      finish_node(fc, ordw, best, best_t);
     }
     MT_PROF_END(PROF_CHILDREN_UNWIND, prof_t1);
     if (__ballot(cur == -2) != 0ull) {
@@ -1088,9 +1171,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     }
   }
   MT_PROF_END(PROF_TRACE, prof_t0);
-#ifdef MT_PROF
-  prof_acc[PROF_SHADE] = (prof_quads << 32) | (prof_slow & 0xffffffffull);  // packed: quads | slow quads
-#endif
   MT_PROF_FLUSH(S.prof, lane);
   if (status != DEV_OK) {
     out_prim = -1;

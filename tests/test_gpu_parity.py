@@ -123,7 +123,7 @@ def test_c_abi_intersect_rays_match_reference(case, scene, scenes):
     flat = M.MythTracer(scenes[scene]).flatten()
     h = abi.scene_create(flat)
     try:
-        for mode in (0, 1, 2, 3, 4):
+        for mode in (0, 1, 2, 3, 4, 5):
             abi.set_traversal_mode(h, mode)
             r = abi.intersect_rays(h, g["rays"])
             assert np.array_equal(r["line"], g["line"]), mode
@@ -145,7 +145,7 @@ def test_c_abi_render_direct_and_modes(scenes):
         abi.set_lights(h, scenegen.ROOM_LIGHTS)
         sens = binding.sensor(scenegen.ROOM_CAMERA, 200, 112)
         base = None
-        for mode in (0, 1, 2, 3, 4, 0):
+        for mode in (0, 1, 2, 3, 4, 5, 0):
             abi.set_traversal_mode(h, mode)
             r = abi.render_chunk(h, sens, 200, 112, debug=True)
             key = {k: r["stats"][k] for k in ALL_KEYS}
