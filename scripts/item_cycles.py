@@ -23,3 +23,17 @@ med = np.argsort(np.abs(d - np.median(d)))[:3]
 for i in med: print(" median-ish item", i, "cycles %.3e passes %d steps %.3e steps/pass %.0f cyc/step %.0f" % (d[i], passes[i], steps[i], steps[i] / passes[i], d[i] / steps[i]))
 c = np.sort(d)[::-1]
 print("share of total cycles in top 1%% items: %.3f ; top 10%%: %.3f" % (c[:324].sum() / c.sum(), c[:3240].sum() / c.sum()))
+# greedy list-scheduling simulation: how long would the frame take if work items
+# were handed out in this order to 3072 / 2048 waves (no interference model)
+import heapq
+for nw in (2048, 3072):
+    h = [0.0] * nw
+    heapq.heapify(h)
+    for x in d:
+        t = heapq.heappop(h); heapq.heappush(h, t + x)
+    mk = max(h)
+    print("waves %d: makespan in given order %.3e cycles (%.1f ms @2.4GHz), perfect balance %.3e, max item %.3e" % (nw, mk, mk / 2.4e6, d.sum() / nw, d.max()))
+    hs = [0.0] * nw; heapq.heapify(hs)
+    for x in np.sort(d)[::-1]:
+        t = heapq.heappop(hs); heapq.heappush(hs, t + x)
+    print("   longest-first order: makespan %.3e (%.1f ms)" % (max(hs), max(hs) / 2.4e6))

@@ -28,12 +28,29 @@ __device__ __forceinline__ unsigned long long quad_eval(const Quad &q, const F &
   const float b3[6] = {q.hi[2], q.hi[3], q.hi[4], q.hi[5], q.hi[6], q.hi[7]};
   return filt(b0, f) | filt(b1, f) | filt(b2, f) | filt(b3, f);
 }
+typedef float f4v __attribute__((ext_vector_type(4)));
+struct Hex { f16v a; f16v b; f4v c; };   // six boxes = 144 bytes
+__device__ __forceinline__ void issue_hex(Hex &q, const MT_CONST float *p) {
+  asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x80" : "=&s"(q.a), "=&s"(q.b), "=&s"(q.c) : "s"(p));
+}
+__device__ __forceinline__ void await_hex(Hex &q) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.a), "+s"(q.b), "+s"(q.c)); }
+__device__ __forceinline__ unsigned long long hex_eval(const Hex &q, const F &f) {
+  float v[36];
+#pragma unroll
+  for (int i = 0; i < 16; i++) { v[i] = q.a[i]; v[16 + i] = q.b[i]; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[32 + i] = q.c[i];
+  unsigned long long m = 0;
+#pragma unroll
+  for (int j = 0; j < 6; j++) m |= filt(&v[j * 6], f);
+  return m;
+}
 // variant 0: double-buffered quads (what mt_trace.h does)
 // variant 1: single quad, no overlap
 // variant 2: compiler-managed scalar loads of 8 boxes per batch, no overlap
 // variant 3: LDS-staged: 1 KiB per global_load_lds, ds_read broadcast
 template <int V>
-__global__ __launch_bounds__(256) void k(const float *boxes, int n_boxes, int list_len, int reps, unsigned long long *out, unsigned long long *cyc) {
+__global__ __launch_bounds__(256) void k(const float *boxes, int n_boxes, int list_len, int reps, unsigned long long *out, unsigned long long *cyc, int cold) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   F f; f.ix = 1.0f + lane * 1e-3f; f.iy = 0.9f; f.iz = 1.1f; f.cnx = -1e9f; f.cny = -1e9f; f.cnz = -1e9f; f.cfx = -2e9f; f.cfy = -2e9f; f.cfz = -2e9f;
@@ -43,6 +60,7 @@ __global__ __launch_bounds__(256) void k(const float *boxes, int n_boxes, int li
   start &= ~3u;
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   for (int rep = 0; rep < reps; rep++) {
+    if (cold) start = ((unsigned)__builtin_amdgcn_readfirstlane((int)((((unsigned)wave * 2654435761u) ^ ((unsigned)rep * 40503u * 65537u)) % (unsigned)(n_boxes - list_len - 64)))) & ~3u;
     const MT_CONST float *p = (const MT_CONST float *)(uintptr_t)(boxes + (size_t)start * 6);
     if (V == 0) {
       Quad A, B;
@@ -58,6 +76,21 @@ __global__ __launch_bounds__(256) void k(const float *boxes, int n_boxes, int li
         acc |= quad_eval(B, f);
         if (!ma) break;
         await_quad(A); k += 4;
+      }
+    } else if (V == 4) {
+      Hex A, B;
+      issue_hex(A, p); await_hex(A);
+      for (int k = 0;;) {
+        const bool mb = k + 6 < list_len;
+        if (mb) issue_hex(B, p + 36);
+        acc |= hex_eval(A, f);
+        if (!mb) break;
+        await_hex(B); k += 6; p += 72;
+        const bool ma = k + 6 < list_len;
+        if (ma) issue_hex(A, p);
+        acc |= hex_eval(B, f);
+        if (!ma) break;
+        await_hex(A); k += 6;
       }
     } else if (V == 1) {
       Quad A;
@@ -102,15 +135,18 @@ int main(int argc, char **argv) {
   for (size_t i = 0; i < h.size(); i++) h[i] = (float)((i * 2654435761u) % 1000) * 0.4f;
   float *d; hipMalloc(&d, h.size() * 4); hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   unsigned long long *out, *cyc; hipMalloc(&out, 8 * 65536); hipMalloc(&cyc, 8 * 65536);
-  for (int v = 0; v < 4; v++) for (int wpb_blocks = 1; wpb_blocks <= 3; wpb_blocks++) {
+  const int cold = argc > 2 ? atoi(argv[2]) : 0;
+  for (int v = 0; v < 5; v++) for (int wpb_blocks = 2; wpb_blocks <= 3; wpb_blocks++) {
+    if (v == 1 || v == 3) continue;
     const int blocks = 256 * wpb_blocks, waves = blocks * 4;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 2; it++) {
       hipEventRecord(e0);
-      if (v == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 8192, 0, d, n_boxes, list_len, reps, out, cyc);
-      if (v == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 8192, 0, d, n_boxes, list_len, reps, out, cyc);
-      if (v == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 8192, 0, d, n_boxes, list_len, reps, out, cyc);
-      if (v == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 8192, 0, d, n_boxes, list_len, reps, out, cyc);
+      if (v == 0) hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 8192, 0, d, n_boxes, list_len, reps, out, cyc, cold);
+      if (v == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 8192, 0, d, n_boxes, list_len, reps, out, cyc, cold);
+      if (v == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 8192, 0, d, n_boxes, list_len, reps, out, cyc, cold);
+      if (v == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 8192, 0, d, n_boxes, list_len, reps, out, cyc, cold);
+      if (v == 3) hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 8192, 0, d, n_boxes, list_len, reps, out, cyc, cold);
       hipEventRecord(e1); hipEventSynchronize(e1);
     }
     float ms; hipEventElapsedTime(&ms, e0, e1);
