@@ -36,8 +36,10 @@ struct FrameIO {
 };
 
 // Work item -> pixel of the calling lane.  An item is an 8x8-pixel block of a
-// tile slot; `sub` < 0 means all 64 lanes (8x8), sub = 0..3 means only the
-// 4x4 quadrant `sub` of it, on lanes 0..15 (used to cut heavy blocks).
+// tile slot.  sub < 0: one lane per pixel, all 64 pixels.  sub = 0..3: the 4x4
+// quarter `sub` of the block with FOUR lanes per pixel (pixel = lane / 4,
+// role = lane % 4), used to run the shadow loops of up to four lights of a
+// pixel side by side.
 struct ItemGeom {
   int px, py;        // image coordinates of this lane's pixel
   bool inside;       // lane has a pixel
@@ -53,23 +55,40 @@ __device__ __forceinline__ ItemGeom item_geometry(const RenderParams &P, unsigne
   const int cw = min(P.tile_w, P.region_x + P.region_w - tx0);  // edge clipping as
   const int ch = min(P.tile_h, P.region_y + P.region_h - ty0);  // main_net_master.cc:205-206
   int ox, oy;
-  bool lane_used = true;
   if (sub < 0) {
     ox = lane & 7;
     oy = lane >> 3;
   } else {
-    ox = (sub & 1) * 4 + (lane & 3);
-    oy = (sub >> 1) * 4 + ((lane >> 2) & 3);
-    lane_used = lane < 16;
+    const int q = lane >> 2;
+    ox = (sub & 1) * 4 + (q & 3);
+    oy = (sub >> 1) * 4 + (q >> 2);
   }
   const int lx = (b % P.blocks_x) * 8 + ox;
   const int ly = (b / P.blocks_x) * 8 + oy;
   ItemGeom g;
   g.px = tx0 + lx;
   g.py = ty0 + ly;
-  g.inside = lane_used && (lx < cw) && (ly < ch);
+  g.inside = (lx < cw) && (ly < ch);
   g.px_index = (size_t)j * (size_t)P.tile_w * (size_t)P.tile_h + (size_t)ly * (size_t)cw + (size_t)lx;
   return g;
+}
+
+// Value of `v` held by role J of the caller's quad (four adjacent lanes), via
+// DPP quad_perm.  Must be executed by all lanes of the quad together.
+template <int J>
+__device__ __forceinline__ int quad_get_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false);
+}
+template <int J>
+__device__ __forceinline__ double quad_get_f64(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)quad_get_i32<J>((int)(unsigned)b);
+  const unsigned hi = (unsigned)quad_get_i32<J>((int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int J>
+__device__ __forceinline__ V3 quad_get_v3(V3 v) {
+  return V3{quad_get_f64<J>(v.x), quad_get_f64<J>(v.y), quad_get_f64<J>(v.z)};
 }
 
 // Work fetch.  Written WITHOUT a divergent branch: every lane issues the add
@@ -207,7 +226,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
   const V3 s_ds = v3_load(P.sensor.delta_scanline);
   const V3 s_dp = v3_load(P.sensor.delta_pixel);
   const unsigned n2 = P.class_count[2], n1 = P.class_count[1], n0 = P.class_count[0];
-  const unsigned n_work = n2 + n1 + n0;
+  const unsigned n_work = 4u * n2 + n1 + n0;
 
   for (;;) {
     const unsigned w = fetch_work(P.work_counter + 1, lane);
@@ -218,17 +237,20 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
     if (w >= n_work) break;
     unsigned item;
     int sub = -1;
-    if (w < n2) {
-      item = P.class_list[(size_t)2 * P.n_items + w];
-      // These blocks decide when the frame ends (one glass block measured at
-      // 40 ms of a 48 ms frame, all of it sequential per pixel): let their
-      // waves win the issue arbitration on their SIMD.
+    if (w < 4u * n2) {
+      // A class-2 block goes out as four quarters with four lanes per pixel:
+      // these blocks decide when the frame ends (one glass block measured at
+      // 40 ms of a 48 ms frame, all of it one sequential ray chain per pixel).
+      // Running a pixel's shadow loops side by side shortens that chain, and
+      // their waves win the issue arbitration on their SIMD.
+      item = P.class_list[(size_t)2 * P.n_items + (w >> 2)];
+      sub = (int)(w & 3u);
       __builtin_amdgcn_s_setprio(3);
-    } else if (w < n2 + n1) {
-      item = P.class_list[(size_t)1 * P.n_items + (w - n2)];
+    } else if (w < 4u * n2 + n1) {
+      item = P.class_list[(size_t)1 * P.n_items + (w - 4u * n2)];
       __builtin_amdgcn_s_setprio(1);
     } else {
-      item = P.class_list[w - n2 - n1];
+      item = P.class_list[w - 4u * n2 - n1];
       __builtin_amdgcn_s_setprio(0);
     }
     item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
@@ -238,8 +260,16 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
     bool alive = g.inside;
     const size_t px_index = g.px_index;
 
-    // ---- per-lane state of TraceRayWorker
-    int mode = MODE_RADIANCE;
+    // ---- per-lane state of TraceRayWorker.  R lanes serve one pixel (R = 4
+    // in quad mode, else 1): role 0 owns the pixel and runs the recursion;
+    // during a "light round" role j runs the shadow loop of light round_base+j.
+    const bool quad = sub >= 0;
+    const int R = quad ? 4 : 1;
+    const int role = quad ? (lane & 3) : 0;
+    const bool owner = role == 0;
+    const unsigned long long my_group = quad ? (0xFull << (lane & ~3)) : (1ull << lane);
+    enum { MODE_IDLE = 2 };
+    int mode = owner ? MODE_RADIANCE : MODE_IDLE;
     int level = 0;
     bool in_object = false;
     double coef = 1.0;
@@ -250,18 +280,22 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
     }
     V3 Pt = v3(0, 0, 0), Nn = Pt, surf = Pt, color = Pt, Rd = Pt, dir = Pt, L = Pt, start = Pt,
        lp = Pt;
-    int mtl = -1, li = 0;
+    V3 add1 = Pt, add2 = Pt, add3 = Pt;  // this role's contributions to `color`, in the order they are added
+    bool has_light = false, has_add3 = false;
+    double refl_dot = 0.0;
+    int mtl = -1, li = 0, round_base = 0;
     bool traversing = false;
+    bool want_round = false, waiting_round = false;
 
-    // Bound on traversals per 8x8 item: every ray of a pixel is one pass; a
+    // Bound on traversals per item: every ray of a pixel is at most one pass; a
     // pixel needs at most 2^(max_depth+1) radiance rays, each with one shadow
     // loop per light whose iterations each cross a different surface.
     const long long pass_bound =
         (2ll << P.max_depth) * (1 + (long long)S.n_lights * ((long long)S.n_tris + 2)) + 16;
     long long passes = 0;
     while (__ballot(alive) != 0ull) {
-      int prim;
-      double t;
+      int prim = -1;
+      double t = 0.0;
       if (S.hb) {
         const unsigned long long am = __ballot(alive);
         const unsigned long long ex = __builtin_amdgcn_read_exec();
@@ -272,11 +306,12 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
         }
       }
       int trc = DEV_OK;
+      const bool tracing = alive && mode != MODE_IDLE;
       if (passes == 0) {  // the primary hit was found by launch 1
-        prim = alive ? P.hit_prim[px_index] : -1;
-        t = alive ? P.hit_t[px_index] : 0.0;
+        prim = tracing ? P.hit_prim[px_index] : -1;
+        t = tracing ? P.hit_t[px_index] : 0.0;
       } else {
-        const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, alive, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+        const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, tracing, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
         add_trace_stats<STATS>(st, to);
         prim = to.prim;
         t = to.t;
@@ -291,9 +326,11 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
         alive = false;
         break;
       }
-      if (alive) {
-        bool next_light = false, after_lights = false, do_return = false;
-        V3 retval = v3(0, 0, 0);
+
+      // ---- stage 1 (per lane): consume the traversal result
+      bool after_lights = false, do_return = false;
+      V3 retval = v3(0, 0, 0);
+      if (tracing) {
         if (mode == MODE_RADIANCE) {
           if (STATS && level > 0) st.v[ST_RAYS_SECONDARY]++;  // level 0 was counted by launch 1
           if (prim < 0) {  // mythtracer.cc:23-31
@@ -324,9 +361,12 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
                 surf = surf * texture_color_at(S.texs[m->tex], uvw.x, uvw.y);
               }
               Rd = dir - Nn * (2 * dot(dir, Nn));  // :68-69
+              refl_dot = dot(Rd, towards_camera);  // :170, the same for every light
               color = v3(0, 0, 0);
-              li = 0;
-              next_light = true;
+              round_base = 0;
+              if (S.n_lights > 0) want_round = true;
+              else after_lights = true;
+              mode = MODE_IDLE;
             }
           }
         } else {  // ---- one iteration of the shadow loop, mythtracer.cc:94-156
@@ -373,33 +413,88 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
             }
           }
           if (light_done) {
+            // The three terms this light adds to `color` (:83-84, :163-167,
+            // :169-177), computed exactly as written there; the pixel's owner
+            // adds them in light order.
             const MT_CONST mt_material *m = mtls + mtl;
             const V3 amb = v3(lt->ambient[0], lt->ambient[1], lt->ambient[2]);
+            add1 = amb * surf;
             lp.x = std_max(lp.x, amb.x);  // :159-161
             lp.y = std_max(lp.y, amb.y);
             lp.z = std_max(lp.z, amb.z);
             const V3 kd = v3(m->diffuse[0], m->diffuse[1], m->diffuse[2]);
             const V3 ld = v3(lt->diffuse[0], lt->diffuse[1], lt->diffuse[2]);
-            color = color + kd * surf * dot(L, Nn) * ld * lp;  // :163-167
-            if (!in_shadow) {  // :169-177
-              const double refl_dot = dot(Rd, -dir);
-              if (refl_dot > 0) {
-                const V3 ks = v3(m->specular[0], m->specular[1], m->specular[2]);
-                const V3 ls = v3(lt->specular[0], lt->specular[1], lt->specular[2]);
-                color = color + ks * surf * ::pow(refl_dot, m->specular_exp) * ls;
-              }
+            add2 = kd * surf * dot(L, Nn) * ld * lp;
+            has_add3 = false;
+            if (!in_shadow && refl_dot > 0) {
+              const V3 ks = v3(m->specular[0], m->specular[1], m->specular[2]);
+              const V3 ls = v3(lt->specular[0], lt->specular[1], lt->specular[2]);
+              add3 = ks * surf * ::pow(refl_dot, m->specular_exp) * ls;
+              has_add3 = true;
             }
-            li++;
-            next_light = true;
+            mode = MODE_IDLE;
           }
         }
+      }
 
-        if (next_light) {
-          if (li < S.n_lights) {  // head of the light loop, :78-99
+      // ---- stage 2 (all lanes of the wave together: quad broadcasts)
+      // (a) a round is complete when no role of the pixel is still in a shadow
+      //     loop: the owner adds the roles' terms in light order.
+      {
+        const unsigned long long busy = __ballot(alive && mode == MODE_SHADOW);
+        const bool round_done = owner && waiting_round && ((busy & my_group) == 0ull);
+        const int hl0 = has_light ? 1 : 0, h30 = has_add3 ? 1 : 0;
+        // role 0 is the owner itself
+        if (round_done && has_light) {
+          color = color + add1;
+          color = color + add2;
+          if (has_add3) color = color + add3;
+        }
+        if (quad) {
+          const int hl1 = quad_get_i32<1>(hl0), hl2 = quad_get_i32<2>(hl0), hl3 = quad_get_i32<3>(hl0);
+          const int h31 = quad_get_i32<1>(h30), h32 = quad_get_i32<2>(h30), h33 = quad_get_i32<3>(h30);
+          const V3 a11 = quad_get_v3<1>(add1), a21 = quad_get_v3<1>(add2), a31 = quad_get_v3<1>(add3);
+          const V3 a12 = quad_get_v3<2>(add1), a22 = quad_get_v3<2>(add2), a32 = quad_get_v3<2>(add3);
+          const V3 a13 = quad_get_v3<3>(add1), a23 = quad_get_v3<3>(add2), a33 = quad_get_v3<3>(add3);
+          if (round_done) {
+            if (hl1) { color = color + a11; color = color + a21; if (h31) color = color + a31; }
+            if (hl2) { color = color + a12; color = color + a22; if (h32) color = color + a32; }
+            if (hl3) { color = color + a13; color = color + a23; if (h33) color = color + a33; }
+          }
+        }
+        if (round_done) {
+          waiting_round = false;
+          round_base += R;
+          if (round_base < S.n_lights) want_round = true;
+          else after_lights = true;
+        }
+      }
+      // (b) start of a round: the owner's shading point goes to every role, each
+      //     role with a light sets up its shadow loop (head of the light loop,
+      //     mythtracer.cc:78-99).
+      {
+        int wr = (owner && want_round) ? 1 : 0;
+        int rb = round_base, mt_ = mtl;
+        V3 bP = Pt, bN = Nn, bS = surf;
+        double bR = refl_dot;
+        if (quad) {
+          wr = quad_get_i32<0>(wr);
+          rb = quad_get_i32<0>(rb);
+          mt_ = quad_get_i32<0>(mt_);
+          bP = quad_get_v3<0>(bP);
+          bN = quad_get_v3<0>(bN);
+          bS = quad_get_v3<0>(bS);
+          bR = quad_get_f64<0>(bR);
+        }
+        if (alive && wr) {
+          Pt = bP; Nn = bN; surf = bS; refl_dot = bR; mtl = mt_;
+          li = rb + role;
+          has_light = li < S.n_lights;
+          has_add3 = false;
+          if (has_light) {
             const MT_CONST mt_light *lt = lights + li;
             const V3 lpos = v3(lt->position[0], lt->position[1], lt->position[2]);
             L = normalized(lpos - Pt);
-            color = color + v3(lt->ambient[0], lt->ambient[1], lt->ambient[2]) * surf;  // :83-84
             lp = v3(1.0, 1.0, 1.0);
             traversing = false;
             start = Pt;
@@ -407,10 +502,17 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
             rd = L;
             mode = MODE_SHADOW;
           } else {
-            after_lights = true;
+            mode = MODE_IDLE;
+          }
+          if (owner) {
+            want_round = false;
+            waiting_round = true;
           }
         }
+      }
 
+      // ---- stage 3 (owner, per lane): recursion decisions and returns
+      if (alive && owner) {
         if (after_lights) {
           const MT_CONST mt_material *m = mtls + mtl;
           const double refl = m->reflectance, tr = m->transparency;
@@ -484,6 +586,11 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
             retval = fcolor + retval * tf * m->transparency;  // :220-224
           }
         }
+      }
+      // helpers leave with their owner
+      if (quad) {
+        const int oa = quad_get_i32<0>(alive ? 1 : 0);
+        if (!owner) alive = alive && (oa != 0);
       }
     }
 

@@ -749,20 +749,40 @@ __device__ __forceinline__ bool slab_pass_lane(const double *b, const RayRegs &r
   return !(tmax < 0.0) && !(tmin > tmax);
 }
 
+// Scalar parameters only (they travel in registers; a by-value struct would go
+// through the stack).  Boxes are fetched three at a time so that their load
+// latencies overlap; the tests then run in list order.
 template <bool EX, bool STATS>
 __device__ __attribute__((noinline)) ScanOut scan_small_lane_call(const double *b64, const double *vtx,
-                                                                  int pb, int pc, RayRegs r) {
+                                                                  int pb, int pc, double ox, double oy,
+                                                                  double oz, double dx, double dy,
+                                                                  double dz, double ix, double iy,
+                                                                  double iz) {
+  RayRegs r;
+  r.ox = ox; r.oy = oy; r.oz = oz;
+  r.dx = dx; r.dy = dy; r.dz = dz;
+  r.ix = ix; r.iy = iy; r.iz = iz;
   ScanOut o{-1, 0.0, 0u};
-  for (int k = 0; k < pc; k++) {
-    const double *bp = b64 + (size_t)(pb + k) * 6;
-    const double b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
-    if (!slab_pass_lane<EX>(b, r)) continue;
-    if (STATS) o.mt_tests++;
-    double t;
-    if (moller_trumbore(vtx + (size_t)(pb + k) * 9, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &t)) {
-      if (!(o.best >= 0 && t > o.best_t)) {
-        o.best = pb + k;
-        o.best_t = t;
+  for (int k = 0; k < pc; k += 3) {
+    double b[3][6];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const int kk = (k + j < pc) ? (k + j) : (pc - 1);  // clamped: the load is always valid
+      const double *bp = b64 + (size_t)(pb + kk) * 6;
+#pragma unroll
+      for (int i = 0; i < 6; i++) b[j][i] = bp[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      if (k + j >= pc) break;
+      if (!slab_pass_lane<EX>(b[j], r)) continue;
+      if (STATS) o.mt_tests++;
+      double t;
+      if (moller_trumbore(vtx + (size_t)(pb + k + j) * 9, ox, oy, oz, dx, dy, dz, &t)) {
+        if (!(o.best >= 0 && t > o.best_t)) {
+          o.best = pb + k + j;
+          o.best_t = t;
+        }
       }
     }
   }
@@ -1052,8 +1072,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           break;
         }
         const ScanOut o = all_regular
-            ? scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r)
-            : scan_small_lane_call<true, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r);
+            ? scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz)
+            : scan_small_lane_call<true, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz);
         if (STATS) {
           __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)cur_pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
