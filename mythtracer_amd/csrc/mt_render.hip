@@ -237,18 +237,18 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
     if (w >= n_work) break;
     unsigned item;
     int sub = -1;
-    if (w < 4u * n2) {
-      // A class-2 block goes out as four quarters with four lanes per pixel:
-      // these blocks decide when the frame ends (one glass block measured at
-      // 40 ms of a 48 ms frame, all of it one sequential ray chain per pixel).
-      // Running a pixel's shadow loops side by side shortens that chain, and
-      // their waves win the issue arbitration on their SIMD.
-      item = P.class_list[(size_t)2 * P.n_items + (w >> 2)];
-      sub = (int)(w & 3u);
+    // Order: reflective blocks (class 1) first — the longest of them (a floor
+    // that mirrors glass: 30+ sequential rays per pixel) cannot be told apart
+    // beforehand, so all of them start early; then the class-2 blocks, each as
+    // four quarters with four lanes per pixel (a pixel's shadow loops run side
+    // by side, which halves its ray chain); then everything else.
+    if (w < n1) {
+      item = P.class_list[(size_t)1 * P.n_items + w];
       __builtin_amdgcn_s_setprio(3);
-    } else if (w < 4u * n2 + n1) {
-      item = P.class_list[(size_t)1 * P.n_items + (w - 4u * n2)];
-      __builtin_amdgcn_s_setprio(1);
+    } else if (w < n1 + 4u * n2) {
+      item = P.class_list[(size_t)2 * P.n_items + ((w - n1) >> 2)];
+      sub = (int)((w - n1) & 3u);
+      __builtin_amdgcn_s_setprio(2);
     } else {
       item = P.class_list[w - 4u * n2 - n1];
       __builtin_amdgcn_s_setprio(0);
