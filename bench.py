@@ -158,19 +158,25 @@ def main():
         step()
     fence()
     abi.read_stats(h)              # drop warm-up counts
+    abi.kernel_times(h)            # ... and warm-up kernel durations
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
     counters = abi.read_stats(h)   # this rank, all timed steps
+    # per-kernel device durations of the timed steps: HIP events the library
+    # records on the launch stream around each of its two kernels
+    k_primary, k_render = abi.kernel_times(h, 64)
 
     keys = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests", "node_visits",
             "tri_tests", "mt_tests", "shaded_hits", "wave_node_steps", "wave_tri_steps"]
     vec = torch.tensor([float(counters[k]) for k in keys], dtype=torch.float64, device=dev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    kmax = torch.tensor([sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=dev)
+    kmax = torch.tensor([float(k_render.mean()) if len(k_render) else 0.0,
+                         float(k_primary.mean()) if len(k_primary) else 0.0,
+                         sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -188,14 +194,29 @@ def main():
         if os.path.exists(gpath):
             key = "%s_%dx%d_d%d" % (args.scene, W, H, args.max_depth)
             golden = json.load(open(gpath)).get(key, {}).get("sha256")
-        # dominant (only) kernel of a step: render_kernel.  Per-launch figures
-        # of THIS rank's launch at N=1; at N>1 the slowest rank's duration.
-        k_ms = float(kmax.item())
+        # A step is two launches: mt::primary_kernel (primary rays, block cost
+        # classes) and mt::render_kernel (shading, shadow + secondary rays) —
+        # the dominant one.  Per-launch figures of THIS rank at N=1; at N>1 the
+        # slowest rank's durations.
+        k_ms, k_primary_ms, k_step_ms = (float(x) for x in kmax.tolist())
         my = counters if world == 1 else None
         roof = None
         if world == 1:
             pf = {k: my[k] // max(args.steps, 1) for k in keys}
+            # primary_kernel's share of the counters: one untimed frame with
+            # no lights and recursion 0 traces the primary rays only
+            scratch = torch.zeros_like(frame)
+            abi.set_lights(h, [])
+            abi.render_chunk_device(h, sens, W, H, (0, 0, W, H), 0,
+                                    ctypes.c_void_p(scratch.data_ptr()), None, stream)
+            torch.cuda.synchronize()
+            prim = abi.read_stats(h)
+            abi.kernel_times(h)
+            abi.set_lights(h, lights)
+            for k in ("box_tests", "tri_tests", "mt_tests"):
+                pf[k] -= prim[k]
             alg = algorithmic_bytes(pf, W * H)
+            alg_primary = 48 * prim["box_tests"] + 48 * prim["tri_tests"] + 72 * prim["mt_tests"] + 12 * W * H
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tpath):
@@ -205,6 +226,10 @@ def main():
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                     "kernel": "mt::render_kernel", "kernel_ms": k_ms,
                     "algorithmic_bytes_per_launch": alg,
+                    "launches_averaged": int(len(k_render)),
+                    "other_kernels": {"mt::primary_kernel": {
+                        "kernel_ms": k_primary_ms, "algorithmic_bytes_per_launch": alg_primary}},
+                    "step_ms_device": k_step_ms,
                     "note": "algorithmic bytes = SURVEY 8(d) bytes of the reference's un-pruned "
                             "traversal; they are served as wave-uniform scalar loads (one 48-B box "
                             "per 64 rays), so the kernel is fp64-VALU bound, not HBM bound",

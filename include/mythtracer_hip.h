@@ -190,6 +190,15 @@ int mt_blit_tiles_device(mt_scene *scene, int image_w, int image_h,
 /* Fetches and clears the accumulated counters (kernel_ms/total_ms = 0). */
 int mt_scene_read_stats(mt_scene *scene, mt_stats *stats);
 
+/* Device durations of the launches made since the previous call (at most the
+ * last 64, oldest first; at most max_n): primary_ms[i] = mt::primary_kernel,
+ * render_ms[i] = mt::render_kernel of launch i, from HIP events recorded on
+ * the launch's own stream.  Waits for those launches.  Returns the number of
+ * entries written, or a negative MT_ERR_*.  (No reference counterpart: the
+ * reference times a frame with wall clocks, main_local.cc:86-101.) */
+int mt_scene_kernel_times(mt_scene *scene, int max_n, double *primary_ms,
+                          double *render_ms);
+
 /* OctTree::IntersectRay (octtree.cc:26-40) for a batch: rays = n x 6 doubles
  * (origin, direction).  Outputs (each nullable): tri = stream-order triangle
  * index or -1, line_no, t, point (3 per ray; untouched = NaN on miss). */
@@ -202,7 +211,8 @@ int mt_intersect_rays(mt_scene *scene, int n, const double *rays,
  * the octant-uniform path, 3 = automatic but never the triangle-parallel
  * (transposed) node scan, 4 = automatic but without the fp32 conservative
  * pre-filter, 5 = automatic but every node through a wave step (no
- * lane-parallel scan of small nodes).  Results are identical in every mode. */
+ * lane-parallel scan of small nodes), 6 = automatic but without the group
+ * boxes that skip runs of triangles.  Results are identical in every mode. */
 int mt_scene_set_traversal_mode(mt_scene *scene, int mode);
 
 #ifdef __cplusplus

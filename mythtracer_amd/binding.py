@@ -20,6 +20,7 @@ HIP_SYMBOLS = [
     "mt_scene_destroy", "mt_scene_set_lights", "mt_render_chunk",
     "mt_render_chunk_device", "mt_render_tiles_device", "mt_blit_tiles_device",
     "mt_scene_read_stats", "mt_intersect_rays", "mt_scene_set_traversal_mode",
+    "mt_scene_kernel_times",
 ]
 
 STAT_NAMES = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests",
@@ -120,6 +121,7 @@ class HipAbi:
         L.mt_scene_read_stats.argtypes = [vp, C.POINTER(mt_stats)]
         L.mt_intersect_rays.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
         L.mt_scene_set_traversal_mode.argtypes = [vp, ci]
+        L.mt_scene_kernel_times.argtypes = [vp, ci, vp, vp]
 
     def last_error(self) -> str:
         return self.lib.mt_last_error().decode(errors="replace")
@@ -245,6 +247,16 @@ class HipAbi:
         st = mt_stats()
         self.check(self.lib.mt_scene_read_stats(h, C.byref(st)))
         return st.as_dict()
+
+    def kernel_times(self, h, max_n: int = 64):
+        """(primary_ms[], render_ms[]) of the launches since the previous call."""
+        a = np.zeros(max_n)
+        b = np.zeros(max_n)
+        n = self.lib.mt_scene_kernel_times(h, max_n, a.ctypes.data_as(C.c_void_p),
+                                           b.ctypes.data_as(C.c_void_p))
+        if n < 0:
+            self.check(n)
+        return a[:n].copy(), b[:n].copy()
 
     def intersect_rays(self, h, rays):
         rays = _f64(rays).reshape(-1, 6)

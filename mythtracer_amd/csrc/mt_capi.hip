@@ -67,6 +67,11 @@ struct mt_scene {
   size_t lds_bytes = 0;
   int grid_blocks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // per-launch kernel timing (mt_scene_kernel_times): [i][0] before the primary
+  // kernel, [1] between the two kernels, [2] after the render kernel
+  static constexpr int kTimedLaunches = 64;
+  hipEvent_t ev_k[kTimedLaunches][3] = {};
+  unsigned long long launches_timed = 0, launches_read = 0;
   int n_cu = 0;
   bool stats_enabled = true;
   unsigned long long *hb_host = nullptr;  // MT_DEBUG_HEARTBEAT: pinned, device-visible
@@ -193,14 +198,25 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
   HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
   // launch 1: primary rays + cost classes; launch 2: shading, heavy blocks first
+  hipEvent_t *ek = s->ev_k[s->launches_timed % mt_scene::kTimedLaunches];
+  for (int i = 0; i < 3; i++) {
+    if (!ek[i]) HIP_TRY(hipEventCreate(&ek[i]));
+  }
+  HIP_TRY(hipEventRecord(ek[0], stream));
   if (s->stats_enabled) {
     hipLaunchKernelGGL(primary_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
-    hipLaunchKernelGGL(render_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
   } else {
     hipLaunchKernelGGL(primary_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
+  }
+  HIP_TRY(hipEventRecord(ek[1], stream));
+  if (s->stats_enabled) {
+    hipLaunchKernelGGL(render_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
+  } else {
     hipLaunchKernelGGL(render_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
   }
+  HIP_TRY(hipEventRecord(ek[2], stream));
   HIP_TRY(hipGetLastError());
+  s->launches_timed++;
   if (d_item) {  // debug: dump per-item durations (synchronises!)
     std::vector<unsigned long long> host((size_t)P.n_items * 4 * 2);
     HIP_TRY(hipMemcpy(host.data(), d_item, host.size() * 8, hipMemcpyDeviceToHost));
@@ -292,6 +308,11 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_lights) (void)hipFree(s->d_lights);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  for (auto &tri : s->ev_k) {
+    for (hipEvent_t e : tri) {
+      if (e) (void)hipEventDestroy(e);
+    }
+  }
   delete s;
 }
 
@@ -401,7 +422,26 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     r.prim_begin = d->node_prim_begin[i];
     r.prim_count = d->node_prim_count[i];
   }
+  // Block boxes (mt_device.h kGroupTris): union of the fp64 boxes of each
+  // block of kGroupTris consecutive stream triangles, then rounded to fp32
+  // exactly like the per-triangle copies (the filter's margin covers it).
+  std::vector<float> groups;
+  for (int t0 = 0; t0 < d->n_tris; t0 += kGroupTris) {
+    const int e = std::min(t0 + kGroupTris, d->n_tris);
+    double u[6];
+    for (int k = 0; k < 6; k++) u[k] = d->tri_aabb[(size_t)t0 * 6 + k];
+    for (int t = t0 + 1; t < e; t++) {
+      const double *b = d->tri_aabb + (size_t)t * 6;
+      for (int k = 0; k < 3; k++) {
+        u[k] = std::min(u[k], b[k]);
+        u[3 + k] = std::max(u[3 + k], b[3 + k]);
+      }
+    }
+    for (int k = 0; k < 6; k++) groups.push_back((float)u[k]);
+  }
+  groups.resize(groups.size() + 8 * 6, 0.0f);  // the scan looks four boxes ahead
   int rc;
+  if ((rc = upload(s, groups.data(), groups.size(), &s->dev.grp_aabb32)) != MT_OK) return rc;
   if ((rc = upload(s, recs.data(), recs.size(), &s->dev.nodes)) != MT_OK) return rc;
   const size_t nt = (size_t)d->n_tris;
   {
@@ -505,7 +545,7 @@ int mt_scene_set_lights(mt_scene *s, const mt_light *lights, int n) {
 }
 
 int mt_scene_set_traversal_mode(mt_scene *s, int mode) {
-  if (!s || mode < 0 || mode > 5) return fail(MT_ERR_ARG, "mode must be 0..5");
+  if (!s || mode < 0 || mode > 6) return fail(MT_ERR_ARG, "mode must be 0..6");
   s->dev.force_mode = mode;
   return MT_OK;
 }
@@ -525,13 +565,39 @@ int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
     HIP_TRY(hipMemset(s->d_prof, 0, sizeof pr));
     static const char *names[PROF_COUNT] = {"trace_cycles", "scan_raypar_cycles", "scan_transposed_cycles",
                                             "children_unwind_cycles", "n_raypar_scans", "n_transposed_scans",
-                                            "n_transposed_chunks", "n_raypar_tris", "n_traces", "lane_phase_cycles"};
+                                            "n_transposed_chunks", "n_raypar_tris", "n_traces", "lane_phase_cycles",
+                                            "scan_m2f", "scan_m2", "scan_m1", "scan_m0", "n_m2f", "n_m2", "n_m1", "n_m0",
+                                            "tris_m2f", "tris_m1", "tris_transposed", "g_groups", "g_live", "g_ranges", "g_range_tris"};
     fprintf(stderr, "[mt prof]");
     for (int i = 0; i < PROF_COUNT; i++) fprintf(stderr, " %s=%llu", names[i], pr[i]);
     fprintf(stderr, "\n");
   }
 #endif
   return check_status(c);
+}
+
+int mt_scene_kernel_times(mt_scene *s, int max_n, double *primary_ms, double *render_ms) {
+  if (!s || max_n < 0 || (max_n > 0 && (!primary_ms || !render_ms))) {
+    return fail(MT_ERR_ARG, "bad kernel_times arguments");
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  unsigned long long first = s->launches_read;
+  if (s->launches_timed - first > (unsigned long long)mt_scene::kTimedLaunches) {
+    first = s->launches_timed - mt_scene::kTimedLaunches;  // older ones were overwritten
+  }
+  if (s->launches_timed - first > (unsigned long long)max_n) first = s->launches_timed - max_n;
+  int n = 0;
+  for (unsigned long long i = first; i < s->launches_timed; i++, n++) {
+    hipEvent_t *ek = s->ev_k[i % mt_scene::kTimedLaunches];
+    HIP_TRY(hipEventSynchronize(ek[2]));
+    float a = 0, b = 0;
+    HIP_TRY(hipEventElapsedTime(&a, ek[0], ek[1]));
+    HIP_TRY(hipEventElapsedTime(&b, ek[1], ek[2]));
+    primary_ms[n] = a;
+    render_ms[n] = b;
+  }
+  s->launches_read = s->launches_timed;
+  return n;
 }
 
 int mt_render_chunk_device(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h,

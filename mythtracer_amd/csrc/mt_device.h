@@ -24,6 +24,15 @@ struct NodeRec {
 };
 static_assert(sizeof(NodeRec) == 96, "NodeRec must be 96 bytes");
 
+// Nodes with at least kBigNode triangles are scanned wave-uniformly, smaller
+// ones lane-parallel (mt_trace.h).  The triangle stream carries one fp32 box
+// per block of kGroupTris consecutive triangles (block b = stream positions
+// [16 b, 16 b + 16), whatever nodes they belong to): a ray that provably
+// misses the block box fails the reference's per-triangle AABB pre-filter
+// (primitive_triangle.cc:73-76) for every member, so the block is skipped.
+constexpr int kBigNode = 16;
+constexpr int kGroupTris = 16;
+
 struct DevTexture {
   const void *texels;
   int32_t width, height, format, pad;
@@ -34,6 +43,7 @@ struct DevScene {
   const NodeRec *nodes;
   const double *tri_aabb;    // 6 per triangle, node-stream order
   const float *tri_aabb32;   // the same boxes rounded to fp32 (conservative pre-filter)
+  const float *grp_aabb32;   // fp32 union box of each block of kGroupTris consecutive stream triangles
   double bmax[3];            // max |coordinate| of any triangle box, per axis
   const double *tri_vertex;  // 9 per triangle
   const double *tri_normal;  // 9 per triangle
@@ -60,7 +70,10 @@ struct DevScene {
 };
 
 enum { PROF_TRACE = 0, PROF_SCAN_RAYPAR, PROF_SCAN_TRANSPOSED, PROF_CHILDREN_UNWIND, PROF_N_RAYPAR,
-       PROF_N_TRANSPOSED, PROF_N_CHUNKS, PROF_N_RAYPAR_TRIS, PROF_N_TRACES, PROF_SHADE, PROF_COUNT };
+       PROF_N_TRANSPOSED, PROF_N_CHUNKS, PROF_N_RAYPAR_TRIS, PROF_N_TRACES, PROF_SHADE,
+       PROF_SCAN_M2F, PROF_SCAN_M2, PROF_SCAN_M1, PROF_SCAN_M0, PROF_N_M2F, PROF_N_M2, PROF_N_M1, PROF_N_M0,
+       PROF_TRIS_M2F, PROF_TRIS_M1, PROF_TRIS_TRANSPOSED,
+       PROF_G_GROUPS, PROF_G_LIVE, PROF_G_RANGES, PROF_G_RANGE_TRIS, PROF_COUNT };
 
 enum {
   ST_RAYS_PRIMARY = 0,

@@ -113,6 +113,9 @@ __device__ __forceinline__ double readlane_f64(double v, int lane_id) {
   const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lane_id);
   return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+__device__ __forceinline__ float readlane_f32(float v, int lane_id) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_id));
+}
 
 // Wave-wide minimum of a 32-bit value; every lane must be active.
 __device__ __forceinline__ int wave_min_i32(int v) {
@@ -156,6 +159,9 @@ struct ScanOut {
   int best;           // stream index of the closest hit in the list, -1 none
   double best_t;
   unsigned mt_tests;  // Möller–Trumbore evaluations performed for this lane
+#ifdef MT_PROF
+  unsigned n_groups = 0, n_live = 0, n_ranges = 0, n_range_tris = 0;
+#endif
 };
 
 // The per-wave traversal stack in LDS, structure-of-arrays over [depth][lane]
@@ -215,6 +221,22 @@ struct RayRegs {
   double dx, dy, dz;
   double ix, iy, iz;  // Ray::inv_direction, octtree.cc:30-33
 };
+// A ray as nine scalar parameters: a 72-byte struct would be passed to a
+// non-inlined function through scratch memory (by reference), scalars travel
+// in VGPRs.
+#define MT_RAY_PARAMS double ox_, double oy_, double oz_, double dx_, double dy_, double dz_, \
+                      double ix_, double iy_, double iz_
+#define MT_RAY_ARGS(r) (r).ox, (r).oy, (r).oz, (r).dx, (r).dy, (r).dz, (r).ix, (r).iy, (r).iz
+#define MT_F32_PARAMS float fix_, float fiy_, float fiz_, float fcnx_, float fcny_, float fcnz_, \
+                      float fcfx_, float fcfy_, float fcfz_
+#define MT_F32_ARGS(f) (f).ix, (f).iy, (f).iz, (f).cnx, (f).cny, (f).cnz, (f).cfx, (f).cfy, (f).cfz
+#define MT_F32_FROM_PARAMS(f) \
+  Filter32 f;                 \
+  f.ix = fix_; f.iy = fiy_; f.iz = fiz_; f.cnx = fcnx_; f.cny = fcny_; f.cnz = fcnz_; \
+  f.cfx = fcfx_; f.cfy = fcfy_; f.cfz = fcfz_
+#define MT_RAY_FROM_PARAMS(r) \
+  RayRegs r;                  \
+  r.ox = ox_; r.oy = oy_; r.oz = oz_; r.dx = dx_; r.dy = dy_; r.dz = dz_; r.ix = ix_; r.iy = iy_; r.iz = iz_
 
 // Resolves the parked candidate of every lane that has one.
 template <bool STATS>
@@ -343,23 +365,23 @@ __device__ __forceinline__ void scan_node_prims(const DevScene &S, const RayRegs
   const MT_CONST double *p = as_const(S.tri_aabb) + (size_t)pb * 6;
   int pend = -1;
   unsigned long long pmask = 0;  // lanes holding a parked candidate
+  // Two buffers; the look-ahead load is issued unconditionally (the stream is
+  // padded), so every issue meets its wait on every path.
   PairRegs A, B;
   issue_pair(A, p);
   await_pair(A);
   for (int k = 0;;) {
-    const bool more_b = k + 2 < pc;
-    if (more_b) issue_pair(B, p + 12);
+    issue_pair(B, p + 12);
     scan_pair<MODE, OCT, STATS>(S, r, A, pb, k, pc, pend, pmask, best, best_t, st);
-    if (!more_b) break;
     await_pair(B);
     k += 2;
-    const bool more_a = k + 2 < pc;
+    if (k >= pc) break;
     p += 24;
-    if (more_a) issue_pair(A, p);
+    issue_pair(A, p);
     scan_pair<MODE, OCT, STATS>(S, r, B, pb, k, pc, pend, pmask, best, best_t, st);
-    if (!more_a) break;
     await_pair(A);
     k += 2;
+    if (k >= pc) break;
   }
   if (pmask) flush_candidates<STATS>(S, r, pend, best, best_t, st);
 }
@@ -470,8 +492,7 @@ __device__ __forceinline__ void await_quad(QuadRegs &q) {
 // test for the boxes some lane survived, in stream order.
 template <int OCT, bool STATS>
 __device__ __forceinline__ void scan_quad(const DevScene &S, const RayRegs &r, const Filter32 &f,
-                                          const QuadRegs &q, QuadRegs &next, bool next_in_flight,
-                                          int pb, int k, int pc, int &pend,
+                                          const QuadRegs &q, QuadRegs &next, int pb, int k, int pc, int &pend,
                                           unsigned long long &pmask, int &best, double &best_t,
                                           LaneStats &st) {
   const float b0[6] = {q.lo[0], q.lo[1], q.lo[2], q.lo[3], q.lo[4], q.lo[5]};
@@ -487,7 +508,7 @@ __device__ __forceinline__ void scan_quad(const DevScene &S, const RayRegs &r, c
   // Slow path (a few per cent of the quads).  It needs many more registers
   // (fp64 box, Möller–Trumbore), so first let the look-ahead fetch land: from
   // here on nothing is in flight and the compiler may spill what it likes.
-  if (next_in_flight) await_quad(next);
+  await_quad(next);
   const unsigned long long me = 1ull << (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
   const MT_CONST double *boxes = as_const(S.tri_aabb) + (size_t)(pb + k) * 6;
 #pragma unroll
@@ -519,21 +540,59 @@ __device__ __forceinline__ void scan_node_filtered(const DevScene &S, const RayR
   issue_quad(A, p);
   await_quad(A);
   for (int k = 0;;) {
-    const bool more_b = k + 4 < pc;
-    if (more_b) issue_quad(B, p + 24);
-    scan_quad<OCT, STATS>(S, r, f, A, B, more_b, pb, k, pc, pend, pmask, best, best_t, st);
-    if (!more_b) break;
+    issue_quad(B, p + 24);  // unconditional look-ahead: the stream is padded
+    scan_quad<OCT, STATS>(S, r, f, A, B, pb, k, pc, pend, pmask, best, best_t, st);
     await_quad(B);
     k += 4;
-    const bool more_a = k + 4 < pc;
+    if (k >= pc) break;
     p += 48;
-    if (more_a) issue_quad(A, p);
-    scan_quad<OCT, STATS>(S, r, f, B, A, more_a, pb, k, pc, pend, pmask, best, best_t, st);
-    if (!more_a) break;
+    issue_quad(A, p);
+    scan_quad<OCT, STATS>(S, r, f, B, A, pb, k, pc, pend, pmask, best, best_t, st);
     await_quad(A);
     k += 4;
+    if (k >= pc) break;
   }
   if (pmask) flush_candidates<STATS>(S, r, pend, best, best_t, st);
+}
+
+// fp32 verdicts for four group boxes: bit j set when some lane may hit group j.
+template <int OCT>
+__device__ __forceinline__ unsigned group_quad(const QuadRegs &q, const Filter32 &f, int left) {
+  const float b0[6] = {q.lo[0], q.lo[1], q.lo[2], q.lo[3], q.lo[4], q.lo[5]};
+  const float b1[6] = {q.lo[6], q.lo[7], q.lo[8], q.lo[9], q.lo[10], q.lo[11]};
+  const float b2[6] = {q.lo[12], q.lo[13], q.lo[14], q.lo[15], q.hi[0], q.hi[1]};
+  const float b3[6] = {q.hi[2], q.hi[3], q.hi[4], q.hi[5], q.hi[6], q.hi[7]};
+  // branch-free (the list is padded; boxes past its end are masked off)
+  const unsigned m = (filter32_pass<OCT>(b0, f) != 0ull ? 1u : 0u) |
+                     (filter32_pass<OCT>(b1, f) != 0ull ? 2u : 0u) |
+                     (filter32_pass<OCT>(b2, f) != 0ull ? 4u : 0u) |
+                     (filter32_pass<OCT>(b3, f) != 0ull ? 8u : 0u);
+  return left >= 4 ? m : (m & ((1u << left) - 1u));
+}
+
+// The group boxes of a big node (one per kGroupTris triangles, wave-uniform),
+// at most 64 of them: bit g of the result = some lane may hit group g.
+template <int OCT>
+__device__ __forceinline__ unsigned long long group_live_mask(const MT_CONST float *p, int n,
+                                                              const Filter32 &f) {
+  unsigned long long live = 0ull;
+  QuadRegs A, B;
+  issue_quad(A, p);
+  await_quad(A);
+  for (int k = 0;;) {
+    issue_quad(B, p + 24);  // unconditional look-ahead: the array is padded
+    live |= (unsigned long long)group_quad<OCT>(A, f, n - k) << k;
+    await_quad(B);
+    k += 4;
+    if (k >= n) break;
+    p += 48;
+    issue_quad(A, p);
+    live |= (unsigned long long)group_quad<OCT>(B, f, n - k) << k;
+    await_quad(A);
+    k += 4;
+    if (k >= n) break;
+  }
+  return live;
 }
 
 template <bool STATS>
@@ -597,6 +656,86 @@ __device__ __forceinline__ void scan_node_transposed(const DevScene &S, const Ra
           const double ti = readlane_f64(t, i);
           if (!(ubest >= 0 && ti > ubest_t)) {
             ubest = pb + base + i;
+            ubest_t = ti;
+          }
+        }
+      }
+    }
+    if (lane == L) {
+      best = ubest;
+      best_t = ubest_t;
+      if (STATS) st.v[ST_MT_TESTS] += mt_count;
+    }
+  }
+}
+
+// Transposed scan with block boxes (regular rays only): per ray, 64 BLOCK boxes
+// per step (lane = block, fp32 conservative test with the ray's own filter
+// constants), then the triangles of the blocks that may be hit, four blocks
+// (64 triangles) per step, exactly as above: exact fp64 box test, Möller–
+// Trumbore, hits folded in ascending stream order.
+template <bool STATS>
+__device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, const RayRegs &r,
+                                                            const Filter32 &f, int lane,
+                                                            unsigned long long inmask, int pb, int pc,
+                                                            int &best, double &best_t, LaneStats &st) {
+  const int b0 = pb / kGroupTris, nb = (pb + pc - 1) / kGroupTris - b0 + 1;
+  const float *blk = S.grp_aabb32 + (size_t)b0 * 6;
+  unsigned long long todo = inmask;
+  while (todo != 0ull) {
+    const int L = __builtin_ctzll(todo);
+    todo &= todo - 1;
+    RayRegs u;  // lane L's ray, wave-uniform
+    u.ox = readlane_f64(r.ox, L); u.oy = readlane_f64(r.oy, L); u.oz = readlane_f64(r.oz, L);
+    u.dx = readlane_f64(r.dx, L); u.dy = readlane_f64(r.dy, L); u.dz = readlane_f64(r.dz, L);
+    u.ix = readlane_f64(r.ix, L); u.iy = readlane_f64(r.iy, L); u.iz = readlane_f64(r.iz, L);
+    const float fix = readlane_f32(f.ix, L), fiy = readlane_f32(f.iy, L), fiz = readlane_f32(f.iz, L);
+    const float cnx = readlane_f32(f.cnx, L), cny = readlane_f32(f.cny, L), cnz = readlane_f32(f.cnz, L);
+    const float cfx = readlane_f32(f.cfx, L), cfy = readlane_f32(f.cfy, L), cfz = readlane_f32(f.cfz, L);
+    // near / far plane of each axis by the ray's direction sign (wave-uniform)
+    const int nx = __builtin_signbit(u.ix) ? 3 : 0, ny = __builtin_signbit(u.iy) ? 4 : 1,
+              nz = __builtin_signbit(u.iz) ? 5 : 2;
+    const int fx = 3 - nx, fy = 5 - ny, fz = 7 - nz;
+    int ubest = -1;
+    double ubest_t = 0.0;
+    unsigned mt_count = 0;
+    for (int g0 = 0; g0 < nb; g0 += 64) {
+      const int g = g0 + lane;
+      const float *bp = blk + (size_t)(g < nb ? g : nb - 1) * 6;
+      const float tnx = __builtin_fmaf(bp[nx], fix, cnx), tfx = __builtin_fmaf(bp[fx], fix, cfx);
+      const float tny = __builtin_fmaf(bp[ny], fiy, cny), tfy = __builtin_fmaf(bp[fy], fiy, cfy);
+      const float tnz = __builtin_fmaf(bp[nz], fiz, cnz), tfz = __builtin_fmaf(bp[fz], fiz, cfz);
+      const float lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+      const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+      // "may pass" unless provably not (NaN compares as may pass, like filter32_pass)
+      unsigned long long live = __builtin_amdgcn_ballot_w64(!(hi < 0.0f) && !(lo > hi) && g < nb);
+      while (live != 0ull) {
+        int q0 = -1, q1 = -1, q2 = -1, q3 = -1;  // next four blocks to look into
+        q0 = g0 + __builtin_ctzll(live); live &= live - 1;
+        if (live != 0ull) { q1 = g0 + __builtin_ctzll(live); live &= live - 1; }
+        if (live != 0ull) { q2 = g0 + __builtin_ctzll(live); live &= live - 1; }
+        if (live != 0ull) { q3 = g0 + __builtin_ctzll(live); live &= live - 1; }
+        const int quarter = lane >> 4;
+        const int myq = quarter == 0 ? q0 : (quarter == 1 ? q1 : (quarter == 2 ? q2 : q3));
+        const int tri = (b0 + myq) * kGroupTris + (lane & 15);  // stream position
+        const bool ok = myq >= 0 && tri >= pb && tri < pb + pc;
+        const int tri_c = ok ? tri : pb;
+        const double *bx = S.tri_aabb + (size_t)tri_c * 6;
+        const double b[6] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]};
+        const unsigned long long pm = slab_pass<1, 0>(b, u) & __builtin_amdgcn_ballot_w64(ok);
+        if (pm == 0ull) continue;
+        if (STATS) mt_count += (unsigned)__builtin_popcountll(pm);
+        const bool mine = ((pm >> lane) & 1ull) != 0;
+        double t = 0.0;
+        bool hit = false;
+        if (mine) hit = moller_trumbore(S.tri_vertex + (size_t)tri_c * 9, u.ox, u.oy, u.oz, u.dx, u.dy, u.dz, &t);
+        unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
+        while (hm != 0ull) {  // ascending lane = ascending stream position
+          const int i = __builtin_ctzll(hm);
+          hm &= hm - 1;
+          const double ti = readlane_f64(t, i);
+          if (!(ubest >= 0 && ti > ubest_t)) {
+            ubest = __builtin_amdgcn_readlane(tri_c, i);
             ubest_t = ti;
           }
         }
@@ -819,6 +958,20 @@ __device__ __attribute__((noinline)) unsigned order_children_call(const NodeRec 
 // SGPR box buffers (48 registers, partly in flight) never compete with the
 // traversal's own state.  Arguments arrive in VGPRs and are made uniform again.
 
+// The filtered scans take the scene through its device copy (DevScene::self,
+// scalar loads) instead of four pointers: with the ray (18 dwords) and the
+// filter constants (9) the argument list must stay within the 32 dwords the
+// calling convention passes in registers -- more would go through scratch.
+__device__ __forceinline__ DevScene scan_ctx_self(const DevScene *self) {
+  const MT_CONST DevScene *G = as_const(uniform_ptr(self));
+  DevScene S;
+  S.tri_aabb = G->tri_aabb;
+  S.tri_aabb32 = G->tri_aabb32;
+  S.grp_aabb32 = G->grp_aabb32;
+  S.tri_vertex = G->tri_vertex;
+  return S;
+}
+
 __device__ __forceinline__ DevScene scan_ctx(const float *b32, const double *b64, const double *vtx) {
   DevScene S;
   S.tri_aabb32 = uniform_ptr(b32);
@@ -828,10 +981,11 @@ __device__ __forceinline__ DevScene scan_ctx(const float *b32, const double *b64
 }
 
 template <int OCT, bool STATS>
-__device__ __attribute__((noinline)) ScanOut scan_filtered_call(const float *b32, const double *b64,
-                                                                const double *vtx, int pb, int pc,
-                                                                RayRegs r, Filter32 f) {
-  const DevScene S = scan_ctx(b32, b64, vtx);
+__device__ __attribute__((noinline)) ScanOut scan_filtered_call(const DevScene *self, int pb, int pc,
+                                                                MT_RAY_PARAMS, MT_F32_PARAMS) {
+  MT_RAY_FROM_PARAMS(r);
+  MT_F32_FROM_PARAMS(f);
+  const DevScene S = scan_ctx_self(self);
   LaneStats st;
   st.clear();
   ScanOut o{-1, 0.0, 0u};
@@ -840,9 +994,61 @@ __device__ __attribute__((noinline)) ScanOut scan_filtered_call(const float *b32
   return o;
 }
 
+// Big node, ray-parallel, with block boxes: first the boxes of the stream
+// blocks the node's list [pb, pb+pc) touches (64 at a time), then the filtered
+// scan over every run of blocks that some lane may hit.  A ray that misses a
+// block box (conservatively, in fp32) fails the reference's AABB pre-filter
+// (primitive_triangle.cc:73-76) for each member: its exact slab interval on a
+// member box lies inside the one on the union box (fp64 rounding is
+// monotonic), so skipping the block changes nothing.  Runs are visited in list
+// order and folded with the reference's rule (octtree.cc:186-194: a later hit
+// wins unless it is strictly farther).
+template <int OCT, bool STATS>
+__device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *self, int pb, int pc,
+                                                               MT_RAY_PARAMS, MT_F32_PARAMS) {
+  MT_RAY_FROM_PARAMS(r);
+  MT_F32_FROM_PARAMS(f);
+  self = uniform_ptr(self);
+  const MT_CONST float *gp = as_const(as_const(self)->grp_aabb32);
+  pb = uniform_i32(pb);
+  pc = uniform_i32(pc);
+  ScanOut o{-1, 0.0, 0u};
+  const int b0 = pb / kGroupTris, nb = (pb + pc - 1) / kGroupTris - b0 + 1;
+  for (int g0 = 0; g0 < nb; g0 += 64) {
+    const int n = (nb - g0) < 64 ? (nb - g0) : 64;
+#ifdef MT_PROF
+    o.n_groups += (unsigned)n;
+#endif
+    unsigned long long live = group_live_mask<OCT>(gp + (size_t)(b0 + g0) * 6, n, f);
+    while (live != 0ull) {
+      const int a = __builtin_ctzll(live);
+      const unsigned long long rest = ~(live >> a);  // zero bit = end of the run
+      const int len = rest != 0ull ? __builtin_ctzll(rest) : 64 - a;
+      int first = (b0 + g0 + a) * kGroupTris;
+      int last = first + len * kGroupTris;
+      if (first < pb) first = pb;
+      if (last > pb + pc) last = pb + pc;
+      const ScanOut q = scan_filtered_call<OCT, STATS>(self, first, last - first, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+#ifdef MT_PROF
+      o.n_ranges++;
+      o.n_live += (unsigned)len;
+      o.n_range_tris += (unsigned)(last - first);
+#endif
+      if (q.best >= 0 && !(o.best >= 0 && q.best_t > o.best_t)) {
+        o.best = q.best;
+        o.best_t = q.best_t;
+      }
+      o.mt_tests += q.mt_tests;
+      live = (a + len >= 64) ? 0ull : (live >> (a + len)) << (a + len);
+    }
+  }
+  return o;
+}
+
 template <int MODE, int OCT, bool STATS>
 __device__ __attribute__((noinline)) ScanOut scan_exact_call(const double *b64, const double *vtx, int pb,
-                                                             int pc, RayRegs r) {
+                                                             int pc, MT_RAY_PARAMS) {
+  MT_RAY_FROM_PARAMS(r);
   const DevScene S = scan_ctx(nullptr, b64, vtx);
   LaneStats st;
   st.clear();
@@ -856,7 +1062,8 @@ template <bool EX, bool STATS>
 __device__ __attribute__((noinline)) ScanOut scan_transposed_call(const double *b64, const double *vtx,
                                                                   int pb, int pc, int lane,
                                                                   unsigned inmask_lo, unsigned inmask_hi,
-                                                                  RayRegs r) {
+                                                                  MT_RAY_PARAMS) {
+  MT_RAY_FROM_PARAMS(r);
   const DevScene S = scan_ctx(nullptr, b64, vtx);
   const unsigned long long inmask =
       ((unsigned long long)(unsigned)uniform_i32((int)inmask_hi) << 32) | (unsigned)uniform_i32((int)inmask_lo);
@@ -869,17 +1076,42 @@ __device__ __attribute__((noinline)) ScanOut scan_transposed_call(const double *
 }
 
 template <bool STATS>
-__device__ __forceinline__ ScanOut scan_filtered_dispatch(const DevScene &S, int oct, int pb, int pc,
-                                                          const RayRegs &r, const Filter32 &f) {
+__device__ __attribute__((noinline)) ScanOut scan_transposed_blocks_call(const DevScene *self, int pb, int pc,
+                                                                         bool in, MT_RAY_PARAMS, MT_F32_PARAMS) {
+  MT_RAY_FROM_PARAMS(r);
+  MT_F32_FROM_PARAMS(f);
+  const DevScene S = scan_ctx_self(self);
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const unsigned long long inmask = __builtin_amdgcn_ballot_w64(in);
+  LaneStats st;
+  st.clear();
+  ScanOut o{-1, 0.0, 0u};
+  scan_node_transposed_blocks<STATS>(S, r, f, lane, inmask, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
+  o.mt_tests = st.v[ST_MT_TESTS];
+  return o;
+}
+
+template <bool STATS>
+__device__ __forceinline__ ScanOut scan_filtered_dispatch(const DevScene &S, int oct, const float *g32,
+                                                          int pb, int pc, const RayRegs &r,
+                                                          const Filter32 &f) {
   switch (oct) {
-    case 0: return scan_filtered_call<0, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
-    case 1: return scan_filtered_call<1, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
-    case 2: return scan_filtered_call<2, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
-    case 3: return scan_filtered_call<3, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
-    case 4: return scan_filtered_call<4, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
-    case 5: return scan_filtered_call<5, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
-    case 6: return scan_filtered_call<6, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
-    default: return scan_filtered_call<7, STATS>(S.tri_aabb32, S.tri_aabb, S.tri_vertex, pb, pc, r, f);
+    case 0: return (g32 ? scan_grouped_call<0, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<0, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 1: return (g32 ? scan_grouped_call<1, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<1, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 2: return (g32 ? scan_grouped_call<2, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<2, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 3: return (g32 ? scan_grouped_call<3, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<3, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 4: return (g32 ? scan_grouped_call<4, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<4, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 5: return (g32 ? scan_grouped_call<5, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<5, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 6: return (g32 ? scan_grouped_call<6, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<6, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    default: return (g32 ? scan_grouped_call<7, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<7, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
   }
 }
 
@@ -887,14 +1119,14 @@ template <bool STATS>
 __device__ __forceinline__ ScanOut scan_octant_dispatch(const DevScene &S, int oct, int pb, int pc,
                                                         const RayRegs &r) {
   switch (oct) {
-    case 0: return scan_exact_call<2, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
-    case 1: return scan_exact_call<2, 1, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
-    case 2: return scan_exact_call<2, 2, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
-    case 3: return scan_exact_call<2, 3, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
-    case 4: return scan_exact_call<2, 4, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
-    case 5: return scan_exact_call<2, 5, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
-    case 6: return scan_exact_call<2, 6, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
-    default: return scan_exact_call<2, 7, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+    case 0: return scan_exact_call<2, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
+    case 1: return scan_exact_call<2, 1, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
+    case 2: return scan_exact_call<2, 2, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
+    case 3: return scan_exact_call<2, 3, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
+    case 4: return scan_exact_call<2, 4, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
+    case 5: return scan_exact_call<2, 5, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
+    case 6: return scan_exact_call<2, 6, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
+    default: return scan_exact_call<2, 7, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
   }
 }
 
@@ -923,6 +1155,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   S.nodes = G->nodes;
   S.tri_aabb = G->tri_aabb;
   S.tri_aabb32 = G->tri_aabb32;
+  S.grp_aabb32 = G->grp_aabb32;
+  S.self = uniform_ptr(scene);
   S.tri_vertex = G->tri_vertex;
   S.bmax[0] = G->bmax[0]; S.bmax[1] = G->bmax[1]; S.bmax[2] = G->bmax[2];
   S.n_tris = G->n_tris;
@@ -1055,7 +1289,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
 
   // Nodes with fewer than kBigNode triangles are scanned lane-parallel, larger
   // ones wave-uniformly.  (Every leaf is small: the reference splits at 16.)
-  constexpr int kBigNode = 16;
   const bool lane_phase = (S.force_mode != 5);
   // Each wave step retires at least one (lane, node) visit and a lane visits a
   // node at most once per query, so 64 * n_nodes steps can never be exceeded.
@@ -1134,7 +1367,14 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // ~30 to broadcast each ray).
     const int n_in = __builtin_popcountll(inmask);
     const int chunks = (pc + 63) >> 6;
-    const bool transposed = (S.force_mode != 3) && pc > 0 && (n_in * (30 + 45 * chunks) < 20 * pc);
+    // With block boxes (regular rays, big node) both forms get much cheaper:
+    // ray-parallel ~14 per block + 200, transposed ~160 + 40 per 64 blocks per ray.
+    const bool blocks_ok = all_regular && use_filter && pc >= kBigNode && S.force_mode != 6;
+    const int nblk = (pb + pc - 1) / kGroupTris - pb / kGroupTris + 1;
+    const bool transposed =
+        (S.force_mode != 3) && pc > 0 &&
+        (blocks_ok ? (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk)
+                   : (n_in * (30 + 45 * chunks) < 20 * pc));
     int best = -1;
     double best_t = 0.0;
     MT_PROF_BEGIN(prof_t1);
@@ -1142,9 +1382,11 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       MT_PROF_COUNT(PROF_N_TRANSPOSED, 1);
       MT_PROF_COUNT(PROF_N_CHUNKS, n_in * chunks);
       if (STATS) st.wave_tri_steps += (unsigned)(n_in * chunks) - (unsigned)pc;  // replaces the pc counted above
-      const ScanOut o = (mode == 0)
-          ? scan_transposed_call<true, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), r)
-          : scan_transposed_call<false, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), r);
+      const ScanOut o = blocks_ok
+          ? scan_transposed_blocks_call<STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
+          : (mode == 0)
+          ? scan_transposed_call<true, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), MT_RAY_ARGS(r))
+          : scan_transposed_call<false, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), MT_RAY_ARGS(r));
       best = o.best;
       best_t = o.best_t;
       if (STATS && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
@@ -1161,17 +1403,45 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       if (!transposed) {
         const int oct = sx | (sy << 1) | (sz << 2);
         ScanOut o;
-        if (mode == 2 && use_filter) o = scan_filtered_dispatch<STATS>(S, oct, pb, pc, r, f32);
+        const float *g32 = nullptr;
+        if (pc >= kBigNode && S.force_mode != 6) g32 = S.grp_aabb32;
+        if (mode == 2 && use_filter) {
+          o = scan_filtered_dispatch<STATS>(S, oct, g32, pb, pc, r, f32);
+#ifdef MT_PROF
+          MT_PROF_COUNT(PROF_G_GROUPS, __builtin_amdgcn_readfirstlane(o.n_groups));
+          MT_PROF_COUNT(PROF_G_LIVE, __builtin_amdgcn_readfirstlane(o.n_live));
+          MT_PROF_COUNT(PROF_G_RANGES, __builtin_amdgcn_readfirstlane(o.n_ranges));
+          MT_PROF_COUNT(PROF_G_RANGE_TRIS, __builtin_amdgcn_readfirstlane(o.n_range_tris));
+#endif
+        } else if (mode == 1 && use_filter && g32 != nullptr) {
+          // Mixed sign octants: one filtered scan per octant present, each for
+          // its own lanes (a lane's result depends on its own ray only).
+          const int my_oct = sxl | (syl << 1) | (szl << 2);
+          o = ScanOut{-1, 0.0, 0u};
+          for (int q = 0; q < 8; q++) {
+            if (__ballot(my_oct == q) == 0ull) continue;
+            if (my_oct == q) o = scan_filtered_dispatch<STATS>(S, q, g32, pb, pc, r, f32);
+          }
+        }
         else if (mode == 2) o = scan_octant_dispatch<STATS>(S, oct, pb, pc, r);
-        else if (mode == 1) o = scan_exact_call<1, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
-        else o = scan_exact_call<0, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, r);
+        else if (mode == 1) o = scan_exact_call<1, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
+        else o = scan_exact_call<0, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
         best = o.best;
         best_t = o.best_t;
         if (STATS && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
 #ifdef MT_PROF
     }
-    if (!transposed) MT_PROF_END(PROF_SCAN_RAYPAR, prof_t1);
+    if (!transposed) {
+      MT_PROF_END(PROF_SCAN_RAYPAR, prof_t1);
+      const int slot_ = (mode == 2 && use_filter) ? 0 : (mode == 2 ? 1 : (mode == 1 ? 2 : 3));
+      MT_PROF_END(PROF_SCAN_M2F + slot_, prof_t1);
+      MT_PROF_COUNT(PROF_N_M2F + slot_, 1);
+      if (slot_ == 0) MT_PROF_COUNT(PROF_TRIS_M2F, pc);
+      if (slot_ == 2) MT_PROF_COUNT(PROF_TRIS_M1, pc);
+    } else {
+      MT_PROF_COUNT(PROF_TRIS_TRANSPOSED, pc);
+    }
     MT_PROF_BEGIN(prof_t1);
     if (in) {
 #endif

@@ -7,11 +7,10 @@ correct if NOTHING touches those registers until the matching
 `s_waitcnt lgkmcnt(0)` asm statement.  This script compiles the HIP library to
 ISA text and verifies exactly that, for every asm-issued s_load:
 
-  * between the load and the next asm wait (in layout order) no instruction
+  * on EVERY control-flow path from the load to an asm wait no instruction
     reads or writes any destination register of the load (that includes
-    v_writelane/v_readlane spill code and s_mov copies);
-  * every asm wait is immediately preceded (in its own asm block) by nothing
-    else, i.e. the wait statement is intact.
+    v_writelane/v_readlane spill code and s_mov copies), no second asm load is
+    issued, no function is called and the function is not left.
 
 Exit status 0 = safe.  Run by tests/test_host_cpu.py and by hand after any
 change to the traversal code or the compiler.
@@ -55,52 +54,88 @@ def referenced_sgprs(line: str):
     return regs
 
 
+def parse_function(func: str):
+    """-> list of items in layout order: ('label', name) | ('asm', [lines]) | ('ins', text)."""
+    items = []
+    lines = func.split("\n")
+    i = 0
+    while i < len(lines):
+        ln = lines[i]
+        if "#ASMSTART" in ln:
+            j = i + 1
+            block = []
+            while j < len(lines) and "#ASMEND" not in lines[j]:
+                block.append(lines[j].strip())
+                j += 1
+            items.append(("asm", block))
+            i = j + 1
+            continue
+        code = ln.split(";")[0].strip()
+        m = re.fullmatch(r"(\.LBB\w+):", code)
+        if m:
+            items.append(("label", m.group(1)))
+        elif code and not code.startswith(".") and not code.endswith(":"):
+            items.append(("ins", code))
+        i += 1
+    return items
+
+
 def check(text: str):
+    """Control-flow walk: from every asm-issued load follow EVERY path (both
+    arms of each conditional branch) up to the asm wait; nothing on the way may
+    touch a destination register, issue another asm load, or leave the function."""
     problems, n_loads = [], 0
     for func in re.split(r"\n(?=_Z\w+:)", text):
         name = func.split(":", 1)[0].strip()
-        lines = func.split("\n")
-        i = 0
-        while i < len(lines):
-            if "#ASMSTART" in lines[i]:
-                j = i + 1
-                block = []
-                while j < len(lines) and "#ASMEND" not in lines[j]:
-                    block.append(lines[j].strip())
-                    j += 1
-                loads = [b for b in block if b.startswith("s_load_dword")]
-                if loads:
-                    n_loads += 1
-                    inflight = set()
-                    for b in loads:
-                        inflight |= sregs(b.split()[1].rstrip(","))
-                    # walk to the next asm block that holds the wait
-                    k = j + 1
-                    found = False
-                    while k < len(lines):
-                        if "#ASMSTART" in lines[k]:
-                            nxt = []
-                            kk = k + 1
-                            while kk < len(lines) and "#ASMEND" not in lines[kk]:
-                                nxt.append(lines[kk].strip())
-                                kk += 1
-                            if any(x.startswith("s_waitcnt lgkmcnt(0)") for x in nxt):
-                                found = True
-                                break
-                            if any(x.startswith("s_load_dword") for x in nxt):
-                                problems.append("%s: a second asm load is issued before the wait (line %d)" % (name, k))
-                                break
-                            k = kk
-                        else:
-                            code = lines[k].split(";")[0]
-                            hit = referenced_sgprs(code) & inflight
-                            if hit and not code.strip().startswith("."):
-                                problems.append("%s: '%s' touches in-flight s%s" % (name, code.strip(), sorted(hit)[:4]))
-                        k += 1
-                    if not found and not problems:
-                        problems.append("%s: asm load without a following asm wait" % name)
-                i = j
-            i += 1
+        items = parse_function(func)
+        label_at = {it[1]: idx for idx, it in enumerate(items) if it[0] == "label"}
+        for idx, it in enumerate(items):
+            if it[0] != "asm":
+                continue
+            loads = [b for b in it[1] if b.startswith("s_load_dword")]
+            if not loads:
+                continue
+            n_loads += 1
+            inflight = set()
+            for b in loads:
+                inflight |= sregs(b.split()[1].rstrip(","))
+            seen, work, bad = set(), [idx + 1], []
+            while work and not bad:
+                k = work.pop()
+                while True:
+                    if k in seen:
+                        break
+                    seen.add(k)
+                    if k >= len(items):
+                        bad.append("falls off the function with a load in flight")
+                        break
+                    kind, val = items[k]
+                    if kind == "asm":
+                        if any(x.startswith("s_waitcnt lgkmcnt(0)") for x in val):
+                            break  # this path is safe
+                        if any(x.startswith("s_load_dword") for x in val):
+                            bad.append("a second asm load is issued before the wait")
+                            break
+                    elif kind == "ins":
+                        hit = referenced_sgprs(val) & inflight
+                        if hit:
+                            bad.append("'%s' touches in-flight s%s" % (val, sorted(hit)[:4]))
+                            break
+                        op = val.split()[0]
+                        if op in ("s_setpc_b64", "s_endpgm"):
+                            bad.append("leaves the function with a load in flight")
+                            break
+                        if op == "s_swappc_b64":
+                            bad.append("calls a function with a load in flight")
+                            break
+                        if op == "s_branch":
+                            k = label_at.get(val.split()[1], len(items))
+                            continue
+                        if op.startswith("s_cbranch"):
+                            work.append(label_at.get(val.split()[1], len(items)))
+                    k += 1
+            for b in bad:
+                problems.append("%s: %s" % (name, b))
     return n_loads, problems
 
 
