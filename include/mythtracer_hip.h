@@ -211,8 +211,12 @@ int mt_intersect_rays(mt_scene *scene, int n, const double *rays,
  * the octant-uniform path, 3 = automatic but never the triangle-parallel
  * (transposed) node scan, 4 = automatic but without the fp32 conservative
  * pre-filter, 5 = automatic but every node through a wave step (no
- * lane-parallel scan of small nodes), 6 = automatic but without the group
- * boxes that skip runs of triangles.  Results are identical in every mode. */
+ * lane-parallel scan of small nodes), 6 = automatic but without the block
+ * boxes that skip runs of triangles, 7 = automatic but without the subtree
+ * boxes that skip children.  Results are identical in every mode; the
+ * counters box_tests / node_visits / tri_tests equal the reference's
+ * un-pruned traversal in modes 1, 2, 4 and 7 (no subtree is skipped there)
+ * and count only the nodes actually visited in the others. */
 int mt_scene_set_traversal_mode(mt_scene *scene, int mode);
 
 #ifdef __cplusplus

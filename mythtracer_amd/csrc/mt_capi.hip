@@ -439,9 +439,43 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     }
     for (int k = 0; k < 6; k++) groups.push_back((float)u[k]);
   }
+  // Subtree boxes (mt_trace.h tight_keep_mask): union of the fp64 boxes of all
+  // triangles stored in a node or below it, rounded to fp32 like the others.
+  // Breadth-first order: children have larger indices than their parent.  An
+  // empty subtree gets an inverted box, which every ray misses.
+  std::vector<float> subs((size_t)nn * 6 + 8 * 6, 0.0f);
+  {
+    std::vector<double> sb((size_t)nn * 6);
+    for (int i = nn - 1; i >= 0; i--) {
+      double *u = &sb[(size_t)i * 6];
+      for (int k = 0; k < 3; k++) {
+        u[k] = 3.0e38;
+        u[3 + k] = -3.0e38;
+      }
+      const NodeRec &r = recs[i];
+      for (int t = r.prim_begin; t < r.prim_begin + r.prim_count; t++) {
+        const double *b = d->tri_aabb + (size_t)t * 6;
+        for (int k = 0; k < 3; k++) {
+          u[k] = std::min(u[k], b[k]);
+          u[3 + k] = std::max(u[3 + k], b[3 + k]);
+        }
+      }
+      if (r.first_child != 0) {
+        for (int c = 0; c < 8; c++) {
+          const double *b = &sb[(size_t)(r.first_child + c) * 6];
+          for (int k = 0; k < 3; k++) {
+            u[k] = std::min(u[k], b[k]);
+            u[3 + k] = std::max(u[3 + k], b[3 + k]);
+          }
+        }
+      }
+      for (int k = 0; k < 6; k++) subs[(size_t)i * 6 + k] = (float)u[k];
+    }
+  }
   groups.resize(groups.size() + 8 * 6, 0.0f);  // the scan looks four boxes ahead
   int rc;
   if ((rc = upload(s, groups.data(), groups.size(), &s->dev.grp_aabb32)) != MT_OK) return rc;
+  if ((rc = upload(s, subs.data(), subs.size(), &s->dev.sub_aabb32)) != MT_OK) return rc;
   if ((rc = upload(s, recs.data(), recs.size(), &s->dev.nodes)) != MT_OK) return rc;
   const size_t nt = (size_t)d->n_tris;
   {
@@ -545,7 +579,7 @@ int mt_scene_set_lights(mt_scene *s, const mt_light *lights, int n) {
 }
 
 int mt_scene_set_traversal_mode(mt_scene *s, int mode) {
-  if (!s || mode < 0 || mode > 6) return fail(MT_ERR_ARG, "mode must be 0..6");
+  if (!s || mode < 0 || mode > 7) return fail(MT_ERR_ARG, "mode must be 0..7");
   s->dev.force_mode = mode;
   return MT_OK;
 }

@@ -44,6 +44,7 @@ struct DevScene {
   const double *tri_aabb;    // 6 per triangle, node-stream order
   const float *tri_aabb32;   // the same boxes rounded to fp32 (conservative pre-filter)
   const float *grp_aabb32;   // fp32 union box of each block of kGroupTris consecutive stream triangles
+  const float *sub_aabb32;   // per node: fp32 union box of all triangles in its subtree
   double bmax[3];            // max |coordinate| of any triangle box, per axis
   const double *tri_vertex;  // 9 per triangle
   const double *tri_normal;  // 9 per triangle
@@ -57,7 +58,7 @@ struct DevScene {
   int32_t n_tris;
   int32_t n_nodes;
   int32_t tree_depth;
-  int32_t force_mode;  // 0 auto, 1 exact only, 2 no octant path
+  int32_t force_mode;  // mt_scene_set_traversal_mode (include/mythtracer_hip.h)
   int32_t scene_regular;  // 1: all coordinates finite and boxes ordered
   // Debug heartbeat (normally NULL): host-visible words the kernel updates so
   // that a stuck launch can be diagnosed from the host (MT_DEBUG_HEARTBEAT=1).

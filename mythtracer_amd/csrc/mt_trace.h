@@ -768,8 +768,13 @@ __device__ __forceinline__ void scan_node_octant(const DevScene &S, const RayReg
 
 // Child slab tests + ordering of the hit children, octtree.cc:204-216.
 // Returns ord (3 bits per entry) | count << 24.
+// keep: bit c clear = child c's subtree provably holds no triangle this ray's
+// pre-filter accepts (tight_keep_mask); such a child is left out of the list.
+// The sort is stable and a child without a hit only makes the parent's loop
+// move on (octtree.cc:222-251), so leaving it out changes nothing.
 template <int MODE>
-__device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, const RayRegs &r) {
+__device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, const RayRegs &r,
+                                                   unsigned keep = 0xffu) {
   constexpr bool EX = (MODE == 0);
   double xmin[2], xmax[2], ymin[2], ymax[2], zmin[2], zmax[2];
   {
@@ -799,7 +804,7 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
     const double tmax = mn3<EX>(xmax[xh], ymax[yh], zmax[zh]);
     const double tmin = mx3<EX>(xmin[xh], ymin[yh], zmin[zh]);
     if constexpr (EX) valid[c] = !(tmax < 0.0) && !(tmin > tmax);
-    else valid[c] = (tmax >= 0.0) & (tmin <= tmax);
+    else valid[c] = (tmax >= 0.0) & (tmin <= tmax) & (((keep >> c) & 1u) != 0u);
     tm[c] = tmin;
   }
   unsigned ord = 0, cnt = 0;
@@ -928,16 +933,44 @@ __device__ __attribute__((noinline)) ScanOut scan_small_lane_call(const double *
   return o;
 }
 
-// order_children for a per-lane node (no uniformisation of the pointer)
+// Subtree boxes: sub[c*6 .. c*6+5] = fp32 union box of every triangle stored in
+// child c or below it.  A ray that misses it (conservatively, in fp32; same
+// argument as for the block boxes) fails the reference's AABB pre-filter for
+// every triangle down there, so visiting that child could only return "no hit".
+__device__ __forceinline__ unsigned tight_keep_mask(const float *sub, const Filter32 &f, bool sx,
+                                                    bool sy, bool sz) {
+  unsigned keep = 0u;
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const float *b = sub + c * 6;
+    const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
+    const float tnx = __builtin_fmaf(sx ? b3 : b0, f.ix, f.cnx), tfx = __builtin_fmaf(sx ? b0 : b3, f.ix, f.cfx);
+    const float tny = __builtin_fmaf(sy ? b4 : b1, f.iy, f.cny), tfy = __builtin_fmaf(sy ? b1 : b4, f.iy, f.cfy);
+    const float tnz = __builtin_fmaf(sz ? b5 : b2, f.iz, f.cnz), tfz = __builtin_fmaf(sz ? b2 : b5, f.iz, f.cfz);
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+    const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+    if (!(hi < 0.0f) && !(lo > hi)) keep |= 1u << c;  // NaN: keep
+  }
+  return keep;
+}
+
+// order_children for a per-lane node (no uniformisation of the pointer).
+// sub = the eight subtree boxes of the node's children, or nullptr (no culling).
 template <int MODE>
 __device__ __attribute__((noinline)) unsigned order_children_lane_call(const NodeRec *N, double ox, double oy,
                                                                        double oz, double ix, double iy,
-                                                                       double iz) {
+                                                                       double iz, const float *sub,
+                                                                       MT_F32_PARAMS) {
   RayRegs r;
   r.ox = ox; r.oy = oy; r.oz = oz;
   r.dx = 0.0; r.dy = 0.0; r.dz = 0.0;
   r.ix = ix; r.iy = iy; r.iz = iz;
-  return order_children<MODE>(as_const(N), r);
+  unsigned keep = 0xffu;
+  if (MODE != 0 && sub != nullptr) {
+    MT_F32_FROM_PARAMS(f);
+    keep = tight_keep_mask(sub, f, __builtin_signbit(ix), __builtin_signbit(iy), __builtin_signbit(iz));
+  }
+  return order_children<MODE>(as_const(N), r, keep);
 }
 
 // Non-inlined entry of order_children (its exact-mode variant alone needs ~60
@@ -945,12 +978,19 @@ __device__ __attribute__((noinline)) unsigned order_children_lane_call(const Nod
 template <int MODE>
 __device__ __attribute__((noinline)) unsigned order_children_call(const NodeRec *N, double ox, double oy,
                                                                   double oz, double ix, double iy,
-                                                                  double iz) {
+                                                                  double iz, const float *sub,
+                                                                  MT_F32_PARAMS) {
   RayRegs r;
   r.ox = ox; r.oy = oy; r.oz = oz;
   r.dx = 0.0; r.dy = 0.0; r.dz = 0.0;
   r.ix = ix; r.iy = iy; r.iz = iz;
-  return order_children<MODE>(as_const(uniform_ptr(N)), r);
+  unsigned keep = 0xffu;
+  if (MODE != 0 && sub != nullptr) {
+    MT_F32_FROM_PARAMS(f);
+    keep = tight_keep_mask(uniform_ptr(sub), f, __builtin_signbit(ix), __builtin_signbit(iy),
+                           __builtin_signbit(iz));
+  }
+  return order_children<MODE>(as_const(uniform_ptr(N)), r, keep);
 }
 
 // ---- non-inlined entry points of the node scans ------------------------------
@@ -1156,6 +1196,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   S.tri_aabb = G->tri_aabb;
   S.tri_aabb32 = G->tri_aabb32;
   S.grp_aabb32 = G->grp_aabb32;
+  S.sub_aabb32 = G->sub_aabb32;
   S.self = uniform_ptr(scene);
   S.tri_vertex = G->tri_vertex;
   S.bmax[0] = G->bmax[0]; S.bmax[1] = G->bmax[1]; S.bmax[2] = G->bmax[2];
@@ -1204,6 +1245,11 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   const bool f32_ok = make_filter32(S, r, f32);
   const bool use_filter = all_regular && (S.force_mode != 4) && (S.force_mode != 2) &&
                           (__ballot(want && !f32_ok) == 0ull);
+
+  // Subtree culling (see tight_keep_mask); off in the modes without the fp32
+  // filter and in mode 7, where the counters then match the reference's
+  // un-pruned traversal exactly.
+  const bool cull = use_filter && (S.force_mode != 7);
 
   const MT_CONST NodeRec *nodes = as_const(S.nodes);
   int cur = -1;
@@ -1317,8 +1363,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (fc != 0) {
           if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           const NodeRec *Np = S.nodes + cur;
-          ordw = all_regular ? order_children_lane_call<1>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz)
-                             : order_children_lane_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz);
+          const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
+          ordw = all_regular ? order_children_lane_call<1>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, sub, MT_F32_ARGS(f32))
+                             : order_children_lane_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, nullptr, MT_F32_ARGS(f32));
         }
         finish_node(fc, ordw, o.best, o.best_t);
       }
@@ -1449,8 +1496,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       if (fc != 0) {
         if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         const NodeRec *Np = S.nodes + n;
-        ordw = (mode == 0) ? order_children_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz)
-                           : order_children_call<1>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz);
+        const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
+        ordw = (mode == 0) ? order_children_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, nullptr, MT_F32_ARGS(f32))
+                           : order_children_call<1>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, sub, MT_F32_ARGS(f32));
       }
       finish_node(fc, ordw, best, best_t);
     }
