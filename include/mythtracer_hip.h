@@ -190,8 +190,20 @@ int mt_blit_tiles_device(mt_scene *scene, int image_w, int image_h,
 /* Fetches and clears the accumulated counters (kernel_ms/total_ms = 0). */
 int mt_scene_read_stats(mt_scene *scene, mt_stats *stats);
 
+/* Work scheduling.  use_cost_history = 1 (default): a launch with the same
+ * geometry as the previous one (image, region, tiling, recursion depth, light
+ * count) hands out its 8x8-pixel blocks in the order of the costs measured in
+ * that previous launch, longest first, the few longest as four quarters with
+ * four lanes per pixel; everything then runs in ONE kernel.  0: every launch
+ * classifies its blocks by material first (two kernels).  Either way each
+ * pixel is computed by the same arithmetic: the output does not depend on it.
+ * The call also forgets the recorded costs.  (No reference counterpart: the
+ * reference hands rows to a thread pool, mythtracer.cc:244-290.) */
+int mt_scene_set_scheduling(mt_scene *scene, int use_cost_history);
+
 /* Device durations of the launches made since the previous call (at most the
- * last 64, oldest first; at most max_n): primary_ms[i] = mt::primary_kernel,
+ * last 64, oldest first; at most max_n): primary_ms[i] = mt::primary_kernel
+ * (or mt::schedule_kernel when the launch used the cost history),
  * render_ms[i] = mt::render_kernel of launch i, from HIP events recorded on
  * the launch's own stream.  Waits for those launches.  Returns the number of
  * entries written, or a negative MT_ERR_*.  (No reference counterpart: the

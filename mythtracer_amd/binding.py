@@ -20,7 +20,7 @@ HIP_SYMBOLS = [
     "mt_scene_destroy", "mt_scene_set_lights", "mt_render_chunk",
     "mt_render_chunk_device", "mt_render_tiles_device", "mt_blit_tiles_device",
     "mt_scene_read_stats", "mt_intersect_rays", "mt_scene_set_traversal_mode",
-    "mt_scene_kernel_times",
+    "mt_scene_kernel_times", "mt_scene_set_scheduling",
 ]
 
 STAT_NAMES = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests",
@@ -122,6 +122,7 @@ class HipAbi:
         L.mt_intersect_rays.argtypes = [vp, ci, vp, vp, vp, vp, vp, vp]
         L.mt_scene_set_traversal_mode.argtypes = [vp, ci]
         L.mt_scene_kernel_times.argtypes = [vp, ci, vp, vp]
+        L.mt_scene_set_scheduling.argtypes = [vp, ci]
 
     def last_error(self) -> str:
         return self.lib.mt_last_error().decode(errors="replace")
@@ -247,6 +248,9 @@ class HipAbi:
         st = mt_stats()
         self.check(self.lib.mt_scene_read_stats(h, C.byref(st)))
         return st.as_dict()
+
+    def set_scheduling(self, h, use_cost_history: bool):
+        self.check(self.lib.mt_scene_set_scheduling(h, 1 if use_cost_history else 0))
 
     def kernel_times(self, h, max_n: int = 64):
         """(primary_ms[], render_ms[]) of the launches since the previous call."""

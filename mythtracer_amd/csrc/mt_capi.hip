@@ -59,6 +59,15 @@ struct mt_scene {
   size_t hit_t_bytes = 0;
   unsigned int *d_class_list = nullptr;  // [3][n_items]
   size_t class_list_bytes = 0;
+  // cost feedback (schedule_kernel): valid for launches of the same geometry
+  unsigned int *d_item_cost = nullptr;   // [n_items]
+  size_t item_cost_bytes = 0;
+  unsigned int *d_order_item = nullptr;  // [4 n_items]
+  size_t order_item_bytes = 0;
+  signed char *d_order_sub = nullptr;    // [4 n_items]
+  size_t order_sub_bytes = 0;
+  unsigned long long cost_signature = 0;  // 0 = no history
+  bool use_history = true;
   uint8_t *d_rgb = nullptr;
   size_t rgb_bytes = 0;
   mt_debug_px *d_debug = nullptr;
@@ -125,6 +134,10 @@ int configure_launch(mt_scene *s) {
                                                        wpb * 64, s->lds_bytes));
   if (per_cu < 1) per_cu = 1;
   if (per_cu * wpb > 16) per_cu = 16 / wpb;  // more waves only add divergence state
+  if (const char *e = getenv("MT_DEBUG_BLOCKS_PER_CU")) {  // occupancy experiments
+    const int v = atoi(e);
+    if (v >= 1 && v < per_cu) per_cu = v;
+  }
   s->grid_blocks = s->n_cu * per_cu;
   return MT_OK;
 }
@@ -179,8 +192,30 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       rc = ensure_bytes((void **)&s->d_class_list, &s->class_list_bytes,
                         3 * (size_t)P.n_items * sizeof(unsigned int));
     }
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_item_cost, &s->item_cost_bytes, (size_t)P.n_items * 4);
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_item, &s->order_item_bytes, (size_t)P.n_items * 16);
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_sub, &s->order_sub_bytes, (size_t)P.n_items * 4);
     if (rc != MT_OK) return rc;
   }
+  P.item_cost = s->d_item_cost;
+  P.order_item = s->d_order_item;
+  P.order_sub = s->d_order_sub;
+  P.n_work = s->d_work + 7;
+  // The block costs of the previous launch are a valid forecast when that
+  // launch had the same geometry (an animation frame, main_local.cc:79-110, or
+  // a repeated benchmark step).  Then one launch does everything, blocks
+  // longest first; otherwise launch 1 classifies the blocks by material first.
+  unsigned long long sig = 1469598103934665603ull;
+  {
+    const long long key[] = {image_w, image_h, rx, ry, rw, rh, tile_w, tile_h, first_tile, tile_stride,
+                             n_tiles, max_depth, (long long)(size_t)s->d_item_cost, s->dev.n_lights};
+    for (long long v : key) {
+      sig = (sig ^ (unsigned long long)v) * 1099511628211ull;
+    }
+    if (sig == 0) sig = 1;
+  }
+  const bool history = s->use_history && s->cost_signature == sig && d_debug == nullptr;
+  P.from_primary = history ? 0 : 1;
   P.hit_prim = s->d_hit_prim;
   P.hit_t = s->d_hit_t;
   P.class_list = s->d_class_list;
@@ -203,7 +238,10 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (!ek[i]) HIP_TRY(hipEventCreate(&ek[i]));
   }
   HIP_TRY(hipEventRecord(ek[0], stream));
-  if (s->stats_enabled) {
+  if (history) {
+    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
+                       s->grid_blocks * s->waves_per_block);
+  } else if (s->stats_enabled) {
     hipLaunchKernelGGL(primary_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
   } else {
     hipLaunchKernelGGL(primary_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
@@ -217,6 +255,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   HIP_TRY(hipEventRecord(ek[2], stream));
   HIP_TRY(hipGetLastError());
   s->launches_timed++;
+  s->cost_signature = sig;  // the costs now in d_item_cost belong to this geometry
   if (d_item) {  // debug: dump per-item durations (synchronises!)
     std::vector<unsigned long long> host((size_t)P.n_items * 4 * 2);
     HIP_TRY(hipMemcpy(host.data(), d_item, host.size() * 8, hipMemcpyDeviceToHost));
@@ -303,6 +342,9 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_hit_prim) (void)hipFree(s->d_hit_prim);
   if (s->d_hit_t) (void)hipFree(s->d_hit_t);
   if (s->d_class_list) (void)hipFree(s->d_class_list);
+  if (s->d_item_cost) (void)hipFree(s->d_item_cost);
+  if (s->d_order_item) (void)hipFree(s->d_order_item);
+  if (s->d_order_sub) (void)hipFree(s->d_order_sub);
   if (s->d_rgb) (void)hipFree(s->d_rgb);
   if (s->d_debug) (void)hipFree(s->d_debug);
   if (s->d_lights) (void)hipFree(s->d_lights);
@@ -581,6 +623,13 @@ int mt_scene_set_lights(mt_scene *s, const mt_light *lights, int n) {
 int mt_scene_set_traversal_mode(mt_scene *s, int mode) {
   if (!s || mode < 0 || mode > 7) return fail(MT_ERR_ARG, "mode must be 0..7");
   s->dev.force_mode = mode;
+  return MT_OK;
+}
+
+int mt_scene_set_scheduling(mt_scene *s, int use_cost_history) {
+  if (!s || (use_cost_history != 0 && use_cost_history != 1)) return fail(MT_ERR_ARG, "bad scheduling argument");
+  s->use_history = use_cost_history != 0;
+  s->cost_signature = 0;
   return MT_OK;
 }
 

@@ -117,6 +117,14 @@ struct RenderParams {
   unsigned int *class_count;      // [3] blocks per cost class
   unsigned int *class_list;       // [3][n_items] block ids per class
   double *frames;          // recursion frames scratch
+  // Cost feedback between frames of the same launch geometry (see
+  // schedule_kernel): s_memtime ticks each block took in the previous frame,
+  // and the work order derived from them.
+  unsigned int *item_cost;        // [n_items] ticks (>> 6) of the last frame; quarters add up
+  unsigned int *order_item;       // [<= 4 n_items] block id of work unit w
+  signed char *order_sub;         // [<= 4 n_items] -1 = whole block, 0..3 = quarter (4 lanes per pixel)
+  unsigned int *n_work;           // number of work units in order_item/order_sub
+  int32_t from_primary;           // 1: launch 1 ran (hit_prim/hit_t, class lists); 0: order_* lists
   unsigned long long *item_cycles;  // debug (MT_DEBUG_ITEM_CYCLES): s_memtime ticks per work item
 };
 

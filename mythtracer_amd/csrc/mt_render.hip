@@ -189,8 +189,98 @@ __global__ __launch_bounds__(256, 3) void primary_kernel(DevScene S, RenderParam
     const int item_cls = __builtin_amdgcn_readfirstlane(
         (__builtin_amdgcn_ballot_w64(cls == 2) != 0ull) ? 2 : ((__builtin_amdgcn_ballot_w64(cls == 1) != 0ull) ? 1 : 0));
     const unsigned slot = atomicAdd(P.class_count + item_cls, lane == 0 ? 1u : 0u);
-    if (lane == 0) P.class_list[(size_t)item_cls * P.n_items + slot] = item;
+    if (lane == 0) {
+      P.class_list[(size_t)item_cls * P.n_items + slot] = item;
+      // launch 2 adds the block's measured cost; bit 31 = "rendered as quarters"
+      P.item_cost[item] = item_cls == 2 ? 0x80000000u : 0u;
+    }
     flush_item_stats<STATS>(st, P.counters, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Work order from the previous frame's measured block costs (one block of 1024
+// threads, a few microseconds).  A frame cannot finish before its slowest work
+// item, and the per-pixel ray chains cannot be split, so:
+//   * blocks are handed out longest first (bucket sort on log2 of the cost,
+//     eight buckets per octave);
+//   * blocks that took longer than kQuadShare of an even share of the frame's
+//     work are cut into four quarters with FOUR lanes per pixel (the shadow
+//     loops of a pixel's lights run side by side: a shorter chain for about
+//     1.7x the work, which is why only the few longest blocks get it).
+// The order changes nothing about what is computed for a pixel.  Costs are in
+// units of 64 s_memtime ticks; a block rendered as quarters reports their sum,
+// which is scaled back (kQuadWork) before it is compared again.
+constexpr int kSchedThreads = 1024;
+constexpr int kSchedBuckets = 8 * 32;
+__device__ __forceinline__ int cost_bucket(unsigned c) {  // descending cost = ascending bucket
+  if (c == 0u) return kSchedBuckets - 1;
+  const int e = 31 - __builtin_clz(c);                        // octave
+  const int f = e >= 3 ? (int)((c >> (e - 3)) & 7u) : 0;      // eighth within it
+  return kSchedBuckets - 1 - (e * 8 + f);
+}
+__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves) {
+  __shared__ unsigned long long s_sum;
+  __shared__ unsigned s_count[kSchedBuckets];
+  __shared__ unsigned s_start[kSchedBuckets];
+  const int tid = threadIdx.x;
+  if (tid == 0) s_sum = 0ull;
+  for (int b = tid; b < kSchedBuckets; b += kSchedThreads) s_count[b] = 0u;
+  __syncthreads();
+  // costs measured in quad mode are sums over four quarters
+  const float kQuadWork = 1.7f, kQuadShare = 0.45f, kQuarterTime = 0.45f;
+  unsigned long long part = 0ull;
+  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
+    unsigned c = P.item_cost[i];
+    const bool was_quad = (c >> 31) != 0u;
+    c &= 0x7fffffffu;
+    if (was_quad) c = (unsigned)((float)c / kQuadWork);
+    part += c;
+  }
+  atomicAdd(&s_sum, part);
+  __syncthreads();
+  const float share = (float)s_sum / (float)(n_waves > 0 ? n_waves : 1);
+  const float quad_above = share * kQuadShare;
+  // pass 1: bucket counts (a quad block contributes four units)
+  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
+    unsigned c = P.item_cost[i];
+    const bool was_quad = (c >> 31) != 0u;
+    c &= 0x7fffffffu;
+    if (was_quad) c = (unsigned)((float)c / kQuadWork);
+    const bool quad = (float)c > quad_above && c > 0u;
+    const unsigned unit = quad ? (unsigned)((float)c * kQuarterTime) : c;
+    atomicAdd(&s_count[cost_bucket(unit)], quad ? 4u : 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned acc = 0u;
+    for (int b = 0; b < kSchedBuckets; b++) {
+      s_start[b] = acc;
+      acc += s_count[b];
+    }
+    *P.n_work = acc;
+  }
+  __syncthreads();
+  // pass 2: scatter, and reset the costs for the coming frame (bit 31 notes
+  // that the block will be measured as quarters)
+  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
+    unsigned c = P.item_cost[i];
+    const bool was_quad = (c >> 31) != 0u;
+    c &= 0x7fffffffu;
+    if (was_quad) c = (unsigned)((float)c / kQuadWork);
+    const bool quad = (float)c > quad_above && c > 0u;
+    const unsigned unit = quad ? (unsigned)((float)c * kQuarterTime) : c;
+    const unsigned at = atomicAdd(&s_start[cost_bucket(unit)], quad ? 4u : 1u);
+    if (quad) {
+      for (int q = 0; q < 4; q++) {
+        P.order_item[at + q] = i;
+        P.order_sub[at + q] = (signed char)q;
+      }
+    } else {
+      P.order_item[at] = i;
+      P.order_sub[at] = (signed char)-1;
+    }
+    P.item_cost[i] = quad ? 0x80000000u : 0u;
   }
 }
 
@@ -225,8 +315,9 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
   const V3 s_start = v3_load(P.sensor.start_point);
   const V3 s_ds = v3_load(P.sensor.delta_scanline);
   const V3 s_dp = v3_load(P.sensor.delta_pixel);
+  const bool from_primary = P.from_primary != 0;
   const unsigned n2 = P.class_count[2], n1 = P.class_count[1], n0 = P.class_count[0];
-  const unsigned n_work = 4u * n2 + n1 + n0;
+  const unsigned n_work = from_primary ? 4u * n2 + n1 + n0 : *P.n_work;
 
   for (;;) {
     const unsigned w = fetch_work(P.work_counter + 1, lane);
@@ -237,12 +328,20 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
     if (w >= n_work) break;
     unsigned item;
     int sub = -1;
-    // Order: reflective blocks (class 1) first — the longest of them (a floor
-    // that mirrors glass: 30+ sequential rays per pixel) cannot be told apart
-    // beforehand, so all of them start early; then the class-2 blocks, each as
-    // four quarters with four lanes per pixel (a pixel's shadow loops run side
-    // by side, which halves its ray chain); then everything else.
-    if (w < n1) {
+    if (!from_primary) {
+      // Order of the previous frame's measured block costs, longest first
+      // (schedule_kernel); the longest blocks come as four quarters.
+      item = P.order_item[w];
+      sub = (int)P.order_sub[w];
+      if (w < (n_work >> 4)) __builtin_amdgcn_s_setprio(3);
+      else if (w < (n_work >> 2)) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
+    } else if (w < n1) {
+      // No history: reflective blocks (class 1) first — the longest of them (a
+      // floor that mirrors glass: 30+ sequential rays per pixel) cannot be told
+      // apart beforehand, so all of them start early; then the class-2 blocks,
+      // each as four quarters with four lanes per pixel (a pixel's shadow loops
+      // run side by side, which halves its ray chain); then everything else.
       item = P.class_list[(size_t)1 * P.n_items + w];
       __builtin_amdgcn_s_setprio(3);
     } else if (w < n1 + 4u * n2) {
@@ -253,9 +352,10 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
       item = P.class_list[w - 4u * n2 - n1];
       __builtin_amdgcn_s_setprio(0);
     }
+    sub = __builtin_amdgcn_readfirstlane(sub);
     item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
 
-    const unsigned long long item_t0 = P.item_cycles ? __builtin_amdgcn_s_memtime() : 0ull;
+    const unsigned long long item_t0 = __builtin_amdgcn_s_memtime();
     const ItemGeom g = item_geometry(P, item, sub, lane);
     bool alive = g.inside;
     const size_t px_index = g.px_index;
@@ -307,7 +407,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
       }
       int trc = DEV_OK;
       const bool tracing = alive && mode != MODE_IDLE;
-      if (passes == 0) {  // the primary hit was found by launch 1
+      if (passes == 0 && from_primary) {  // the primary hit was found by launch 1
         prim = tracing ? P.hit_prim[px_index] : -1;
         t = tracing ? P.hit_t[px_index] : 0.0;
       } else {
@@ -332,7 +432,10 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
       V3 retval = v3(0, 0, 0);
       if (tracing) {
         if (mode == MODE_RADIANCE) {
-          if (STATS && level > 0) st.v[ST_RAYS_SECONDARY]++;  // level 0 was counted by launch 1
+          if (STATS) {  // with launch 1, level 0 was counted there
+            if (level > 0) st.v[ST_RAYS_SECONDARY]++;
+            else if (!from_primary) st.v[ST_RAYS_PRIMARY]++;
+          }
           if (prim < 0) {  // mythtracer.cc:23-31
             do_return = true;
           } else {
@@ -595,9 +698,16 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
     }
 
     if (S.hb && lane == 0) S.hb[wave_id * 4 + 0] = 4;
-    if (P.item_cycles && lane == 0) {
-      P.item_cycles[(size_t)w * 2] = __builtin_amdgcn_s_memtime() - item_t0;
-      P.item_cycles[(size_t)w * 2 + 1] = ((unsigned long long)passes << 32) | st.wave_tri_steps;
+    {
+      const unsigned long long ticks = __builtin_amdgcn_s_memtime() - item_t0;
+      if (lane == 0) {
+        const unsigned long long c = ticks >> 6;  // quarters of a block add up
+        atomicAdd(P.item_cost + item, c > 0x0fffffffull ? 0x0fffffffu : (unsigned)c);
+        if (P.item_cycles) {
+          P.item_cycles[(size_t)w * 2] = ticks;
+          P.item_cycles[(size_t)w * 2 + 1] = ((unsigned long long)passes << 32) | st.wave_tri_steps;
+        }
+      }
     }
     flush_item_stats<STATS>(st, P.counters, lane);
   }

@@ -1188,7 +1188,7 @@ struct TraceOut {
 // stack.  Must be called by all 64 lanes (want = false for lanes without a ray).
 template <bool STATS>
 __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, unsigned stack_base, int lane,
-                                                         bool want, double ox, double oy, double oz,
+                                                         bool want_all, double ox, double oy, double oz,
                                                          double dx, double dy, double dz) {
   const MT_CONST DevScene *G = as_const(uniform_ptr(scene));
   DevScene S;
@@ -1239,6 +1239,15 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   const bool fin = __builtin_isfinite(ox) && __builtin_isfinite(oy) && __builtin_isfinite(oz) &&
                    __builtin_isfinite(r.ix) && __builtin_isfinite(r.iy) && __builtin_isfinite(r.iz) &&
                    r.ix != 0.0 && r.iy != 0.0 && r.iz != 0.0;
+  // A wave that holds both kinds is traversed twice, the regular lanes first:
+  // one ray with a zero direction component (a pixel row level with the
+  // camera, say) must not push the other 63 onto the exact path, which has
+  // neither the fp32 filter nor the block / subtree boxes.
+  const int rounds = (S.scene_regular != 0 && S.force_mode != 1 && __ballot(want_all && !fin) != 0ull &&
+                      __ballot(want_all && fin) != 0ull) ? 2 : 1;
+  int status = DEV_OK;
+  for (int round = 0; round < rounds; round++) {
+  const bool want = rounds == 1 ? want_all : (want_all && (fin == (round == 0)));
   const bool all_regular = (S.scene_regular != 0) && (S.force_mode != 1) &&
                            (__ballot(want && !fin) == 0ull);
   Filter32 f32;
@@ -1340,7 +1349,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   // node at most once per query, so 64 * n_nodes steps can never be exceeded.
   const long long step_bound = 64ll * (long long)S.n_nodes + 64;
   long long steps = 0;
-  int status = DEV_OK;
   for (;;) {
     // ---- phase A: every lane works through its own small nodes
     if (lane_phase) {
@@ -1508,6 +1516,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       break;
     }
   }
+  if (status != DEV_OK) break;
+  }  // rounds
   MT_PROF_END(PROF_TRACE, prof_t0);
   MT_PROF_FLUSH(S.prof, lane);
   if (status != DEV_OK) {

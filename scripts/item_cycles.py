@@ -8,7 +8,9 @@ from mythtracer_amd import scenegen as sg
 info = sg.write_scene("room", "/tmp/mt_scenes")
 m = M.MythTracer(info["obj"]); m.set_lights(sg.ROOM_LIGHTS)
 W, H = 1920, 1080
-g = m.render(sg.ROOM_CAMERA, W, H)
+n_frames = int(os.environ.get("FRAMES", "3"))  # frame 1 has no cost history, the later ones do
+for _ in range(n_frames):
+    g = m.render(sg.ROOM_CAMERA, W, H)
 a = np.fromfile(out, dtype=np.uint64).reshape(-1, 2)
 a = a[a[:, 0] > 0]
 d = a[:, 0].astype(np.float64)

@@ -43,7 +43,7 @@ def counters_match(got, want):
     be fewer, because subtrees the ray provably cannot hit are not visited
     (mode 7 visits them all: test_counters_equal_the_oracle)."""
     assert {k: v for k, v in got.items() if k not in PRUNED} == {k: v for k, v in want.items() if k not in PRUNED}
-    assert all(got[k] <= want[k] for k in PRUNED), (got, want)
+    assert all(got[k] <= want[k] for k in PRUNED if k in got), (got, want)
 
 
 def load(name):
@@ -113,6 +113,49 @@ def test_ragged_chunks(chunk, scenes):
     assert_rgb_close(g["rgb"], r["rgb"], str(chunk))
     assert np.array_equal(g["line"], r["line"])
     counters_match(g["counters"], r["counters"])
+
+
+def test_cost_history_scheduling_changes_nothing(scenes):
+    """A repeated launch of the same geometry is scheduled from the block costs
+    measured in the previous one (one kernel, longest blocks first, some as
+    quarters with four lanes per pixel): same image, same counters as the
+    first, material-classified launch and as a scene with the history off."""
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["mini"])
+    h = abi.scene_create(m.flatten())
+    try:
+        abi.set_lights(h, scenegen.ROOM_LIGHTS)
+        sens = binding.sensor(scenegen.ROOM_CAMERA, 320, 180)
+        g = load("mini_320x180")
+        first = abi.render_chunk(h, sens, 320, 180)
+        assert_rgb_close(first["rgb"], g["rgb"], "first launch")
+        for i in range(3):
+            again = abi.render_chunk(h, sens, 320, 180)
+            assert np.array_equal(again["rgb"], first["rgb"]), i
+            # (which subtrees get skipped depends on the rays that share a wave,
+            # so the three pruned counters may differ between schedules)
+            counters_match({k: again["stats"][k] for k in ALL_KEYS if k not in PRUNED},
+                           {k: first["stats"][k] for k in ALL_KEYS if k not in PRUNED})
+        part = abi.render_chunk(h, sens, 320, 180, chunk=(16, 8, 200, 120))  # other geometry: no history
+        assert np.array_equal(part["rgb"], first["rgb"][8:128, 16:216])
+        part2 = abi.render_chunk(h, sens, 320, 180, chunk=(16, 8, 200, 120))  # ... and now with
+        assert np.array_equal(part2["rgb"], part["rgb"])
+        abi.set_scheduling(h, False)
+        for i in range(2):
+            off = abi.render_chunk(h, sens, 320, 180)
+            assert np.array_equal(off["rgb"], first["rgb"])
+        abi.set_scheduling(h, True)
+        abi.set_lights(h, [scenegen.ROOM_LIGHTS[0]] * 6)  # more lights than roles in a quad
+        a = abi.render_chunk(h, sens, 320, 180)
+        b = abi.render_chunk(h, sens, 320, 180)
+        assert np.array_equal(a["rgb"], b["rgb"])
+        assert all(a["stats"][k] == b["stats"][k] for k in ALL_KEYS if k not in PRUNED)
+        abi.set_lights(h, [])
+        a = abi.render_chunk(h, sens, 320, 180)
+        b = abi.render_chunk(h, sens, 320, 180)
+        assert np.array_equal(a["rgb"], b["rgb"])
+    finally:
+        abi.scene_destroy(h)
 
 
 def test_bad_chunks_are_rejected(scenes):
