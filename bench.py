@@ -226,8 +226,13 @@ def main():
             abi.set_lights(h, lights)
             abi.set_traversal_mode(h, 0)
             pf = {k: full[k] for k in keys}
-            for k in ("box_tests", "tri_tests", "mt_tests"):
-                pf[k] -= prim[k]
+            # With cost history (every timed step of a default run) render_kernel
+            # traces the primary rays too and the first kernel of the step is the
+            # 50-us schedule_kernel; without it they belong to primary_kernel.
+            primary_inside = k_primary_ms * 20.0 < k_ms
+            if not primary_inside:
+                for k in ("box_tests", "tri_tests", "mt_tests"):
+                    pf[k] -= prim[k]
             alg = algorithmic_bytes(pf, W * H)
             alg_primary = 48 * prim["box_tests"] + 48 * prim["tri_tests"] + 72 * prim["mt_tests"] + 12 * W * H
             traffic = None
@@ -240,12 +245,17 @@ def main():
                     "kernel": "mt::render_kernel", "kernel_ms": k_ms,
                     "algorithmic_bytes_per_launch": alg,
                     "launches_averaged": int(len(k_render)),
-                    "other_kernels": {"mt::primary_kernel": {
-                        "kernel_ms": k_primary_ms, "algorithmic_bytes_per_launch": alg_primary}},
+                    "primary_rays_traced_by_this_kernel": bool(primary_inside),
+                    "other_kernels": {"mt::schedule_kernel (mt::primary_kernel in a launch without cost history)": {
+                        "kernel_ms": k_primary_ms},
+                        "primary_rays_algorithmic_bytes": alg_primary},
                     "step_ms_device": k_step_ms,
                     "note": "algorithmic bytes = SURVEY 8(d) bytes of the reference's un-pruned "
-                            "traversal; they are served as wave-uniform scalar loads (one 48-B box "
-                            "per 64 rays), so the kernel is fp64-VALU bound, not HBM bound",
+                            "traversal (counted by an untimed frame in traversal mode 7); the kernel "
+                            "serves one box to 64 rays with a scalar load and rules out most blocks and "
+                            "subtrees by 24-byte union boxes, so it is latency/VALU bound, not HBM bound "
+                            "(DESIGN.md section 5); traffic = memory-side bytes per launch from the "
+                            "rocprofv3 PMC passes under profiles/",
                     "frame_work_visited_by_the_kernels": evaluated,
                     "frame_work_of_the_reference": reference_evaluates}
         out = {
@@ -259,7 +269,7 @@ def main():
                                    ".obj), %dx%d, %d lights with shadow rays, max recursion %d"
                                    % (args.scene, info["triangles"], W, H, len(lights), args.max_depth),
                        "tile": "%dx%d interleaved over %d rank(s)" % (tw, th, world) if world > 1
-                               else "single launch, 8x8-pixel work items",
+                               else "whole frame per launch, 8x8-pixel work items",
                        "scene_sha256": info["sha256"]},
             "frame_ms_wall": elapsed / max(args.steps, 1) * 1e3,
             "rays_per_frame": {k: per_frame[k] for k in ("rays_primary", "rays_secondary", "rays_shadow")},

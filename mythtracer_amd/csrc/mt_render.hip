@@ -705,7 +705,8 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
         atomicAdd(P.item_cost + item, c > 0x0fffffffull ? 0x0fffffffu : (unsigned)c);
         if (P.item_cycles) {
           P.item_cycles[(size_t)w * 2] = ticks;
-          P.item_cycles[(size_t)w * 2 + 1] = ((unsigned long long)passes << 32) | st.wave_tri_steps;
+          P.item_cycles[(size_t)w * 2 + 1] =
+              ((unsigned long long)passes << 40) | ((unsigned long long)item << 8) | (unsigned)(sub + 1);
         }
       }
     }

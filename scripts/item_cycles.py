@@ -14,15 +14,18 @@ for _ in range(n_frames):
 a = np.fromfile(out, dtype=np.uint64).reshape(-1, 2)
 a = a[a[:, 0] > 0]
 d = a[:, 0].astype(np.float64)
-passes = (a[:, 1] >> np.uint64(32)).astype(np.float64); steps = (a[:, 1] & np.uint64(0xffffffff)).astype(np.float64)
+passes = (a[:, 1] >> np.uint64(40)).astype(np.float64)
+item = ((a[:, 1] >> np.uint64(8)) & np.uint64(0xffffffff)).astype(np.int64); sub = (a[:, 1] & np.uint64(0xff)).astype(np.int64) - 1
+steps = np.ones_like(passes)
+bx = (item % (W // 8)) * 8; by = (item // (W // 8)) * 8
 print("items", len(d), "kernel_ms", g["kernel_ms"])
 print("ticks: sum %.3e mean %.0f median %.0f p90 %.0f p99 %.0f max %.0f" % (d.sum(), d.mean(), np.median(d), np.percentile(d, 90), np.percentile(d, 99), d.max()))
-print("passes: mean %.1f median %.0f p99 %.0f max %.0f ; tri-steps/pass mean %.0f" % (passes.mean(), np.median(passes), np.percentile(passes, 99), passes.max(), steps.sum() / passes.sum()))
-print("cycles per tri-step overall %.1f" % (d.sum() / steps.sum()))
+print("passes: mean %.1f median %.0f p99 %.0f max %.0f" % (passes.mean(), np.median(passes), np.percentile(passes, 99), passes.max()))
 order = np.argsort(-d)[:8]
-for i in order: print(" work", i, "cycles %.3e passes %d steps %.3e steps/pass %.0f cyc/step %.0f" % (d[i], passes[i], steps[i], steps[i] / max(passes[i],1), d[i] / max(steps[i],1)))
+for i in order: print(" work", i, "cycles %.3e passes %d item %d sub %d block x %d y %d" % (d[i], passes[i], item[i], sub[i], bx[i], by[i]))
+print("quarter units: %d, whole blocks: %d" % ((sub >= 0).sum(), (sub < 0).sum()))
 med = np.argsort(np.abs(d - np.median(d)))[:3]
-for i in med: print(" median-ish item", i, "cycles %.3e passes %d steps %.3e steps/pass %.0f cyc/step %.0f" % (d[i], passes[i], steps[i], steps[i] / passes[i], d[i] / steps[i]))
+for i in med: print(" median-ish item", i, "cycles %.3e passes %d" % (d[i], passes[i]))
 c = np.sort(d)[::-1]
 print("share of total cycles in top 1%% items: %.3f ; top 10%%: %.3f" % (c[:324].sum() / c.sum(), c[:3240].sum() / c.sum()))
 # greedy list-scheduling simulation: how long would the frame take if work items

@@ -1,26 +1,70 @@
-"""Summarises gpurun_out/prof_<tag>/ (scripts/pmc_passes.sh) per kernel:
-average duration from the kernel trace and per-launch averages of every
-counter.  Usage: python scripts/pmc_summary.py <tag> > profiles/<tag>_pmc_summary.txt"""
+"""Summarises gpurun_out/prof_<tag>/ (scripts/pmc_passes.sh) per kernel.
+
+bench.py --steps 4 --warmup 2 launches mt::render_kernel eight times: warm-up 1
+(no cost history yet: primary_kernel + render_kernel), warm-up 2 and the four
+timed steps (schedule_kernel + render_kernel), then two untimed counting frames
+(traversal mode 7; primary rays only).  Figures below are means over the four
+TIMED launches (dispatches 3..6 of render_kernel in launch order); the other
+launches are listed for reference.
+
+Usage: python scripts/pmc_summary.py <tag> > profiles/<tag>_pmc_summary.txt"""
 import csv, glob, os, sys, collections
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-dur = collections.defaultdict(list)
+TIMED = slice(2, 6)
+
+
+def by_kernel(rows, value):
+    """rows of one pass -> {kernel: [value per dispatch, in launch order]}"""
+    per = collections.OrderedDict()
+    for r in sorted(rows, key=lambda r: int(r["Dispatch_Id"])):
+        per.setdefault((r["Kernel_Name"], int(r["Dispatch_Id"])), 0.0)
+        per[(r["Kernel_Name"], int(r["Dispatch_Id"]))] += value(r)
+    out = collections.defaultdict(list)
+    for (k, _), v in per.items():
+        out[k].append(v)
+    return out
+
+
+dur = {}
 for f in glob.glob(os.path.join(base, "stats", "**", "*kernel_trace.csv"), recursive=True):
-    for r in csv.DictReader(open(f)):
-        dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-print("kernel durations (rocprofv3 --kernel-trace, ms): name  launches  mean  min  max")
+    dur = by_kernel(list(csv.DictReader(open(f))),
+                    lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+print("kernel durations, rocprofv3 --kernel-trace (ms per launch, in launch order)")
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
-    print("  %-60s %3d  %.3f  %.3f  %.3f" % (k[:60], len(v), sum(v) / len(v), min(v), max(v)))
-cnt = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(base, "pmc*", "**", "*counter_collection.csv"), recursive=True):
-    per = collections.defaultdict(float)
-    for r in csv.DictReader(open(f)):
-        per[(r["Kernel_Name"], r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
-    for (k, d, c), v in per.items():
-        cnt[k][c].append(v)
-for k in sorted(cnt, key=lambda k: -sum(dur.get(k, [0]))):
-    print("\ncounters per launch (mean over launches): %s" % k[:80])
-    for c in sorted(cnt[k]):
-        v = cnt[k][c]
-        print("  %-26s %.6g   (%d launches)" % (c, sum(v) / len(v), len(v)))
+    if not k.startswith(("void mt::", "mt::")):
+        continue
+    print("  %s" % k[:70])
+    print("     all launches: %s" % " ".join("%.3f" % x for x in v))
+    if "render_kernel" in k and len(v) >= 6:
+        t = v[TIMED]
+        print("     timed launches (3..6): mean %.3f  min %.3f  max %.3f" % (sum(t) / len(t), min(t), max(t)))
+cnt = collections.defaultdict(dict)
+for f in sorted(glob.glob(os.path.join(base, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+    rows = list(csv.DictReader(open(f)))
+    for c in sorted(set(r["Counter_Name"] for r in rows)):
+        per = by_kernel([r for r in rows if r["Counter_Name"] == c], lambda r: float(r["Counter_Value"]))
+        for k, v in per.items():
+            cnt[k][c] = v
+for k in cnt:
+    if "render_kernel" not in k:
+        continue
+    print("\ncounters of %s, mean over the timed launches (3..6)" % k[:60])
+    m = {}
+    for c, v in sorted(cnt[k].items()):
+        t = v[TIMED] if len(v) >= 6 else v
+        m[c] = sum(t) / len(t)
+        print("  %-26s %.6g" % (c, m[c]))
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        # MI355X_MICROARCH.md, HBM / rocprofv3 section: FETCH_SIZE and WRITE_SIZE are in
+        # KiB; on gfx950 FETCH_SIZE counts 64-B requests as 32 B (x2)
+        rd, wr = m["FETCH_SIZE"] * 1024 * 2, m["WRITE_SIZE"] * 1024
+        print("  memory-side traffic per launch: read %.1f MB  write %.1f MB  total %.1f MB" % (rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
+        print("  HBM_TRAFFIC_BYTES %d" % int(rd + wr))
+    if "TCC_HIT_sum" in m:
+        print("  L2 hit rate %.4f" % (m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])))
+    if "SQ_WAVE_CYCLES" in m:
+        print("  share of wave time: VALU busy %.3f  waiting on s_waitcnt %.3f  issue-stalled %.3f" % (
+            m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"], m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
+            m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]))
