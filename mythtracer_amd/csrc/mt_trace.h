@@ -436,6 +436,44 @@ __device__ __forceinline__ float f32_not_below(double c) {
   return f;
 }
 
+// ---- rays with ONE zero direction component --------------------------------
+// 1/d = +-inf on exactly one axis a, the other two reciprocals finite and
+// non-zero, finite origin.  For a box whose a-range does not contain o[a] even
+// after widening it by one fp32 ulp (the fp32 copies are rounded to nearest),
+// the reference's slab test (aabb.cc, via primitive_triangle.cc:73-76) gives
+// t1 = t2 = +inf or t1 = t2 = -inf on that axis, no NaN; with finite far
+// distances on the other two axes that is tmin = +inf > tmax, or tmax = -inf
+// < 0: a miss.  The same holds for every box inside such a box, so union boxes
+// (blocks, subtrees) may be skipped for these rays too.  Nothing is concluded
+// when o[a] lies inside the range: a member box whose min plane equals o[a]
+// passes through NaN whatever the other axes say.  (All magnitudes involved
+// are bounded by 2^400, so the finite products stay finite.)
+__device__ __forceinline__ int degenerate_axis(double ox, double oy, double oz, double ix, double iy,
+                                               double iz) {
+  // magnitudes bounded so that (plane - o) * (1/d) cannot overflow on the two
+  // regular axes (the caller checks the scene's coordinates against 2^400 too)
+  const bool fo = __builtin_fabs(ox) <= 0x1p400 && __builtin_fabs(oy) <= 0x1p400 && __builtin_fabs(oz) <= 0x1p400;
+  const bool rx = __builtin_fabs(ix) <= 0x1p400 && ix != 0.0, ry = __builtin_fabs(iy) <= 0x1p400 && iy != 0.0,
+             rz = __builtin_fabs(iz) <= 0x1p400 && iz != 0.0;
+  if (!fo) return -1;
+  if (__builtin_isinf(ix) && ry && rz) return 0;
+  if (__builtin_isinf(iy) && rx && rz) return 1;
+  if (__builtin_isinf(iz) && rx && ry) return 2;
+  return -1;
+}
+__device__ __forceinline__ bool outside_on_axis(const float *b, int axis, double o) {
+  return o < (double)f32_pred(b[axis]) || o > (double)f32_succ(b[3 + axis]);
+}
+// subtree boxes of the eight children -> keep mask for such a ray
+__device__ __forceinline__ unsigned degenerate_keep_mask(const float *sub, int axis, double o) {
+  unsigned keep = 0u;
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    if (!outside_on_axis(sub + c * 6, axis, o)) keep |= 1u << c;
+  }
+  return keep;
+}
+
 // Returns false when the filter must not be used for this ray.
 __device__ __forceinline__ bool make_filter32(const DevScene &S, const RayRegs &r, Filter32 &f) {
   const double o[3] = {r.ox, r.oy, r.oz}, iv[3] = {r.ix, r.iy, r.iz};
@@ -674,7 +712,7 @@ __device__ __forceinline__ void scan_node_transposed(const DevScene &S, const Ra
 // constants), then the triangles of the blocks that may be hit, four blocks
 // (64 triangles) per step, exactly as above: exact fp64 box test, Möller–
 // Trumbore, hits folded in ascending stream order.
-template <bool STATS>
+template <bool EX, bool STATS>
 __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, const RayRegs &r,
                                                             const Filter32 &f, int lane,
                                                             unsigned long long inmask, int pb, int pc,
@@ -696,6 +734,8 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
     const int nx = __builtin_signbit(u.ix) ? 3 : 0, ny = __builtin_signbit(u.iy) ? 4 : 1,
               nz = __builtin_signbit(u.iz) ? 5 : 2;
     const int fx = 3 - nx, fy = 5 - ny, fz = 7 - nz;
+    const int deg_axis = EX ? degenerate_axis(u.ox, u.oy, u.oz, u.ix, u.iy, u.iz) : -1;
+    const double deg_o = deg_axis == 0 ? u.ox : (deg_axis == 1 ? u.oy : u.oz);
     int ubest = -1;
     double ubest_t = 0.0;
     unsigned mt_count = 0;
@@ -707,8 +747,11 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
       const float tnz = __builtin_fmaf(bp[nz], fiz, cnz), tfz = __builtin_fmaf(bp[fz], fiz, cfz);
       const float lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
       const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
-      // "may pass" unless provably not (NaN compares as may pass, like filter32_pass)
-      unsigned long long live = __builtin_amdgcn_ballot_w64(!(hi < 0.0f) && !(lo > hi) && g < nb);
+      // "may pass" unless provably not (NaN compares as may pass, like filter32_pass);
+      // EX: an irregular ray -- only the one-zero-component test above applies
+      bool may = !(hi < 0.0f) && !(lo > hi);
+      if (EX) may = !(deg_axis >= 0 && outside_on_axis(bp, deg_axis, deg_o));
+      unsigned long long live = __builtin_amdgcn_ballot_w64(may && g < nb);
       while (live != 0ull) {
         int q0 = -1, q1 = -1, q2 = -1, q3 = -1;  // next four blocks to look into
         q0 = g0 + __builtin_ctzll(live); live &= live - 1;
@@ -722,7 +765,7 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
         const int tri_c = ok ? tri : pb;
         const double *bx = S.tri_aabb + (size_t)tri_c * 6;
         const double b[6] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]};
-        const unsigned long long pm = slab_pass<1, 0>(b, u) & __builtin_amdgcn_ballot_w64(ok);
+        const unsigned long long pm = slab_pass<EX ? 0 : 1, 0>(b, u) & __builtin_amdgcn_ballot_w64(ok);
         if (pm == 0ull) continue;
         if (STATS) mt_count += (unsigned)__builtin_popcountll(pm);
         const bool mine = ((pm >> lane) & 1ull) != 0;
@@ -872,6 +915,21 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
     for (int j = 0; j < 8; j++) ord |= (si[j] & 7u) << (3 * j);
     cnt = m;
     // entries >= m are zero-filled garbage; they are never read (pos < cnt)
+    if (keep != 0xffu) {
+      // With NaN keys the insertion sort's outcome depends on every element
+      // that takes part, so skipped children are taken out AFTER the sort.
+      unsigned o2 = 0, c2 = 0;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {
+        const unsigned c = (ord >> (3 * j)) & 7u;
+        if ((unsigned)j < cnt && ((keep >> c) & 1u) != 0u) {
+          o2 |= c << (3 * c2);
+          c2++;
+        }
+      }
+      ord = o2;
+      cnt = c2;
+    }
   }
   return (ord & 0x00ffffffu) | (cnt << 24);
 }
@@ -954,6 +1012,18 @@ __device__ __forceinline__ unsigned tight_keep_mask(const float *sub, const Filt
   return keep;
 }
 
+// Regular-mode ordering, inlined into the traversal (small: ~35 VGPRs); the
+// exact-mode variant below stays a function of its own.
+__device__ __forceinline__ unsigned order_children_regular(const NodeRec *N, const RayRegs &r, const float *sub,
+                                                           const Filter32 &f, bool uniform_node) {
+  unsigned keep = 0xffu;
+  if (sub != nullptr) {
+    keep = tight_keep_mask(uniform_node ? uniform_ptr(sub) : sub, f, __builtin_signbit(r.ix),
+                           __builtin_signbit(r.iy), __builtin_signbit(r.iz));
+  }
+  return order_children<1>(as_const(uniform_node ? uniform_ptr(N) : N), r, keep);
+}
+
 // order_children for a per-lane node (no uniformisation of the pointer).
 // sub = the eight subtree boxes of the node's children, or nullptr (no culling).
 template <int MODE>
@@ -969,6 +1039,10 @@ __device__ __attribute__((noinline)) unsigned order_children_lane_call(const Nod
   if (MODE != 0 && sub != nullptr) {
     MT_F32_FROM_PARAMS(f);
     keep = tight_keep_mask(sub, f, __builtin_signbit(ix), __builtin_signbit(iy), __builtin_signbit(iz));
+  }
+  if (MODE == 0 && sub != nullptr) {
+    const int axis = degenerate_axis(ox, oy, oz, ix, iy, iz);
+    if (axis >= 0) keep = degenerate_keep_mask(sub, axis, axis == 0 ? ox : (axis == 1 ? oy : oz));
   }
   return order_children<MODE>(as_const(N), r, keep);
 }
@@ -989,6 +1063,10 @@ __device__ __attribute__((noinline)) unsigned order_children_call(const NodeRec 
     MT_F32_FROM_PARAMS(f);
     keep = tight_keep_mask(uniform_ptr(sub), f, __builtin_signbit(ix), __builtin_signbit(iy),
                            __builtin_signbit(iz));
+  }
+  if (MODE == 0 && sub != nullptr) {
+    const int axis = degenerate_axis(ox, oy, oz, ix, iy, iz);
+    if (axis >= 0) keep = degenerate_keep_mask(uniform_ptr(sub), axis, axis == 0 ? ox : (axis == 1 ? oy : oz));
   }
   return order_children<MODE>(as_const(uniform_ptr(N)), r, keep);
 }
@@ -1115,7 +1193,7 @@ __device__ __attribute__((noinline)) ScanOut scan_transposed_call(const double *
   return o;
 }
 
-template <bool STATS>
+template <bool EX, bool STATS>
 __device__ __attribute__((noinline)) ScanOut scan_transposed_blocks_call(const DevScene *self, int pb, int pc,
                                                                          bool in, MT_RAY_PARAMS, MT_F32_PARAMS) {
   MT_RAY_FROM_PARAMS(r);
@@ -1126,7 +1204,7 @@ __device__ __attribute__((noinline)) ScanOut scan_transposed_blocks_call(const D
   LaneStats st;
   st.clear();
   ScanOut o{-1, 0.0, 0u};
-  scan_node_transposed_blocks<STATS>(S, r, f, lane, inmask, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
+  scan_node_transposed_blocks<EX, STATS>(S, r, f, lane, inmask, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
   o.mt_tests = st.v[ST_MT_TESTS];
   return o;
 }
@@ -1259,6 +1337,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   // filter and in mode 7, where the counters then match the reference's
   // un-pruned traversal exactly.
   const bool cull = use_filter && (S.force_mode != 7);
+  // The same two kinds of boxes for irregular rays with one zero direction
+  // component (degenerate_axis): automatic mode only.
+  const bool irr_boxes = !all_regular && (S.scene_regular != 0) && (S.force_mode == 0) &&
+                         S.bmax[0] <= 0x1p400 && S.bmax[1] <= 0x1p400 && S.bmax[2] <= 0x1p400;
 
   const MT_CONST NodeRec *nodes = as_const(S.nodes);
   int cur = -1;
@@ -1372,8 +1454,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           const NodeRec *Np = S.nodes + cur;
           const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
-          ordw = all_regular ? order_children_lane_call<1>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, sub, MT_F32_ARGS(f32))
-                             : order_children_lane_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, nullptr, MT_F32_ARGS(f32));
+          ordw = all_regular ? order_children_regular(Np, r, sub, f32, false)
+                             : order_children_lane_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                           irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr,
+                                                           MT_F32_ARGS(f32));
         }
         finish_node(fc, ordw, o.best, o.best_t);
       }
@@ -1426,10 +1510,12 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // ray-parallel ~14 per block + 200, transposed ~160 + 40 per 64 blocks per ray.
     const bool blocks_ok = all_regular && use_filter && pc >= kBigNode && S.force_mode != 6;
     const int nblk = (pb + pc - 1) / kGroupTris - pb / kGroupTris + 1;
+    const bool blocks_irr = irr_boxes && pc >= kBigNode && n_in <= 16;
     const bool transposed =
         (S.force_mode != 3) && pc > 0 &&
-        (blocks_ok ? (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk)
-                   : (n_in * (30 + 45 * chunks) < 20 * pc));
+        (blocks_irr ? true
+         : blocks_ok ? (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk)
+                     : (n_in * (30 + 45 * chunks) < 20 * pc));
     int best = -1;
     double best_t = 0.0;
     MT_PROF_BEGIN(prof_t1);
@@ -1438,7 +1524,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       MT_PROF_COUNT(PROF_N_CHUNKS, n_in * chunks);
       if (STATS) st.wave_tri_steps += (unsigned)(n_in * chunks) - (unsigned)pc;  // replaces the pc counted above
       const ScanOut o = blocks_ok
-          ? scan_transposed_blocks_call<STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
+          ? scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
+          : blocks_irr
+          ? scan_transposed_blocks_call<true, STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
           : (mode == 0)
           ? scan_transposed_call<true, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), MT_RAY_ARGS(r))
           : scan_transposed_call<false, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), MT_RAY_ARGS(r));
@@ -1505,8 +1593,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         const NodeRec *Np = S.nodes + n;
         const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
-        ordw = (mode == 0) ? order_children_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, nullptr, MT_F32_ARGS(f32))
-                           : order_children_call<1>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz, sub, MT_F32_ARGS(f32));
+        ordw = (mode == 0) ? order_children_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                    irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr,
+                                                    MT_F32_ARGS(f32))
+                           : order_children_regular(Np, r, sub, f32, true);
       }
       finish_node(fc, ordw, best, best_t);
     }
