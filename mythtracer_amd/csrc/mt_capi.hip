@@ -512,6 +512,14 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
         }
       }
       for (int k = 0; k < 6; k++) subs[(size_t)i * 6 + k] = (float)u[k];
+      if (r.first_child != 0) {
+        int mask = 0;
+        for (int c = 0; c < 8; c++) {
+          const double *b = &sb[(size_t)(r.first_child + c) * 6];
+          if (b[0] <= b[3]) mask |= 1 << c;  // an empty subtree keeps the inverted box
+        }
+        recs[i].child_mask = mask;
+      }
     }
   }
   groups.resize(groups.size() + 8 * 6, 0.0f);  // the scan looks four boxes ahead
@@ -650,7 +658,7 @@ int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
                                             "children_unwind_cycles", "n_raypar_scans", "n_transposed_scans",
                                             "n_transposed_chunks", "n_raypar_tris", "n_traces", "lane_phase_cycles",
                                             "scan_m2f", "scan_m2", "scan_m1", "scan_m0", "n_m2f", "n_m2", "n_m1", "n_m0",
-                                            "tris_m2f", "tris_m1", "tris_transposed", "g_groups", "g_live", "g_ranges", "g_range_tris"};
+                                            "tris_m2f", "tris_m1", "tris_transposed", "g_groups", "g_live", "g_ranges", "g_range_tris", "nin_sum", "nin_lt8", "nin_lt24", "want_sum"};
     fprintf(stderr, "[mt prof]");
     for (int i = 0; i < PROF_COUNT; i++) fprintf(stderr, " %s=%llu", names[i], pr[i]);
     fprintf(stderr, "\n");

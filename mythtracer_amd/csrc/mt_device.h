@@ -19,7 +19,7 @@ struct NodeRec {
   int32_t first_child;  // 0 = leaf
   int32_t prim_begin;
   int32_t prim_count;
-  int32_t pad0;
+  int32_t child_mask;   // bit c: child c's subtree holds at least one triangle
   double pad1;
 };
 static_assert(sizeof(NodeRec) == 96, "NodeRec must be 96 bytes");
@@ -74,7 +74,8 @@ enum { PROF_TRACE = 0, PROF_SCAN_RAYPAR, PROF_SCAN_TRANSPOSED, PROF_CHILDREN_UNW
        PROF_N_TRANSPOSED, PROF_N_CHUNKS, PROF_N_RAYPAR_TRIS, PROF_N_TRACES, PROF_SHADE,
        PROF_SCAN_M2F, PROF_SCAN_M2, PROF_SCAN_M1, PROF_SCAN_M0, PROF_N_M2F, PROF_N_M2, PROF_N_M1, PROF_N_M0,
        PROF_TRIS_M2F, PROF_TRIS_M1, PROF_TRIS_TRANSPOSED,
-       PROF_G_GROUPS, PROF_G_LIVE, PROF_G_RANGES, PROF_G_RANGE_TRIS, PROF_COUNT };
+       PROF_G_GROUPS, PROF_G_LIVE, PROF_G_RANGES, PROF_G_RANGE_TRIS,
+       PROF_NIN_SUM, PROF_NIN_LT8, PROF_NIN_LT24, PROF_WANT_SUM, PROF_COUNT };
 
 enum {
   ST_RAYS_PRIMARY = 0,

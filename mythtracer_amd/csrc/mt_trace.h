@@ -816,8 +816,11 @@ __device__ __forceinline__ void scan_node_octant(const DevScene &S, const RayReg
 // The sort is stable and a child without a hit only makes the parent's loop
 // move on (octtree.cc:222-251), so leaving it out changes nothing.
 template <int MODE>
+// um (wave-uniform): children outside it are not looked at at all (regular
+// mode only; the caller passes the union of the lanes' non-empty children when
+// subtree skipping is on, so these are children `keep` would drop anyway).
 __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, const RayRegs &r,
-                                                   unsigned keep = 0xffu) {
+                                                   unsigned keep = 0xffu, unsigned um = 0xffu) {
   constexpr bool EX = (MODE == 0);
   double xmin[2], xmax[2], ymin[2], ymax[2], zmin[2], zmax[2];
   {
@@ -996,10 +999,11 @@ __device__ __attribute__((noinline)) ScanOut scan_small_lane_call(const double *
 // argument as for the block boxes) fails the reference's AABB pre-filter for
 // every triangle down there, so visiting that child could only return "no hit".
 __device__ __forceinline__ unsigned tight_keep_mask(const float *sub, const Filter32 &f, bool sx,
-                                                    bool sy, bool sz) {
+                                                    bool sy, bool sz, unsigned um = 0xffu) {
   unsigned keep = 0u;
 #pragma unroll
   for (int c = 0; c < 8; c++) {
+    if (((um >> c) & 1u) == 0u) continue;  // wave-uniform skip (empty subtree for every lane)
     const float *b = sub + c * 6;
     const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
     const float tnx = __builtin_fmaf(sx ? b3 : b0, f.ix, f.cnx), tfx = __builtin_fmaf(sx ? b0 : b3, f.ix, f.cfx);
@@ -1016,12 +1020,24 @@ __device__ __forceinline__ unsigned tight_keep_mask(const float *sub, const Filt
 // exact-mode variant below stays a function of its own.
 __device__ __forceinline__ unsigned order_children_regular(const NodeRec *N, const RayRegs &r, const float *sub,
                                                            const Filter32 &f, bool uniform_node) {
-  unsigned keep = 0xffu;
+  unsigned keep = 0xffu, um = 0xffu;
   if (sub != nullptr) {
+    // children with an empty subtree (NodeRec::child_mask) are dropped by the
+    // subtree test anyway: leave them out of all the arithmetic, wave-wide
+    if (uniform_node) {
+      um = (unsigned)as_const(uniform_ptr(N))->child_mask & 0xffu;
+    } else {
+      const unsigned m = (unsigned)N->child_mask;
+      um = 0u;
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        if (__ballot(((m >> c) & 1u) != 0u) != 0ull) um |= 1u << c;
+      }
+    }
     keep = tight_keep_mask(uniform_node ? uniform_ptr(sub) : sub, f, __builtin_signbit(r.ix),
-                           __builtin_signbit(r.iy), __builtin_signbit(r.iz));
+                           __builtin_signbit(r.iy), __builtin_signbit(r.iz), um);
   }
-  return order_children<1>(as_const(uniform_node ? uniform_ptr(N) : N), r, keep);
+  return order_children<1>(as_const(uniform_node ? uniform_ptr(N) : N), r, keep, um);
 }
 
 // order_children for a per-lane node (no uniformisation of the pointer).
@@ -1505,6 +1521,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // instruction counts: a ray-parallel step ~20, a transposed chunk ~45 plus
     // ~30 to broadcast each ray).
     const int n_in = __builtin_popcountll(inmask);
+    MT_PROF_COUNT(PROF_NIN_SUM, n_in);
+    MT_PROF_COUNT(PROF_NIN_LT8, n_in < 8 ? 1 : 0);
+    MT_PROF_COUNT(PROF_NIN_LT24, n_in < 24 ? 1 : 0);
+    MT_PROF_COUNT(PROF_WANT_SUM, __builtin_popcountll(__ballot(cur >= 0)));
     const int chunks = (pc + 63) >> 6;
     // With block boxes (regular rays, big node) both forms get much cheaper:
     // ray-parallel ~14 per block + 200, transposed ~160 + 40 per 64 blocks per ray.
