@@ -239,8 +239,10 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   }
   HIP_TRY(hipEventRecord(ek[0], stream));
   if (history) {
+    float quad_share = 0.8f;  // blocks above this share of an even split are cut into quarters
+    if (const char *e = getenv("MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
     hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
-                       s->grid_blocks * s->waves_per_block);
+                       s->grid_blocks * s->waves_per_block, quad_share);
   } else if (s->stats_enabled) {
     hipLaunchKernelGGL(primary_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
   } else {

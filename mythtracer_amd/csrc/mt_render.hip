@@ -204,10 +204,12 @@ __global__ __launch_bounds__(256, 3) void primary_kernel(DevScene S, RenderParam
 // item, and the per-pixel ray chains cannot be split, so:
 //   * blocks are handed out longest first (bucket sort on log2 of the cost,
 //     eight buckets per octave);
-//   * blocks that took longer than kQuadShare of an even share of the frame's
-//     work are cut into four quarters with FOUR lanes per pixel (the shadow
-//     loops of a pixel's lights run side by side: a shorter chain for about
-//     1.7x the work, which is why only the few longest blocks get it).
+//   * blocks that took longer than quad_share (0.8) of an even share of the
+//     frame's work are cut into four quarters with FOUR lanes per pixel (the
+//     shadow loops of a pixel's lights run side by side: a shorter chain for
+//     about 1.7x the work, which is why only the few longest blocks get it;
+//     measured on the 1080p room frame: 0.25 -> 13.3 ms, 0.45 -> 11.7, 0.6 ->
+//     10.8, 0.8 -> 10.0, 0.9 -> 10.8, 1.0 -> 12.0, never -> 25.0).
 // The order changes nothing about what is computed for a pixel.  Costs are in
 // units of 64 s_memtime ticks; a block rendered as quarters reports their sum,
 // which is scaled back (kQuadWork) before it is compared again.
@@ -219,7 +221,7 @@ __device__ __forceinline__ int cost_bucket(unsigned c) {  // descending cost = a
   const int f = e >= 3 ? (int)((c >> (e - 3)) & 7u) : 0;      // eighth within it
   return kSchedBuckets - 1 - (e * 8 + f);
 }
-__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves) {
+__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves, float quad_share) {
   __shared__ unsigned long long s_sum;
   __shared__ unsigned s_count[kSchedBuckets];
   __shared__ unsigned s_start[kSchedBuckets];
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
   for (int b = tid; b < kSchedBuckets; b += kSchedThreads) s_count[b] = 0u;
   __syncthreads();
   // costs measured in quad mode are sums over four quarters
-  const float kQuadWork = 1.7f, kQuadShare = 0.45f, kQuarterTime = 0.45f;
+  const float kQuadWork = 1.7f, kQuadShare = quad_share, kQuarterTime = 0.45f;
   unsigned long long part = 0ull;
   for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
     unsigned c = P.item_cost[i];
