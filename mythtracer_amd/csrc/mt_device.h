@@ -25,12 +25,13 @@ struct NodeRec {
 static_assert(sizeof(NodeRec) == 96, "NodeRec must be 96 bytes");
 
 // Nodes with at least kBigNode triangles are scanned wave-uniformly, smaller
-// ones lane-parallel (mt_trace.h).  The triangle stream carries one fp32 box
+// ones lane-parallel (mt_trace.h).  Swept on the 1080p room frame: 8 -> 11.6 ms,
+// 16 -> 10.2, 32 -> 9.75, 48 -> 10.0, 64 -> 10.5.  The triangle stream carries one fp32 box
 // per block of kGroupTris consecutive triangles (block b = stream positions
 // [16 b, 16 b + 16), whatever nodes they belong to): a ray that provably
 // misses the block box fails the reference's per-triangle AABB pre-filter
 // (primitive_triangle.cc:73-76) for every member, so the block is skipped.
-constexpr int kBigNode = 16;
+constexpr int kBigNode = 32;
 constexpr int kGroupTris = 16;
 
 struct DevTexture {
