@@ -712,6 +712,7 @@ __device__ __forceinline__ void scan_node_transposed(const DevScene &S, const Ra
 // constants), then the triangles of the blocks that may be hit, four blocks
 // (64 triangles) per step, exactly as above: exact fp64 box test, Möller–
 // Trumbore, hits folded in ascending stream order.
+static_assert(64 % kGroupTris == 0, "a wave must hold whole blocks");
 template <bool EX, bool STATS>
 __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, const RayRegs &r,
                                                             const Filter32 &f, int lane,
@@ -753,14 +754,19 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
       if (EX) may = !(deg_axis >= 0 && outside_on_axis(bp, deg_axis, deg_o));
       unsigned long long live = __builtin_amdgcn_ballot_w64(may && g < nb);
       while (live != 0ull) {
-        int q0 = -1, q1 = -1, q2 = -1, q3 = -1;  // next four blocks to look into
-        q0 = g0 + __builtin_ctzll(live); live &= live - 1;
-        if (live != 0ull) { q1 = g0 + __builtin_ctzll(live); live &= live - 1; }
-        if (live != 0ull) { q2 = g0 + __builtin_ctzll(live); live &= live - 1; }
-        if (live != 0ull) { q3 = g0 + __builtin_ctzll(live); live &= live - 1; }
-        const int quarter = lane >> 4;
-        const int myq = quarter == 0 ? q0 : (quarter == 1 ? q1 : (quarter == 2 ? q2 : q3));
-        const int tri = (b0 + myq) * kGroupTris + (lane & 15);  // stream position
+        // the next 64 / kGroupTris live blocks, one per slice of the wave
+        constexpr int kSlices = 64 / kGroupTris;
+        const int slice = lane / kGroupTris;
+        int myq = -1;
+#pragma unroll
+        for (int q = 0; q < kSlices; q++) {
+          if (live != 0ull) {
+            const int blk = g0 + __builtin_ctzll(live);
+            live &= live - 1;
+            if (slice == q) myq = blk;
+          }
+        }
+        const int tri = (b0 + myq) * kGroupTris + (lane % kGroupTris);  // stream position
         const bool ok = myq >= 0 && tri >= pb && tri < pb + pc;
         const int tri_c = ok ? tri : pb;
         const double *bx = S.tri_aabb + (size_t)tri_c * 6;
