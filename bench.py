@@ -256,6 +256,10 @@ def main():
                             "subtrees by 24-byte union boxes, so it is latency/VALU bound, not HBM bound "
                             "(DESIGN.md section 5); traffic = memory-side bytes per launch from the "
                             "rocprofv3 PMC passes under profiles/",
+                    # both normalisations -- the bytes of the nodes this kernel
+                    # actually visits (subtrees it can rule out are not counted) ...
+                    "achieved_own_counters": (48 * evaluated["box_tests"] + 48 * evaluated["tri_tests"]
+                                              + 72 * evaluated["mt_tests"]) / (k_step_ms * 1e-3) / 1e9,
                     "frame_work_visited_by_the_kernels": evaluated,
                     "frame_work_of_the_reference": reference_evaluates}
         out = {
