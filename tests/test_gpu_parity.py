@@ -411,6 +411,43 @@ def test_big_frames_identical_to_reference(scenes):
                          "sub-sampled comparison above passed")
 
 
+def test_4k_frame_contains_the_reference_1080p_frame(scenes):
+    """BASELINE configs[4] size (3840x2160, 8 ranks).  Size-independent property:
+    Sensor::GetRay (camera.cc:58-69) divides the same corner vectors by W and H,
+    so the ray of 4K pixel (2x, 2y) is bit-for-bit the ray of 1080p pixel (x, y)
+    (halving and doubling are exact) -- the even pixels of the 4K frame must be
+    the reference's 1080p frame.  Rendered as 8 interleaved tile sets and
+    blitted, as bench.py --gpus 8 does, and as one launch."""
+    import hashlib
+    import torch
+    frames = json.load(open(os.path.join(GOLDEN, "frames.json")))
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["room"])
+    m.set_lights(scenegen.ROOM_LIGHTS)
+    h = m.device_scene()
+    abi.set_lights(h, scenegen.ROOM_LIGHTS)
+    W, H, T, world = 3840, 2160, 64, 8
+    sens = binding.sensor(scenegen.ROOM_CAMERA, W, H)
+    frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    for rank in range(world):
+        f, s, n = tiling.rank_tiles(W, H, T, T, rank, world)
+        slots = torch.zeros(n * tiling.slot_bytes(T, T), dtype=torch.uint8, device="cuda")
+        abi.render_tiles_device(h, sens, W, H, T, T, f, s, n, 5, ctypes.c_void_p(slots.data_ptr()))
+        abi.blit_tiles_device(h, W, H, T, T, f, s, n, ctypes.c_void_p(slots.data_ptr()),
+                              ctypes.c_void_p(frame.data_ptr()))
+    torch.cuda.synchronize()
+    tiled = frame.cpu().numpy()
+    single = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    for _ in range(2):  # the second launch is scheduled from the first one's block costs
+        abi.render_chunk_device(h, sens, W, H, (0, 0, W, H), 5, ctypes.c_void_p(single.data_ptr()), None, None)
+    torch.cuda.synchronize()
+    st = abi.read_stats(h)
+    assert np.array_equal(tiled, single.cpu().numpy())
+    assert st["rays_primary"] == 2 * W * H + W * H  # two launches + the eight tile sets
+    sha = hashlib.sha256(np.ascontiguousarray(tiled[::2, ::2]).tobytes()).hexdigest()
+    assert sha == frames["room_1920x1080_d5"]["sha256"]
+
+
 def test_tiles_and_blit_equal_single_launch(scenes):
     """mt_render_tiles_device + mt_blit_tiles_device: three virtual ranks on one
     GPU reproduce the single-launch frame byte for byte (the multi-GPU path
