@@ -660,7 +660,8 @@ int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
                                             "children_unwind_cycles", "n_raypar_scans", "n_transposed_scans",
                                             "n_transposed_chunks", "n_raypar_tris", "n_traces", "lane_phase_cycles",
                                             "scan_m2f", "scan_m2", "scan_m1", "scan_m0", "n_m2f", "n_m2", "n_m1", "n_m0",
-                                            "tris_m2f", "tris_m1", "tris_transposed", "g_groups", "g_live", "g_ranges", "g_range_tris", "nin_sum", "nin_lt8", "nin_lt24", "want_sum"};
+                                            "tris_m2f", "tris_m1", "tris_transposed", "g_groups", "g_live", "g_ranges", "g_range_tris", "nin_sum", "nin_lt8", "nin_lt24", "want_sum",
+                                            "grp_mask_t", "grp_ranges_t", "tr_blocks_t", "tr_tris_t", "tr_bcast_t", "tr_rays", "m2f_call_t"};
     fprintf(stderr, "[mt prof]");
     for (int i = 0; i < PROF_COUNT; i++) fprintf(stderr, " %s=%llu", names[i], pr[i]);
     fprintf(stderr, "\n");

@@ -76,7 +76,8 @@ enum { PROF_TRACE = 0, PROF_SCAN_RAYPAR, PROF_SCAN_TRANSPOSED, PROF_CHILDREN_UNW
        PROF_SCAN_M2F, PROF_SCAN_M2, PROF_SCAN_M1, PROF_SCAN_M0, PROF_N_M2F, PROF_N_M2, PROF_N_M1, PROF_N_M0,
        PROF_TRIS_M2F, PROF_TRIS_M1, PROF_TRIS_TRANSPOSED,
        PROF_G_GROUPS, PROF_G_LIVE, PROF_G_RANGES, PROF_G_RANGE_TRIS,
-       PROF_NIN_SUM, PROF_NIN_LT8, PROF_NIN_LT24, PROF_WANT_SUM, PROF_COUNT };
+       PROF_NIN_SUM, PROF_NIN_LT8, PROF_NIN_LT24, PROF_WANT_SUM,
+       PROF_TA_G, PROF_TB_G, PROF_TA_T, PROF_TB_T, PROF_TC_T, PROF_T_RAYS, PROF_M2F_CALL, PROF_COUNT };
 
 enum {
   ST_RAYS_PRIMARY = 0,

@@ -1,16 +1,19 @@
-// mt_render.hip — the per-pixel megakernel and the ray-batch kernel.
+// mt_render.hip — the frame kernels (primary / schedule / render), the ray-batch
+// kernel and the tile blit.
 //
 // Replaces the pixel loop of MythTracer::RayTrace(WorkChunk*)
 // (mythtracer.cc:292-305): Sensor::GetRay (camera.cc:65-69), TraceRayWorker
 // (mythtracer.cc:13-228) and V3DtoRGB (:235-241).
 //
 // Execution model: persistent waves.  Every wave owns a slice of the block's
-// LDS (its traversal stack) and pulls 8x8-pixel work items from one global
-// counter until none are left; waves never synchronise with each other.  One
-// lane renders one pixel.  The reference's recursion (reflection, refraction)
-// and its shadow loop are run as a per-lane state machine with ONE call site
-// of the wave-synchronous traversal (mt_trace.h), so that whatever kind of ray
-// each lane needs next, all 64 lanes traverse together.
+// LDS (its traversal stack) and pulls work units (8x8-pixel blocks, or quarters
+// of the longest ones) from one global counter until none are left; waves never
+// synchronise with each other.  One lane renders one pixel -- or, in a quarter,
+// four lanes render one pixel, each running the shadow loop of one light.  The
+// reference's recursion (reflection, refraction) and its shadow loop are run as
+// a per-lane state machine with ONE call site of the wave-synchronous traversal
+// (mt_trace.h), so that whatever kind of ray each lane needs next, all 64 lanes
+// traverse together.
 #include "mt_shade.h"
 
 namespace mt {
@@ -287,13 +290,16 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
 }
 
 // ---------------------------------------------------------------------------
-// Launch 2: everything of TraceRayWorker after the primary hit (shading,
-// shadow loops, reflection/refraction recursion) and the pixel store.  Work
-// order: class-2 blocks first, then class 1, then class 0: the frame cannot
-// finish before its slowest work item and the long per-pixel ray chains cannot
-// be split, so the expensive blocks start first and run at raised priority.
-// (Cutting them into 4x4-pixel quarters was tried and rejected: a pass over 16
-// lanes costs about 80 % of a pass over 64, total work +80 %.)
+// The frame kernel: TraceRayWorker for every pixel of the launch's tiles and
+// the pixel store.  With cost history (P.from_primary == 0) it traces the
+// primary rays itself and takes its work units in schedule_kernel's order;
+// without, it continues from primary_kernel's hits: reflective blocks first,
+// then the transparent ones as quarters, then the rest.  Either way the
+// expensive units start first and run at raised wave priority: the frame cannot
+// finish before its slowest unit and a pixel's ray chain cannot be split.
+// (Plain 4x4 quarters with one lane per pixel do not help -- a pass over 16 lanes
+// costs about 80 % of a pass over 64; quarters pay off only with four lanes per
+// pixel, i.e. with the pixel's shadow loops running side by side.)
 template <bool STATS>
 __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -161,6 +161,7 @@ struct ScanOut {
   unsigned mt_tests;  // Möller–Trumbore evaluations performed for this lane
 #ifdef MT_PROF
   unsigned n_groups = 0, n_live = 0, n_ranges = 0, n_range_tris = 0;
+  unsigned t_a = 0, t_b = 0, t_c = 0;  // section times (s_memtime ticks)
 #endif
 };
 
@@ -717,13 +718,18 @@ template <bool EX, bool STATS>
 __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, const RayRegs &r,
                                                             const Filter32 &f, int lane,
                                                             unsigned long long inmask, int pb, int pc,
-                                                            int &best, double &best_t, LaneStats &st) {
+                                                            int &best, double &best_t, LaneStats &st,
+                                                            unsigned *tp = nullptr) {
   const int b0 = pb / kGroupTris, nb = (pb + pc - 1) / kGroupTris - b0 + 1;
   const float *blk = S.grp_aabb32 + (size_t)b0 * 6;
   unsigned long long todo = inmask;
   while (todo != 0ull) {
     const int L = __builtin_ctzll(todo);
     todo &= todo - 1;
+#ifdef MT_PROF
+    const unsigned long long tt0 = __builtin_amdgcn_s_memtime();
+    unsigned long long tt_tri = 0;
+#endif
     RayRegs u;  // lane L's ray, wave-uniform
     u.ox = readlane_f64(r.ox, L); u.oy = readlane_f64(r.oy, L); u.oz = readlane_f64(r.oz, L);
     u.dx = readlane_f64(r.dx, L); u.dy = readlane_f64(r.dy, L); u.dz = readlane_f64(r.dz, L);
@@ -740,6 +746,9 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
     int ubest = -1;
     double ubest_t = 0.0;
     unsigned mt_count = 0;
+#ifdef MT_PROF
+    const unsigned long long tt1 = __builtin_amdgcn_s_memtime();
+#endif
     for (int g0 = 0; g0 < nb; g0 += 64) {
       const int g = g0 + lane;
       const float *bp = blk + (size_t)(g < nb ? g : nb - 1) * 6;
@@ -753,6 +762,9 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
       bool may = !(hi < 0.0f) && !(lo > hi);
       if (EX) may = !(deg_axis >= 0 && outside_on_axis(bp, deg_axis, deg_o));
       unsigned long long live = __builtin_amdgcn_ballot_w64(may && g < nb);
+#ifdef MT_PROF
+      const unsigned long long tt2 = __builtin_amdgcn_s_memtime();
+#endif
       while (live != 0ull) {
         // the next 64 / kGroupTris live blocks, one per slice of the wave
         constexpr int kSlices = 64 / kGroupTris;
@@ -789,7 +801,18 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
           }
         }
       }
+#ifdef MT_PROF
+      tt_tri += __builtin_amdgcn_s_memtime() - tt2;
+#endif
     }
+#ifdef MT_PROF
+    if (tp) {
+      const unsigned long long tt3 = __builtin_amdgcn_s_memtime();
+      tp[0] += (unsigned)(tt1 - tt0);                 // broadcast of the ray
+      tp[1] += (unsigned)(tt3 - tt1 - tt_tri);        // block stage
+      tp[2] += (unsigned)tt_tri;                      // triangle stage
+    }
+#endif
     if (lane == L) {
       best = ubest;
       best_t = ubest_t;
@@ -1159,7 +1182,14 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
 #ifdef MT_PROF
     o.n_groups += (unsigned)n;
 #endif
+#ifdef MT_PROF
+    const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
+#endif
     unsigned long long live = group_live_mask<OCT>(gp + (size_t)(b0 + g0) * 6, n, f);
+#ifdef MT_PROF
+    const unsigned long long tg1 = __builtin_amdgcn_s_memtime();
+    o.t_a += (unsigned)(tg1 - tg0);
+#endif
     while (live != 0ull) {
       const int a = __builtin_ctzll(live);
       const unsigned long long rest = ~(live >> a);  // zero bit = end of the run
@@ -1181,6 +1211,9 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
       o.mt_tests += q.mt_tests;
       live = (a + len >= 64) ? 0ull : (live >> (a + len)) << (a + len);
     }
+#ifdef MT_PROF
+    o.t_b += (unsigned)(__builtin_amdgcn_s_memtime() - tg1);
+#endif
   }
   return o;
 }
@@ -1226,7 +1259,13 @@ __device__ __attribute__((noinline)) ScanOut scan_transposed_blocks_call(const D
   LaneStats st;
   st.clear();
   ScanOut o{-1, 0.0, 0u};
+#ifdef MT_PROF
+  unsigned tp[3] = {0, 0, 0};
+  scan_node_transposed_blocks<EX, STATS>(S, r, f, lane, inmask, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st, tp);
+  o.t_c = tp[0]; o.t_a = tp[1]; o.t_b = tp[2];
+#else
   scan_node_transposed_blocks<EX, STATS>(S, r, f, lane, inmask, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
+#endif
   o.mt_tests = st.v[ST_MT_TESTS];
   return o;
 }
@@ -1560,6 +1599,12 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       best_t = o.best_t;
       if (STATS && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       MT_PROF_END(PROF_SCAN_TRANSPOSED, prof_t1);
+#ifdef MT_PROF
+      MT_PROF_COUNT(PROF_TA_T, __builtin_amdgcn_readfirstlane(o.t_a));
+      MT_PROF_COUNT(PROF_TB_T, __builtin_amdgcn_readfirstlane(o.t_b));
+      MT_PROF_COUNT(PROF_TC_T, __builtin_amdgcn_readfirstlane(o.t_c));
+      MT_PROF_COUNT(PROF_T_RAYS, n_in);
+#endif
     } else {
       MT_PROF_COUNT(PROF_N_RAYPAR, 1);
       MT_PROF_COUNT(PROF_N_RAYPAR_TRIS, pc);
@@ -1575,12 +1620,18 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         const float *g32 = nullptr;
         if (pc >= kBigNode && S.force_mode != 6) g32 = S.grp_aabb32;
         if (mode == 2 && use_filter) {
+#ifdef MT_PROF
+          const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
+#endif
           o = scan_filtered_dispatch<STATS>(S, oct, g32, pb, pc, r, f32);
 #ifdef MT_PROF
+          MT_PROF_COUNT(PROF_M2F_CALL, __builtin_amdgcn_s_memtime() - tc0);
           MT_PROF_COUNT(PROF_G_GROUPS, __builtin_amdgcn_readfirstlane(o.n_groups));
           MT_PROF_COUNT(PROF_G_LIVE, __builtin_amdgcn_readfirstlane(o.n_live));
           MT_PROF_COUNT(PROF_G_RANGES, __builtin_amdgcn_readfirstlane(o.n_ranges));
           MT_PROF_COUNT(PROF_G_RANGE_TRIS, __builtin_amdgcn_readfirstlane(o.n_range_tris));
+          MT_PROF_COUNT(PROF_TA_G, __builtin_amdgcn_readfirstlane(o.t_a));
+          MT_PROF_COUNT(PROF_TB_G, __builtin_amdgcn_readfirstlane(o.t_b));
 #endif
         } else if (mode == 1 && use_filter && g32 != nullptr) {
           // Mixed sign octants: one filtered scan per octant present, each for
