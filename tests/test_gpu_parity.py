@@ -411,6 +411,46 @@ def test_big_frames_identical_to_reference(scenes):
                          "sub-sampled comparison above passed")
 
 
+@pytest.mark.parametrize("scale,offset", [(1e-4, 0.0), (3e4, 0.0), (1.0, 2.5e6), (7.0, -9.1e5)])
+def test_filters_stay_conservative_at_extreme_coordinates(scale, offset, scenes, tmp_path):
+    """The fp32 pre-filter, the block boxes and the subtree boxes work on fp32
+    copies of the scene: a scene scaled to 1e-4 / 3e4 of its size or moved
+    millions of units from the origin (where fp32 resolves only ~0.25 units)
+    must still give exactly the oracle's image, first hits and ray counts, and
+    the same as the modes that use none of them."""
+    src = open(scenes["mini"]).read().splitlines()
+    out = []
+    for ln in src:
+        if ln.startswith("v "):
+            x, y, z = (float(t) for t in ln.split()[1:4])
+            out.append("v %.17g %.17g %.17g" % (x * scale + offset, y * scale + offset, z * scale + offset))
+        else:
+            out.append(ln)
+    obj = tmp_path / "mini_moved.obj"
+    obj.write_text("\n".join(out) + "\n")
+    mtl = os.path.join(os.path.dirname(scenes["mini"]), "mini.mtl")
+    if os.path.exists(mtl):
+        (tmp_path / "mini.mtl").write_text(open(mtl).read())
+    cam = list(scenegen.ROOM_CAMERA)
+    cam[:3] = [c * scale + offset for c in cam[:3]]
+    lights = [tuple(c * scale + offset for c in l[:3]) + tuple(l[3:]) for l in scenegen.ROOM_LIGHTS]
+    m = M.MythTracer(str(obj))
+    o = orclib.OracleScene(str(obj))
+    m.set_lights(lights)
+    o.set_lights(lights)
+    g, r = m.render(cam, 160, 90, debug=True), o.render(cam, 160, 90, debug=True)
+    assert np.array_equal(g["line"], r["line"])
+    assert np.array_equal(g["point"], r["point"], equal_nan=True)
+    assert_rgb_close(g["rgb"], r["rgb"], "scale %g offset %g" % (scale, offset))
+    counters_match(g["counters"], r["counters"])
+    assert (r["line"] >= 0).mean() > 0.5  # the camera still sees the scene
+    abi = M.hip_abi()
+    for mode in (4, 6, 7):
+        abi.set_traversal_mode(m.device_scene(), mode)
+        g2 = m.render(cam, 160, 90, debug=True)
+        assert np.array_equal(g2["rgb"], g["rgb"]) and np.array_equal(g2["line"], g["line"]), mode
+
+
 def test_4k_frame_contains_the_reference_1080p_frame(scenes):
     """BASELINE configs[4] size (3840x2160, 8 ranks).  Size-independent property:
     Sensor::GetRay (camera.cc:58-69) divides the same corner vectors by W and H,
