@@ -317,6 +317,61 @@ def test_ties_degenerates_and_missing_normals():
     assert (g["line"] >= 100).any()  # twins are visible: the later coincident triangle won
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_triangle_soups_all_modes(seed):
+    """Random clustered triangle soups (big straddlers + many small triangles, on
+    an integer lattice so that coincident planes, shared edges and exact ties are
+    common) against random, axis-parallel, one-zero-component and on-plane rays:
+    OctTree::IntersectRay on the GPU in every traversal mode vs the oracle."""
+    rnd = scenegen.SplitMix64(1000 + seed)
+    m, o = _both()
+    tris = []
+    for k in range(1500):
+        big = k % 37 == 0
+        c = [rnd.rng(0, 64) for _ in range(3)]
+        ext = 40.0 if big else 3.0
+        v = [[float(round(c[a] + rnd.rng(-ext, ext))) for a in range(3)] for _ in range(3)]
+        tris.append(v)
+    for s in (m, o):
+        for k, v in enumerate(tris):
+            s.add_triangle(v, None, mtl=-1, line_no=k)
+    rays = []
+    for i in range(4096):
+        org = [rnd.rng(-20, 90) for _ in range(3)]
+        kind = i % 8
+        if kind == 0:    # axis-parallel
+            d = [0.0, 0.0, 0.0]
+            d[i // 8 % 3] = 1.0 if (i // 24) % 2 else -1.0
+        elif kind == 1:  # exactly one zero component, origin on a lattice plane
+            d = [rnd.rng(-1, 1) for _ in range(3)]
+            a = i // 8 % 3
+            d[a] = 0.0
+            org[a] = float(round(org[a]))
+        elif kind == 2:  # origin on lattice planes
+            org = [float(round(x)) for x in org]
+            d = [rnd.rng(-1, 1) for _ in range(3)]
+        else:
+            tgt = [rnd.rng(0, 64) for _ in range(3)]
+            d = [tgt[a] - org[a] for a in range(3)]
+        n = sum(x * x for x in d) ** 0.5 or 1.0
+        rays.append(org + [x / n for x in d])
+    rays = np.array(rays)
+    want = o.intersect(rays)
+    hit = want["line"] >= 0
+    assert 0.2 < hit.mean() < 0.98
+    abi = M.hip_abi()
+    h = m.device_scene()
+    for mode in (0, 1, 2, 3, 4, 5, 6, 7):
+        abi.set_traversal_mode(h, mode)
+        got = abi.intersect_rays(h, rays)
+        assert np.array_equal(got["line"], want["line"]), mode
+        assert np.array_equal(got["t"][hit], want["t"][hit]), mode
+        assert np.array_equal(got["point"][hit], want["point"][hit]), mode
+        assert got["stats"]["mt_tests"] == want["counters"]["mt_tests"], mode
+        if mode in (1, 2, 4, 7):
+            assert all(got["stats"][k] == want["counters"][k] for k in PRUNED), mode
+
+
 def test_transparency_shadow_loop_and_refraction():
     """Stacked glass panes between the floor and the light: the shadow loop
     walks through them (mythtracer.cc:94-156), light power decays below the
