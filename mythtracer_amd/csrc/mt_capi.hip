@@ -110,7 +110,7 @@ bool finite3(const double *p, size_t n) {
 
 // Launch geometry: as many 4-wave blocks as the CU's LDS/VGPR budget admits.
 int configure_launch(mt_scene *s) {
-  const size_t per_wave = wave_stack_bytes(s->dev.tree_depth);
+  const size_t per_wave = wave_stack_bytes(s->dev.tree_depth, s->dev.pack_shift != 0);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > kLdsBudget) wpb >>= 1;
   if (per_wave * wpb > kLdsBudget) {
@@ -570,6 +570,15 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   s->dev.tree_depth = max_depth;
   s->dev.force_mode = 0;
   s->dev.scene_regular = regular ? 1 : 0;
+  {
+    // 16-byte traversal stack frames when "first child" and "best triangle + 1"
+    // share one word: a quarter less LDS per wave
+    int tri_bits = 1;
+    while (tri_bits < 31 && ((long long)d->n_tris + 1) > (1ll << tri_bits)) tri_bits++;
+    int node_bits = 1;
+    while (node_bits < 31 && (long long)nn > (1ll << node_bits)) node_bits++;
+    s->dev.pack_shift = (tri_bits + node_bits <= 32 && !getenv("MT_DEBUG_NO_PACKED_STACK")) ? tri_bits : 0;
+  }
   s->dev.n_lights = 0;
   s->dev.lights = nullptr;
   HIP_TRY(hipMalloc((void **)&s->d_counters, ST_COUNT * sizeof(unsigned long long)));

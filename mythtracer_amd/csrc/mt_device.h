@@ -61,6 +61,7 @@ struct DevScene {
   int32_t tree_depth;
   int32_t force_mode;  // mt_scene_set_traversal_mode (include/mythtracer_hip.h)
   int32_t scene_regular;  // 1: all coordinates finite and boxes ordered
+  int32_t pack_shift;     // 0: 20-byte stack frames; else bits of the (triangle index + 1) field of a packed frame
   // Debug heartbeat (normally NULL): host-visible words the kernel updates so
   // that a stuck launch can be diagnosed from the host (MT_DEBUG_HEARTBEAT=1).
   volatile unsigned long long *hb;
@@ -131,9 +132,11 @@ struct RenderParams {
   unsigned long long *item_cycles;  // debug (MT_DEBUG_ITEM_CYCLES): s_memtime ticks per work item
 };
 
-// Bytes of LDS one wave needs for its traversal stack.
-__host__ __device__ inline size_t wave_stack_bytes(int depth) {
-  return (size_t)depth * 64 * 20 + 4 * 64 * 4;  // stack frames + four per-lane work counters
+// Bytes of LDS one wave needs for its traversal stack: 20-byte frames, or 16-byte
+// ones when a node index and a triangle index fit one word together
+// (DevScene::pack_shift != 0), plus four per-lane work counters.
+__host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
+  return (size_t)depth * 64 * (packed ? 16 : 20) + 4 * 64 * 4;
 }
 
 constexpr int kFrameSlots = 11;  // 10 doubles + 1 packed meta word per frame

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 3) void primary_kernel(DevScene S, RenderParam
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
   const MT_CONST mt_material *mtls = as_const(S.mtls);
   LaneStats st;
   st.clear();
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
   const int waves_per_block = blockDim.x >> 6;
   const int wave_id = blockIdx.x * waves_per_block + wave_in_block;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
   FrameIO fio;
   fio.base = P.frames + (size_t)wave_id * (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64;
   fio.lane = lane;
@@ -733,7 +733,7 @@ __global__ __launch_bounds__(256, 3) void intersect_kernel(DevScene S, int n, co
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool want = i < n;
   double o[3] = {0, 0, 0}, d[3] = {0, 0, 1};

@@ -173,17 +173,23 @@ struct ScanOut {
 struct WaveStack {
   unsigned base;   // byte offset of this wave's region in LDS
   int depth;       // frames per lane
+  int pack_shift;  // see DevScene::pack_shift
   // bt: best distance so far in that node; fc: first child of that node;
   // bp: best primitive so far (-1 none); ord: bits 0-23 child order (3 bits
-  // each), 24-27 count, 28-31 position.
+  // each), 24-27 count, 28-31 position.  Packed frames hold fc and bp + 1 in
+  // one word (fb).
+  __device__ __forceinline__ unsigned frame_bytes() const { return pack_shift ? 16u : 20u; }
   __device__ __forceinline__ MT_LDS double *bt() const { return (MT_LDS double *)(uintptr_t)base; }
   __device__ __forceinline__ MT_LDS int *fc() const { return (MT_LDS int *)(uintptr_t)(base + (unsigned)depth * 64u * 8u); }
   __device__ __forceinline__ MT_LDS int *bp() const { return (MT_LDS int *)(uintptr_t)(base + (unsigned)depth * 64u * 12u); }
-  __device__ __forceinline__ MT_LDS unsigned *ord() const { return (MT_LDS unsigned *)(uintptr_t)(base + (unsigned)depth * 64u * 16u); }
-  __device__ __forceinline__ void bind(char *smem_base, int wave_in_block, int tree_depth) {
+  __device__ __forceinline__ MT_LDS unsigned *ord() const {
+    return (MT_LDS unsigned *)(uintptr_t)(base + (unsigned)depth * 64u * (pack_shift ? 12u : 16u));
+  }
+  __device__ __forceinline__ void bind(char *smem_base, int wave_in_block, int tree_depth, int shift) {
     (void)smem_base;  // dynamic LDS starts at offset 0 of the block's allocation (no static LDS is declared)
     depth = tree_depth;
-    base = (unsigned)wave_in_block * (unsigned)wave_stack_bytes(tree_depth);
+    pack_shift = shift;
+    base = (unsigned)wave_in_block * (unsigned)wave_stack_bytes(tree_depth, shift != 0);
   }
 };
 
@@ -1344,6 +1350,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   S.tree_depth = G->tree_depth;
   S.force_mode = G->force_mode;
   S.scene_regular = G->scene_regular;
+  S.pack_shift = G->pack_shift;
   S.hb = nullptr;
   S.prof = G->prof;
   LaneStats st;
@@ -1356,13 +1363,15 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   WaveStack stk;
   stk.base = (unsigned)uniform_i32((int)stack_base);
   stk.depth = S.tree_depth;
+  stk.pack_shift = S.pack_shift;
   MT_LDS double *const stk_bt = stk.bt();
   MT_LDS int *const stk_fc = stk.fc();
   MT_LDS int *const stk_bp = stk.bp();
   MT_LDS unsigned *const stk_ord = stk.ord();
   // per-lane work counters of this traversal live in LDS (behind the stack),
   // not in registers: four ds_add per node step instead of four live VGPRs
-  MT_LDS unsigned *const cnt = (MT_LDS unsigned *)(uintptr_t)(stk.base + (unsigned)stk.depth * 64u * 20u);
+  MT_LDS unsigned *const cnt = (MT_LDS unsigned *)(uintptr_t)(stk.base + (unsigned)stk.depth * 64u * stk.frame_bytes());
+  const int pack_shift = stk.pack_shift;  // wave-uniform
   if (STATS) {
     cnt[0 * 64 + lane] = 0; cnt[1 * 64 + lane] = 0; cnt[2 * 64 + lane] = 0; cnt[3 * 64 + lane] = 0;
   }
@@ -1452,9 +1461,13 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           break;
         }
         const int at = depth * 64 + lane;
-        stk_fc[at] = my_fc;
+        if (pack_shift) {
+          stk_fc[at] = (int)(((unsigned)my_fc << pack_shift) | (unsigned)(best + 1));
+        } else {
+          stk_fc[at] = my_fc;
+          stk_bp[at] = best;
+        }
         stk_bt[at] = best_t;
-        stk_bp[at] = best;
         stk_ord[at] = (ordw & 0x0fffffffu) | (pos << 28);
         depth++;
         cur = child;
@@ -1470,9 +1483,16 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       depth--;
       const int at = depth * 64 + lane;
       const unsigned po = stk_ord[at];
-      int pbp = stk_bp[at];
+      int pbp;
       double pbt = stk_bt[at];
-      my_fc = stk_fc[at];
+      if (pack_shift) {
+        const unsigned fb = (unsigned)stk_fc[at];
+        my_fc = (int)(fb >> pack_shift);
+        pbp = (int)(fb & ((1u << pack_shift) - 1u)) - 1;
+      } else {
+        pbp = stk_bp[at];
+        my_fc = stk_fc[at];
+      }
       pos = po >> 28;
       ordw = po & 0x0fffffffu;
       if (best >= 0 && !(pbp >= 0 && best_t > pbt)) {  // :233-246 take it and break
