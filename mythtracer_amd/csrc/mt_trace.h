@@ -38,6 +38,9 @@
 namespace mt {
 
 #define MT_CONST __attribute__((address_space(4)))
+#ifndef MT_DUP
+#define MT_DUP 0  // diagnostic: execute one section of the traversal twice (timing experiments only)
+#endif
 
 // Phase profiling (diagnostic build only: python -m mythtracer_amd.build --prof).
 #ifdef MT_PROF
@@ -518,6 +521,17 @@ __device__ __forceinline__ unsigned long long filter32_pass(const float *b, cons
   return __builtin_amdgcn_fcmpf(hi, 0.0f, kUGE) & __builtin_amdgcn_fcmpf(lo, hi, kULE);
 }
 
+// One per-lane box (a child's subtree box) against the lane's own filter.
+__device__ __forceinline__ bool subtree_may_hit(const float *b, const Filter32 &f, bool sx, bool sy, bool sz) {
+  const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
+  const float tnx = __builtin_fmaf(sx ? b3 : b0, f.ix, f.cnx), tfx = __builtin_fmaf(sx ? b0 : b3, f.ix, f.cfx);
+  const float tny = __builtin_fmaf(sy ? b4 : b1, f.iy, f.cny), tfy = __builtin_fmaf(sy ? b1 : b4, f.iy, f.cfy);
+  const float tnz = __builtin_fmaf(sz ? b5 : b2, f.iz, f.cnz), tfz = __builtin_fmaf(sz ? b2 : b5, f.iz, f.cfz);
+  const float lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+  const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+  return !(hi < 0.0f) && !(lo > hi);  // NaN: keep
+}
+
 typedef float f16v __attribute__((ext_vector_type(16)));
 typedef float f8v __attribute__((ext_vector_type(8)));
 struct QuadRegs {  // four fp32 boxes = 96 bytes
@@ -854,8 +868,11 @@ template <int MODE>
 // um (wave-uniform): children outside it are not looked at at all (regular
 // mode only; the caller passes the union of the lanes' non-empty children when
 // subtree skipping is on, so these are children `keep` would drop anyway).
+// sub/f (regular mode): the children's subtree boxes are tested here, and only
+// for the children some lane enters.
 __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, const RayRegs &r,
-                                                   unsigned keep = 0xffu, unsigned um = 0xffu) {
+                                                   unsigned keep = 0xffu, unsigned um = 0xffu,
+                                                   const float *sub = nullptr, const Filter32 *f = nullptr) {
   constexpr bool EX = (MODE == 0);
   double xmin[2], xmax[2], ymin[2], ymax[2], zmin[2], zmax[2];
   {
@@ -886,6 +903,16 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
     const double tmin = mx3<EX>(xmin[xh], ymin[yh], zmin[zh]);
     if constexpr (EX) valid[c] = !(tmax < 0.0) && !(tmin > tmax);
     else valid[c] = (tmax >= 0.0) & (tmin <= tmax) & (((keep >> c) & 1u) != 0u);
+    if constexpr (!EX) {
+      if (sub != nullptr) {
+        if (((um >> c) & 1u) == 0u) {
+          valid[c] = false;  // empty subtree (for every lane)
+        } else if (__ballot(valid[c]) != 0ull) {
+          valid[c] = valid[c] && subtree_may_hit(sub + c * 6, *f, __builtin_signbit(r.ix),
+                                                 __builtin_signbit(r.iy), __builtin_signbit(r.iz));
+        }
+      }
+    }
     tm[c] = tmin;
   }
   unsigned ord = 0, cnt = 0;
@@ -1069,10 +1096,9 @@ __device__ __forceinline__ unsigned order_children_regular(const NodeRec *N, con
         if (__ballot(((m >> c) & 1u) != 0u) != 0ull) um |= 1u << c;
       }
     }
-    keep = tight_keep_mask(uniform_node ? uniform_ptr(sub) : sub, f, __builtin_signbit(r.ix),
-                           __builtin_signbit(r.iy), __builtin_signbit(r.iz), um);
   }
-  return order_children<1>(as_const(uniform_node ? uniform_ptr(N) : N), r, keep, um);
+  return order_children<1>(as_const(uniform_node ? uniform_ptr(N) : N), r, keep, um,
+                           sub == nullptr ? nullptr : (uniform_node ? uniform_ptr(sub) : sub), &f);
 }
 
 // order_children for a per-lane node (no uniformisation of the pointer).
@@ -1521,6 +1547,12 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           cur = -2;
           break;
         }
+#if MT_DUP == 2
+        if (all_regular) {
+          const ScanOut od = scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz);
+          asm volatile("" :: "v"(od.best), "v"(od.best_t));
+        }
+#endif
         const ScanOut o = all_regular
             ? scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz)
             : scan_small_lane_call<true, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz);
@@ -1535,6 +1567,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           const NodeRec *Np = S.nodes + cur;
           const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
+#if MT_DUP == 1
+          if (all_regular) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, false)));
+#endif
           ordw = all_regular ? order_children_regular(Np, r, sub, f32, false)
                              : order_children_lane_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                            irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr,
@@ -1643,6 +1678,12 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
 #ifdef MT_PROF
           const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
 #endif
+#if MT_DUP == 3
+          {
+            const ScanOut od = scan_filtered_dispatch<STATS>(S, oct, g32, pb, pc, r, f32);
+            asm volatile("" :: "v"(od.best), "v"(od.best_t));
+          }
+#endif
           o = scan_filtered_dispatch<STATS>(S, oct, g32, pb, pc, r, f32);
 #ifdef MT_PROF
           MT_PROF_COUNT(PROF_M2F_CALL, __builtin_amdgcn_s_memtime() - tc0);
@@ -1690,6 +1731,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         const NodeRec *Np = S.nodes + n;
         const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
+#if MT_DUP == 1
+        if (mode != 0) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, true)));
+#endif
         ordw = (mode == 0) ? order_children_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                     irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr,
                                                     MT_F32_ARGS(f32))
