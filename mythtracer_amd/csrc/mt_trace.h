@@ -917,6 +917,20 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
   }
   unsigned ord = 0, cnt = 0;
   if constexpr (!EX) {
+    // At most one child left for any lane of the wave: nothing to sort.
+    unsigned any = 0u;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      if (__ballot(valid[c]) != 0ull) any |= 1u << c;
+    }
+    if ((any & (any - 1u)) == 0u) {
+      if (any == 0u) return 0u;
+      const unsigned c0 = (unsigned)__builtin_ctz(any);
+      bool v0 = false;
+#pragma unroll
+      for (int c = 0; c < 8; c++) v0 = v0 || (valid[c] && (unsigned)c == c0);
+      return v0 ? (c0 | (1u << 24)) : 0u;
+    }
     // No NaN keys: the stable sort by tmin is the order by (tmin, index).
     unsigned rank[8];
 #pragma unroll
