@@ -419,6 +419,12 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
         prim = tracing ? P.hit_prim[px_index] : -1;
         t = tracing ? P.hit_t[px_index] : 0.0;
       } else {
+#if MT_DUP == 6
+        {
+          const TraceOut td = trace_wave<false>(S.self, stk.base, lane, tracing, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+          asm volatile("" :: "v"(td.prim), "v"(td.t));
+        }
+#endif
         const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, tracing, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
         add_trace_stats<STATS>(st, to);
         prim = to.prim;

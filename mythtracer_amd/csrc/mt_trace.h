@@ -507,15 +507,28 @@ __device__ __forceinline__ bool make_filter32(const DevScene &S, const RayRegs &
 
 // fp32 verdict for one wave-uniform box b[0..5] (min xyz, max xyz): mask of
 // lanes for which the exact test MAY pass.  NaN compares as "may pass".
+// OCT = 0..7: the lanes' common sign octant.  OCT = 8: lanes of any octants --
+// near = min and far = max of the two products per axis; fma is monotonic in the
+// plane coordinate, so these ARE the octant form's values for every lane.
 template <int OCT>
 __device__ __forceinline__ unsigned long long filter32_pass(const float *b, const Filter32 &f) {
   constexpr int kUGE = 11, kULE = 13;
-  constexpr int NX = (OCT & 1) ? 3 : 0, FX = (OCT & 1) ? 0 : 3;
-  constexpr int NY = (OCT & 2) ? 4 : 1, FY = (OCT & 2) ? 1 : 4;
-  constexpr int NZ = (OCT & 4) ? 5 : 2, FZ = (OCT & 4) ? 2 : 5;
-  const float tnx = __builtin_fmaf(b[NX], f.ix, f.cnx), tfx = __builtin_fmaf(b[FX], f.ix, f.cfx);
-  const float tny = __builtin_fmaf(b[NY], f.iy, f.cny), tfy = __builtin_fmaf(b[FY], f.iy, f.cfy);
-  const float tnz = __builtin_fmaf(b[NZ], f.iz, f.cnz), tfz = __builtin_fmaf(b[FZ], f.iz, f.cfz);
+  float tnx, tny, tnz, tfx, tfy, tfz;
+  if constexpr (OCT == 8) {
+    tnx = __builtin_fminf(__builtin_fmaf(b[0], f.ix, f.cnx), __builtin_fmaf(b[3], f.ix, f.cnx));
+    tfx = __builtin_fmaxf(__builtin_fmaf(b[0], f.ix, f.cfx), __builtin_fmaf(b[3], f.ix, f.cfx));
+    tny = __builtin_fminf(__builtin_fmaf(b[1], f.iy, f.cny), __builtin_fmaf(b[4], f.iy, f.cny));
+    tfy = __builtin_fmaxf(__builtin_fmaf(b[1], f.iy, f.cfy), __builtin_fmaf(b[4], f.iy, f.cfy));
+    tnz = __builtin_fminf(__builtin_fmaf(b[2], f.iz, f.cnz), __builtin_fmaf(b[5], f.iz, f.cnz));
+    tfz = __builtin_fmaxf(__builtin_fmaf(b[2], f.iz, f.cfz), __builtin_fmaf(b[5], f.iz, f.cfz));
+  } else {
+    constexpr int NX = (OCT & 1) ? 3 : 0, FX = (OCT & 1) ? 0 : 3;
+    constexpr int NY = (OCT & 2) ? 4 : 1, FY = (OCT & 2) ? 1 : 4;
+    constexpr int NZ = (OCT & 4) ? 5 : 2, FZ = (OCT & 4) ? 2 : 5;
+    tnx = __builtin_fmaf(b[NX], f.ix, f.cnx); tfx = __builtin_fmaf(b[FX], f.ix, f.cfx);
+    tny = __builtin_fmaf(b[NY], f.iy, f.cny); tfy = __builtin_fmaf(b[FY], f.iy, f.cfy);
+    tnz = __builtin_fmaf(b[NZ], f.iz, f.cnz); tfz = __builtin_fmaf(b[FZ], f.iz, f.cfz);
+  }
   const float lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
   const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
   return __builtin_amdgcn_fcmpf(hi, 0.0f, kUGE) & __builtin_amdgcn_fcmpf(lo, hi, kULE);
@@ -575,7 +588,7 @@ __device__ __forceinline__ void scan_quad(const DevScene &S, const RayRegs &r, c
     if (m[j] == 0ull) continue;  // wave-uniform
     const MT_CONST double *a = boxes + j * 6;
     const double b[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
-    const unsigned long long pm = slab_pass<2, OCT>(b, r) & m[j];
+    const unsigned long long pm = slab_pass<(OCT == 8 ? 1 : 2), (OCT == 8 ? 0 : OCT)>(b, r) & m[j];
     if (pm == 0ull) continue;
     if (pm & pmask) {  // some lane would need a second slot: resolve first
       flush_candidates<STATS>(S, r, pend, best, best_t, st);
@@ -1335,8 +1348,10 @@ __device__ __forceinline__ ScanOut scan_filtered_dispatch(const DevScene &S, int
                         : scan_filtered_call<5, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
     case 6: return (g32 ? scan_grouped_call<6, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
                         : scan_filtered_call<6, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
-    default: return (g32 ? scan_grouped_call<7, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+    case 7: return (g32 ? scan_grouped_call<7, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
                         : scan_filtered_call<7, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    default: return (g32 ? scan_grouped_call<8, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<8, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
   }
 }
 
@@ -1657,6 +1672,12 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       MT_PROF_COUNT(PROF_N_TRANSPOSED, 1);
       MT_PROF_COUNT(PROF_N_CHUNKS, n_in * chunks);
       if (STATS) st.wave_tri_steps += (unsigned)(n_in * chunks) - (unsigned)pc;  // replaces the pc counted above
+#if MT_DUP == 4
+      if (blocks_ok) {
+        const ScanOut od = scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
+        asm volatile("" :: "v"(od.best), "v"(od.best_t));
+      }
+#endif
       const ScanOut o = blocks_ok
           ? scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
           : blocks_irr
@@ -1709,14 +1730,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           MT_PROF_COUNT(PROF_TB_G, __builtin_amdgcn_readfirstlane(o.t_b));
 #endif
         } else if (mode == 1 && use_filter && g32 != nullptr) {
-          // Mixed sign octants: one filtered scan per octant present, each for
-          // its own lanes (a lane's result depends on its own ray only).
-          const int my_oct = sxl | (syl << 1) | (szl << 2);
-          o = ScanOut{-1, 0.0, 0u};
-          for (int q = 0; q < 8; q++) {
-            if (__ballot(my_oct == q) == 0ull) continue;
-            if (my_oct == q) o = scan_filtered_dispatch<STATS>(S, q, g32, pb, pc, r, f32);
-          }
+          // Mixed sign octants: the octant-free form of the filter (OCT = 8).
+          o = scan_filtered_dispatch<STATS>(S, 8, g32, pb, pc, r, f32);
         }
         else if (mode == 2) o = scan_octant_dispatch<STATS>(S, oct, pb, pc, r);
         else if (mode == 1) o = scan_exact_call<1, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
