@@ -1202,6 +1202,47 @@ __device__ __forceinline__ DevScene scan_ctx(const float *b32, const double *b64
   return S;
 }
 
+// Lane-parallel scan of a small node with the fp32 pre-filter (regular rays):
+// every lane tests the triangles of ITS node -- fp32 box first (planes picked by
+// the lane's own direction signs; half the bytes and a third of the VALU time of
+// the fp64 test), exact fp64 test and Möller–Trumbore only for the survivors.
+template <bool STATS>
+__device__ __attribute__((noinline)) ScanOut scan_small_lane_f32_call(const DevScene *self, int pb, int pc,
+                                                                      MT_RAY_PARAMS, MT_F32_PARAMS) {
+  MT_RAY_FROM_PARAMS(r);
+  MT_F32_FROM_PARAMS(f);
+  const DevScene S = scan_ctx_self(self);
+  const bool sx = __builtin_signbit(r.ix), sy = __builtin_signbit(r.iy), sz = __builtin_signbit(r.iz);
+  ScanOut o{-1, 0.0, 0u};
+  for (int k = 0; k < pc; k += 4) {
+    float b[4][6];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int kk = (k + j < pc) ? (k + j) : (pc - 1);  // clamped: the load is always valid
+      const float *bp = S.tri_aabb32 + (size_t)(pb + kk) * 6;
+#pragma unroll
+      for (int i = 0; i < 6; i++) b[j][i] = bp[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (k + j >= pc) break;
+      if (!subtree_may_hit(b[j], f, sx, sy, sz)) continue;  // the same conservative test, per lane
+      const double *bx = S.tri_aabb + (size_t)(pb + k + j) * 6;
+      const double e[6] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]};
+      if (!slab_pass_lane<false>(e, r)) continue;
+      if (STATS) o.mt_tests++;
+      double t;
+      if (moller_trumbore(S.tri_vertex + (size_t)(pb + k + j) * 9, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &t)) {
+        if (!(o.best >= 0 && t > o.best_t)) {
+          o.best = pb + k + j;
+          o.best_t = t;
+        }
+      }
+    }
+  }
+  return o;
+}
+
 template <int OCT, bool STATS>
 __device__ __attribute__((noinline)) ScanOut scan_filtered_call(const DevScene *self, int pb, int pc,
                                                                 MT_RAY_PARAMS, MT_F32_PARAMS) {
@@ -1582,7 +1623,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           asm volatile("" :: "v"(od.best), "v"(od.best_t));
         }
 #endif
-        const ScanOut o = all_regular
+        const ScanOut o = (use_filter && S.force_mode != 4)
+            ? scan_small_lane_f32_call<STATS>(S.self, cur_pb, cur_pc, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
+            : all_regular
             ? scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz)
             : scan_small_lane_call<true, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz);
         if (STATS) {
