@@ -667,22 +667,6 @@ __device__ __forceinline__ unsigned long long group_live_mask(const MT_CONST flo
   return live;
 }
 
-template <bool STATS>
-__device__ __forceinline__ void scan_node_filtered_octant(const DevScene &S, const RayRegs &r,
-                                                          const Filter32 &f, int pb, int pc, int oct,
-                                                          int &best, double &best_t, LaneStats &st) {
-  switch (oct) {
-    case 0: scan_node_filtered<0, STATS>(S, r, f, pb, pc, best, best_t, st); break;
-    case 1: scan_node_filtered<1, STATS>(S, r, f, pb, pc, best, best_t, st); break;
-    case 2: scan_node_filtered<2, STATS>(S, r, f, pb, pc, best, best_t, st); break;
-    case 3: scan_node_filtered<3, STATS>(S, r, f, pb, pc, best, best_t, st); break;
-    case 4: scan_node_filtered<4, STATS>(S, r, f, pb, pc, best, best_t, st); break;
-    case 5: scan_node_filtered<5, STATS>(S, r, f, pb, pc, best, best_t, st); break;
-    case 6: scan_node_filtered<6, STATS>(S, r, f, pb, pc, best, best_t, st); break;
-    default: scan_node_filtered<7, STATS>(S, r, f, pb, pc, best, best_t, st); break;
-  }
-}
-
 // Transposed scan: ONE ray at a time, 64 TRIANGLES per step (lane = triangle).
 // Used when only a few lanes want a node: scanning a 90-triangle list for 2
 // rays costs 4 of these steps instead of 90 ray-parallel ones.  All 64 lanes
@@ -854,27 +838,11 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
   }
 }
 
-// Octant dispatch for mode 2 (eight specialised loops: the near/far planes
-// become fixed registers instead of scalar selects).
-template <bool STATS>
-__device__ __forceinline__ void scan_node_octant(const DevScene &S, const RayRegs &r, int pb, int pc,
-                                                 int oct, int &best, double &best_t, LaneStats &st) {
-  switch (oct) {
-    case 0: scan_node_prims<2, 0, STATS>(S, r, pb, pc, best, best_t, st); break;
-    case 1: scan_node_prims<2, 1, STATS>(S, r, pb, pc, best, best_t, st); break;
-    case 2: scan_node_prims<2, 2, STATS>(S, r, pb, pc, best, best_t, st); break;
-    case 3: scan_node_prims<2, 3, STATS>(S, r, pb, pc, best, best_t, st); break;
-    case 4: scan_node_prims<2, 4, STATS>(S, r, pb, pc, best, best_t, st); break;
-    case 5: scan_node_prims<2, 5, STATS>(S, r, pb, pc, best, best_t, st); break;
-    case 6: scan_node_prims<2, 6, STATS>(S, r, pb, pc, best, best_t, st); break;
-    default: scan_node_prims<2, 7, STATS>(S, r, pb, pc, best, best_t, st); break;
-  }
-}
 
 // Child slab tests + ordering of the hit children, octtree.cc:204-216.
 // Returns ord (3 bits per entry) | count << 24.
 // keep: bit c clear = child c's subtree provably holds no triangle this ray's
-// pre-filter accepts (tight_keep_mask); such a child is left out of the list.
+// pre-filter accepts; such a child is left out of the list.
 // The sort is stable and a child without a hit only makes the parent's loop
 // move on (octtree.cc:222-251), so leaving it out changes nothing.
 template <int MODE>
@@ -1086,24 +1054,9 @@ __device__ __attribute__((noinline)) ScanOut scan_small_lane_call(const double *
 // Subtree boxes: sub[c*6 .. c*6+5] = fp32 union box of every triangle stored in
 // child c or below it.  A ray that misses it (conservatively, in fp32; same
 // argument as for the block boxes) fails the reference's AABB pre-filter for
-// every triangle down there, so visiting that child could only return "no hit".
-__device__ __forceinline__ unsigned tight_keep_mask(const float *sub, const Filter32 &f, bool sx,
-                                                    bool sy, bool sz, unsigned um = 0xffu) {
-  unsigned keep = 0u;
-#pragma unroll
-  for (int c = 0; c < 8; c++) {
-    if (((um >> c) & 1u) == 0u) continue;  // wave-uniform skip (empty subtree for every lane)
-    const float *b = sub + c * 6;
-    const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
-    const float tnx = __builtin_fmaf(sx ? b3 : b0, f.ix, f.cnx), tfx = __builtin_fmaf(sx ? b0 : b3, f.ix, f.cfx);
-    const float tny = __builtin_fmaf(sy ? b4 : b1, f.iy, f.cny), tfy = __builtin_fmaf(sy ? b1 : b4, f.iy, f.cfy);
-    const float tnz = __builtin_fmaf(sz ? b5 : b2, f.iz, f.cnz), tfz = __builtin_fmaf(sz ? b2 : b5, f.iz, f.cfz);
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
-    const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
-    if (!(hi < 0.0f) && !(lo > hi)) keep |= 1u << c;  // NaN: keep
-  }
-  return keep;
-}
+// every triangle down there, so visiting that child could only return "no hit"
+// (subtree_may_hit, applied inside order_children to the children some lane
+// enters).
 
 // Regular-mode ordering, inlined into the traversal (small: ~35 VGPRs); the
 // exact-mode variant below stays a function of its own.
@@ -1128,51 +1081,38 @@ __device__ __forceinline__ unsigned order_children_regular(const NodeRec *N, con
                            sub == nullptr ? nullptr : (uniform_node ? uniform_ptr(sub) : sub), &f);
 }
 
-// order_children for a per-lane node (no uniformisation of the pointer).
-// sub = the eight subtree boxes of the node's children, or nullptr (no culling).
-template <int MODE>
-__device__ __attribute__((noinline)) unsigned order_children_lane_call(const NodeRec *N, double ox, double oy,
-                                                                       double oz, double ix, double iy,
-                                                                       double iz, const float *sub,
-                                                                       MT_F32_PARAMS) {
+// Exact-mode ordering (NaN-capable rays) as functions of their own: the literal
+// insertion sort needs ~60 registers and is rare.  sub = the eight subtree boxes
+// of the node's children for rays with one zero direction component
+// (degenerate_axis), or nullptr.  _lane: per-lane node; the other: wave-uniform.
+__device__ __attribute__((noinline)) unsigned order_children_exact_lane_call(const NodeRec *N, double ox,
+                                                                             double oy, double oz, double ix,
+                                                                             double iy, double iz,
+                                                                             const float *sub) {
   RayRegs r;
   r.ox = ox; r.oy = oy; r.oz = oz;
   r.dx = 0.0; r.dy = 0.0; r.dz = 0.0;
   r.ix = ix; r.iy = iy; r.iz = iz;
   unsigned keep = 0xffu;
-  if (MODE != 0 && sub != nullptr) {
-    MT_F32_FROM_PARAMS(f);
-    keep = tight_keep_mask(sub, f, __builtin_signbit(ix), __builtin_signbit(iy), __builtin_signbit(iz));
-  }
-  if (MODE == 0 && sub != nullptr) {
+  if (sub != nullptr) {
     const int axis = degenerate_axis(ox, oy, oz, ix, iy, iz);
     if (axis >= 0) keep = degenerate_keep_mask(sub, axis, axis == 0 ? ox : (axis == 1 ? oy : oz));
   }
-  return order_children<MODE>(as_const(N), r, keep);
+  return order_children<0>(as_const(N), r, keep);
 }
-
-// Non-inlined entry of order_children (its exact-mode variant alone needs ~60
-// registers; as a function of its own it does not inflate the traversal).
-template <int MODE>
-__device__ __attribute__((noinline)) unsigned order_children_call(const NodeRec *N, double ox, double oy,
-                                                                  double oz, double ix, double iy,
-                                                                  double iz, const float *sub,
-                                                                  MT_F32_PARAMS) {
+__device__ __attribute__((noinline)) unsigned order_children_exact_call(const NodeRec *N, double ox, double oy,
+                                                                        double oz, double ix, double iy,
+                                                                        double iz, const float *sub) {
   RayRegs r;
   r.ox = ox; r.oy = oy; r.oz = oz;
   r.dx = 0.0; r.dy = 0.0; r.dz = 0.0;
   r.ix = ix; r.iy = iy; r.iz = iz;
   unsigned keep = 0xffu;
-  if (MODE != 0 && sub != nullptr) {
-    MT_F32_FROM_PARAMS(f);
-    keep = tight_keep_mask(uniform_ptr(sub), f, __builtin_signbit(ix), __builtin_signbit(iy),
-                           __builtin_signbit(iz));
-  }
-  if (MODE == 0 && sub != nullptr) {
+  if (sub != nullptr) {
     const int axis = degenerate_axis(ox, oy, oz, ix, iy, iz);
     if (axis >= 0) keep = degenerate_keep_mask(uniform_ptr(sub), axis, axis == 0 ? ox : (axis == 1 ? oy : oz));
   }
-  return order_children<MODE>(as_const(uniform_ptr(N)), r, keep);
+  return order_children<0>(as_const(uniform_ptr(N)), r, keep);
 }
 
 // ---- non-inlined entry points of the node scans ------------------------------
@@ -1499,7 +1439,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   const bool use_filter = all_regular && (S.force_mode != 4) && (S.force_mode != 2) &&
                           (__ballot(want && !f32_ok) == 0ull);
 
-  // Subtree culling (see tight_keep_mask); off in the modes without the fp32
+  // Subtree culling (see subtree_may_hit); off in the modes without the fp32
   // filter and in mode 7, where the counters then match the reference's
   // un-pruned traversal exactly.
   const bool cull = use_filter && (S.force_mode != 7);
@@ -1643,9 +1583,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           if (all_regular) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, false)));
 #endif
           ordw = all_regular ? order_children_regular(Np, r, sub, f32, false)
-                             : order_children_lane_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                           irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr,
-                                                           MT_F32_ARGS(f32));
+                             : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                              irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr);
         }
         finish_node(fc, ordw, o.best, o.best_t);
       }
@@ -1806,9 +1745,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
 #if MT_DUP == 1
         if (mode != 0) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, true)));
 #endif
-        ordw = (mode == 0) ? order_children_call<0>(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                    irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr,
-                                                    MT_F32_ARGS(f32))
+        ordw = (mode == 0) ? order_children_exact_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                       irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr)
                            : order_children_regular(Np, r, sub, f32, true);
       }
       finish_node(fc, ordw, best, best_t);
