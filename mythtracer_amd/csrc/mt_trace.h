@@ -1212,10 +1212,13 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
   MT_RAY_FROM_PARAMS(r);
   MT_F32_FROM_PARAMS(f);
   self = uniform_ptr(self);
-  const MT_CONST float *gp = as_const(as_const(self)->grp_aabb32);
+  const DevScene S = scan_ctx_self(self);
+  const MT_CONST float *gp = as_const(S.grp_aabb32);
   pb = uniform_i32(pb);
   pc = uniform_i32(pc);
   ScanOut o{-1, 0.0, 0u};
+  LaneStats st;
+  st.clear();
   const int b0 = pb / kGroupTris, nb = (pb + pc - 1) / kGroupTris - b0 + 1;
   for (int g0 = 0; g0 < nb; g0 += 64) {
     const int n = (nb - g0) < 64 ? (nb - g0) : 64;
@@ -1238,23 +1241,20 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
       int last = first + len * kGroupTris;
       if (first < pb) first = pb;
       if (last > pb + pc) last = pb + pc;
-      const ScanOut q = scan_filtered_call<OCT, STATS>(self, first, last - first, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+      // in list order, best / best_t running through (octtree.cc:186-194)
+      scan_node_filtered<OCT, STATS>(S, r, f, first, last - first, o.best, o.best_t, st);
 #ifdef MT_PROF
       o.n_ranges++;
       o.n_live += (unsigned)len;
       o.n_range_tris += (unsigned)(last - first);
 #endif
-      if (q.best >= 0 && !(o.best >= 0 && q.best_t > o.best_t)) {
-        o.best = q.best;
-        o.best_t = q.best_t;
-      }
-      o.mt_tests += q.mt_tests;
       live = (a + len >= 64) ? 0ull : (live >> (a + len)) << (a + len);
     }
 #ifdef MT_PROF
     o.t_b += (unsigned)(__builtin_amdgcn_s_memtime() - tg1);
 #endif
   }
+  o.mt_tests = st.v[ST_MT_TESTS];
   return o;
 }
 
