@@ -1146,8 +1146,10 @@ __device__ __forceinline__ DevScene scan_ctx(const float *b32, const double *b64
 // every lane tests the triangles of ITS node -- fp32 box first (planes picked by
 // the lane's own direction signs; half the bytes and a third of the VALU time of
 // the fp64 test), exact fp64 test and Möller–Trumbore only for the survivors.
+// Inlined into the traversal (no scalar box buffers here, so nothing to protect
+// from its register allocation; the call cost 2-3 % of the frame).
 template <bool STATS>
-__device__ __attribute__((noinline)) ScanOut scan_small_lane_f32_call(const DevScene *self, int pb, int pc,
+__device__ __forceinline__ ScanOut scan_small_lane_f32_call(const DevScene *self, int pb, int pc,
                                                                       MT_RAY_PARAMS, MT_F32_PARAMS) {
   MT_RAY_FROM_PARAMS(r);
   MT_F32_FROM_PARAMS(f);
