@@ -879,6 +879,13 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
   bool valid[8];
 #pragma unroll
   for (int c = 0; c < 8; c++) {
+    if constexpr (!EX) {
+      if (sub != nullptr && ((um >> c) & 1u) == 0u) {  // empty subtree for every lane: wave-uniform skip
+        valid[c] = false;
+        tm[c] = 0.0;
+        continue;
+      }
+    }
     const int xh = c & 1, zh = (c >> 1) & 1, yh = (c >> 2) & 1;  // octtree.cc:61-100
     const double tmax = mn3<EX>(xmax[xh], ymax[yh], zmax[zh]);
     const double tmin = mx3<EX>(xmin[xh], ymin[yh], zmin[zh]);
@@ -886,9 +893,7 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
     else valid[c] = (tmax >= 0.0) & (tmin <= tmax) & (((keep >> c) & 1u) != 0u);
     if constexpr (!EX) {
       if (sub != nullptr) {
-        if (((um >> c) & 1u) == 0u) {
-          valid[c] = false;  // empty subtree (for every lane)
-        } else if (__ballot(valid[c]) != 0ull) {
+        if (__ballot(valid[c]) != 0ull) {
           valid[c] = valid[c] && subtree_may_hit(sub + c * 6, *f, __builtin_signbit(r.ix),
                                                  __builtin_signbit(r.iy), __builtin_signbit(r.iz));
         }
@@ -1560,8 +1565,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           break;
         }
 #if MT_DUP == 2
-        if (all_regular) {
-          const ScanOut od = scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz);
+        if (use_filter && S.force_mode != 4) {
+          const ScanOut od = scan_small_lane_f32_call<STATS>(S.self, cur_pb, cur_pc, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
           asm volatile("" :: "v"(od.best), "v"(od.best_t));
         }
 #endif
