@@ -506,6 +506,22 @@ def test_filters_stay_conservative_at_extreme_coordinates(scale, offset, scenes,
         assert np.array_equal(g2["rgb"], g["rgb"]) and np.array_equal(g2["line"], g["line"]), mode
 
 
+def test_unpacked_stack_frames(scenes, monkeypatch):
+    """Scenes whose node and triangle indices do not fit one word together use
+    20-byte traversal stack frames instead of 16-byte ones; forced here for a
+    small scene (MT_DEBUG_NO_PACKED_STACK is read when the scene is created)."""
+    g = load("mini_320x180")
+    monkeypatch.setenv("MT_DEBUG_NO_PACKED_STACK", "1")
+    m = M.MythTracer(scenes["mini"])
+    m.set_lights(scenegen.ROOM_LIGHTS)
+    a = m.render(scenegen.ROOM_CAMERA, 320, 180, debug=True)
+    monkeypatch.delenv("MT_DEBUG_NO_PACKED_STACK")
+    assert_rgb_close(a["rgb"], g["rgb"], "unpacked frames")
+    assert np.array_equal(a["line"], g["line"])
+    b = m.render(scenegen.ROOM_CAMERA, 320, 180)  # and through the cost-history path
+    assert np.array_equal(b["rgb"], a["rgb"])
+
+
 def test_4k_frame_contains_the_reference_1080p_frame(scenes):
     """BASELINE configs[4] size (3840x2160, 8 ranks).  Size-independent property:
     Sensor::GetRay (camera.cc:58-69) divides the same corner vectors by W and H,
