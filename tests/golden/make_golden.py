@@ -35,6 +35,14 @@ CORNELL_CAM2 = (20, 70, 10, 25, 35, 10, 95)
 CORNELL_LIGHTS2 = [(50, 90, 50, .2, .2, .2, .8, .8, .8, 1, 1, 1), (10, 20, 90, 0, 0, .1, .3, .3, .6, .2, .2, .2)]
 
 
+ROOM_VIEWS = [
+    ("room_view_back", (330.0, 60.0, 380.0, -5.0, 200.0, 0.0, 90.0), scenegen.ROOM_LIGHTS),
+    ("room_view_floor", (40.0, 15.0, 200.0, 8.0, 90.0, 12.0, 100.0), scenegen.ROOM_LIGHTS),
+    ("room_view_down", (200.0, 240.0, 200.0, 88.0, 30.0, 0.0, 80.0), scenegen.ROOM_LIGHTS[:2]),
+    ("room_view_axis", (200.0, 125.0, 5.0, 0.0, 0.0, 0.0, 70.0), scenegen.ROOM_LIGHTS),
+]
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -171,6 +179,10 @@ def main():
         quirk_cases(td)
         room = scenegen.write_scene("room", scenes)
         render_case(td, "room_240x135", room["obj"], 240, 135, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS)
+        # more views of the room: other octants, grazing floor reflections, a close-up of
+        # the glass, an axis-aligned camera on the root's split plane (x = 200), two lights
+        for name, cam, lights in ROOM_VIEWS:
+            render_case(td, name, room["obj"], 200, 112, cam, lights)
         ray_case(td, "rays_room", room["obj"], random_rays(13, 400, (0, 0, 0), (400, 250, 400)))
         meta = {"mini": mini["sha256"], "mini_nomtl": mini_n["sha256"], "room": room["sha256"]}
         json.dump(meta, open(os.path.join(HERE, "scene_hashes.json"), "w"), indent=1, sort_keys=True)

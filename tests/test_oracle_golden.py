@@ -14,7 +14,9 @@ from conftest import GOLDEN, CORNELL
 RENDER_CASES = [("cornell_256", "cornell"), ("cornell_cam2_96x64", "cornell"),
                 ("cornell_nolights_64", "cornell"), ("mini_320x180", "mini"),
                 ("mini_nomtl_320x180", "mini_nomtl"), ("mini_chunk_101x67", "mini"),
-                ("mini_1x1", "mini"), ("room_240x135", "room")]
+                ("mini_1x1", "mini"), ("room_240x135", "room"),
+                ("room_view_back", "room"), ("room_view_floor", "room"), ("room_view_down", "room"),
+                ("room_view_axis", "room")]
 
 
 def load(name):
