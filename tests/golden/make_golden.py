@@ -154,6 +154,18 @@ def big_frames(td):
         np.savez_compressed(os.path.join(HERE, key + "_sub16.npz"), rgb=r["rgb"][::16, ::16],
                             line=r["line"][::16, ::16], point=r["point"][::16, ::16])
         print(key, frames[key])
+    # two more full-size frames from other views (camera and lights recorded with the hash)
+    for name, cam, lights in ROOM_VIEWS[:2]:
+        info = scenegen.write_scene("room", scenes)
+        W, H = 1920, 1080
+        r = orclib.run_ref(os.path.join(td, name + "_big"), info["obj"], (W, H), cam=cam, lights=lights,
+                           want_debug=True)
+        assert r["returncode"] == 0, r["stderr"]
+        key = "%s_%dx%d_d5" % (name, W, H)
+        frames[key] = {"sha256": sha(r["rgb"]), "line_sha256": sha(r["line"].astype("<i4")),
+                       "seconds_reference_here": r["time"]["seconds"], "threads": r["time"]["threads"],
+                       "scene_sha256": info["sha256"], "cam": list(cam), "lights": [list(l) for l in lights]}
+        print(key, frames[key]["sha256"], frames[key]["seconds_reference_here"])
     json.dump(frames, open(fpath, "w"), indent=1, sort_keys=True)
 
 

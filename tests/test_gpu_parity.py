@@ -561,6 +561,26 @@ def test_4k_frame_contains_the_reference_1080p_frame(scenes):
     assert sha == frames["room_1920x1080_d5"]["sha256"]
 
 
+@pytest.mark.parametrize("view", ["room_view_back", "room_view_floor"])
+def test_big_frames_other_views(view, scenes):
+    """Two more 1920x1080 frames (other sign octants; grazing floor reflections)
+    against the SHA-256 of the frame the compiled reference rendered, first
+    through the material-classified launch, then through the cost-history one."""
+    import hashlib
+    frames = json.load(open(os.path.join(GOLDEN, "frames.json")))
+    e = frames[view + "_1920x1080_d5"]
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["room"])
+    h = m.device_scene()
+    abi.set_lights(h, e["lights"])
+    sens = binding.sensor(e["cam"], 1920, 1080)
+    for launch in range(3):
+        r = abi.render_chunk(h, sens, 1920, 1080)
+        sha = hashlib.sha256(r["rgb"].tobytes()).hexdigest()
+        print(view, "launch", launch, sha, "kernel ms", r["stats"]["kernel_ms"])
+        assert sha == e["sha256"], launch
+
+
 def test_tiles_and_blit_equal_single_launch(scenes):
     """mt_render_tiles_device + mt_blit_tiles_device: three virtual ranks on one
     GPU reproduce the single-launch frame byte for byte (the multi-GPU path
