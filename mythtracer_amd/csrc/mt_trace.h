@@ -5,19 +5,24 @@
 // and Triangle::IntersectRay (primitive_triangle.cc:81-143) of the reference,
 // with bit-identical results.
 //
-// Design (one ray per lane, one NODE per wave step):
+// Design (one ray per lane):
 //   * every lane keeps its own recursion state (the reference's call stack of
 //     PrimitiveIntersectRay) in an LDS-resident per-lane stack;
-//   * the wave repeatedly picks the lowest-numbered node any lane still has to
-//     scan (nodes are numbered breadth-first, so the big top-of-tree lists are
-//     scanned once for all lanes that need them) and scans that node's
-//     triangle list for those lanes only.  The node record and the triangle
-//     boxes are therefore WAVE-UNIFORM: they are fetched with scalar loads
-//     (one 48-byte box serves 64 rays) and fed to the VALU as SGPR operands;
+//   * small nodes (< kBigNode triangles) are scanned lane-parallel, every lane
+//     its own node; for the big ones the wave repeatedly picks the lowest-
+//     numbered node any lane still has to scan (nodes are numbered breadth-first,
+//     so the big top-of-tree lists are scanned once for all lanes that need
+//     them) and scans it for those lanes only.  Its boxes are then WAVE-UNIFORM:
+//     fetched with scalar loads (one box serves 64 rays) and fed to the VALU as
+//     SGPR operands;
+//   * only work whose outcome is provably "the reference's pre-filter rejects
+//     it" is skipped: an fp32 conservative filter before the fp64 box test,
+//     fp32 union boxes over blocks of 16 triangles and over subtrees (see
+//     Filter32, scan_grouped_call, subtree_may_hit, degenerate_axis);
 //   * the rare triangles that pass the box pre-filter are parked per lane and
 //     resolved (Möller–Trumbore) in batches, in the reference's order.
 //
-// Exactness.  fp64 throughout, no FMA contraction (-ffp-contract=off), IEEE
+// Exactness.  fp64 wherever a result is decided, no FMA contraction (-ffp-contract=off), IEEE
 // division and square root.  Three evaluation modes of the slab test produce
 // the same booleans as the reference's std::min/std::max formulation:
 //   mode 0 (exact)   literal std::min/std::max compare+select; used whenever
