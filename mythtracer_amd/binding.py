@@ -343,13 +343,15 @@ def host_lib():
 def sensor(cam7, w, h):
     """Camera::GetSensor on the host -> origin, start, delta_scanline, delta_pixel."""
     out = np.zeros(12)
-    host_lib().mth_sensor(_ptr(_f64(cam7)), w, h, _ptr(out))
+    cam = _f64(cam7)  # bound to a name: must outlive the call
+    host_lib().mth_sensor(_ptr(cam), w, h, _ptr(out))
     return out
 
 
 def sensor_ray(cam7, w, h, x, y):
     d = np.zeros(3)
-    host_lib().mth_sensor_ray(_ptr(_f64(cam7)), w, h, x, y, _ptr(d))
+    cam = _f64(cam7)
+    host_lib().mth_sensor_ray(_ptr(cam), w, h, x, y, _ptr(d))
     return d
 
 
@@ -377,8 +379,11 @@ class MythTracer:
         return bool(self.L.mth_load_obj(self.h, os.fsencode(path)))
 
     def add_material(self, name, ka, kd, ks, ns=0.0, refl=0.0, tr=0.0, tf=(0, 0, 0), ni=0.0):
-        return self.L.mth_add_material(self.h, name.encode(), _ptr(_f64(ka)), _ptr(_f64(kd)),
-                                       _ptr(_f64(ks)), ns, refl, tr, _ptr(_f64(tf)), ni)
+        # every converted array is bound to a name so that it outlives the call
+        # (a temporary's buffer is recycled by numpy before the C side reads it)
+        ka, kd, ks, tf = _f64(ka).reshape(3), _f64(kd).reshape(3), _f64(ks).reshape(3), _f64(tf).reshape(3)
+        return self.L.mth_add_material(self.h, name.encode(), _ptr(ka), _ptr(kd), _ptr(ks),
+                                       float(ns), float(refl), float(tr), _ptr(tf), float(ni))
 
     def add_texture(self, name, rgb):
         rgb = _f64(rgb)
@@ -491,7 +496,8 @@ class MythTracer:
         dp = np.zeros((max(ch, 0), max(cw, 0), 3)) if debug else None
         st = np.zeros(8, dtype=np.uint64)
         ms = np.zeros(2)
-        ok = self.L.mth_render_chunk(self.h, _ptr(_f64(cam)), image_w, image_h, cx, cy, cw, ch,
+        cam = _f64(cam)
+        ok = self.L.mth_render_chunk(self.h, _ptr(cam), image_w, image_h, cx, cy, cw, ch,
                                      _ptr(rgb), _ptr(dl), _ptr(dp), _ptr(st), _ptr(ms))
         if not ok:
             raise RuntimeError("RayTrace failed: " + self.last_error())
@@ -502,7 +508,8 @@ class MythTracer:
     def render_image(self, cam, image_w, image_h):
         """MythTracer::RayTrace(int, int, Camera*, vector<uint8_t>*)."""
         rgb = np.zeros((image_h, image_w, 3), dtype=np.uint8)
-        if not self.L.mth_render_image(self.h, _ptr(_f64(cam)), image_w, image_h, _ptr(rgb)):
+        cam = _f64(cam)
+        if not self.L.mth_render_image(self.h, _ptr(cam), image_w, image_h, _ptr(rgb)):
             raise RuntimeError("RayTrace failed: " + self.last_error())
         return rgb
 

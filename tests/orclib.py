@@ -91,9 +91,11 @@ class OracleScene:
 
     def add_material(self, name, ka, kd, ks, ns=0.0, refl=0.0, tr=0.0,
                      tf=(0, 0, 0), ni=0.0) -> int:
-        return self.L.orc_add_material(self.h, name.encode(), _p(_f64(ka)),
-                                       _p(_f64(kd)), _p(_f64(ks)), ns, refl, tr,
-                                       _p(_f64(tf)), ni)
+        # arrays bound to names: a temporary would be freed before the call
+        ka, kd, ks, tf = (_f64(ka).reshape(3), _f64(kd).reshape(3), _f64(ks).reshape(3),
+                          _f64(tf).reshape(3))
+        return self.L.orc_add_material(self.h, name.encode(), _p(ka), _p(kd), _p(ks),
+                                       float(ns), float(refl), float(tr), _p(tf), float(ni))
 
     def add_texture(self, name, rgb) -> int:
         rgb = _f64(rgb)
@@ -207,19 +209,22 @@ class OracleScene:
 
 def sensor(cam, w, h):
     o = np.zeros(12)
-    lib().orc_sensor(_p(_f64(cam)), w, h, _p(o))
+    cam = _f64(cam)
+    lib().orc_sensor(_p(cam), w, h, _p(o))
     return o
 
 
 def sensor_ray(sens, x, y):
     d = np.zeros(3)
-    lib().orc_sensor_ray(_p(_f64(sens)), x, y, _p(d))
+    sens = _f64(sens)
+    lib().orc_sensor_ray(_p(sens), x, y, _p(d))
     return d
 
 
 def v3d_to_rgb(v):
     o = np.zeros(3, dtype=np.uint8)
-    lib().orc_v3d_to_rgb(_p(_f64(v)), _p(o))
+    v = _f64(v)
+    lib().orc_v3d_to_rgb(_p(v), _p(o))
     return o
 
 

@@ -432,7 +432,15 @@ def test_textured_material():
         s.add_triangle([[0, -4, 0], [6, -4, 0], [0, 4, 0]], n, [[0, 0, 0], [1, 0, 0], [0, 1, 0]], mtl=b, line_no=2)
     flat = m.flatten()
     assert sorted(t["texels"].dtype.name for t in flat["textures"]) == ["float64", "uint8"]
-    _render_both(m, o, (0, 0, -8, 0, 0, 0, 80), 96, 64, [(0, 0, -6, .4, .4, .4, .7, .7, .7, .2, .2, .2)])
+    # the materials arrived as given (ka, kd, ks are distinct vectors)
+    d, has_tex = m.get_material("b")
+    assert has_tex and np.allclose(d[0:3], (.9, .8, .7)) and np.allclose(d[3:6], (.5, .5, .5))
+    g = _render_both(m, o, (0, 0, -8, 0, 0, 0, 80), 96, 64, [(0, 0, -6, .4, .4, .4, .7, .7, .7, .2, .2, .2)])
+    rgb = g["rgb"]
+    assert rgb.max() > 100, "the textured triangles must not be black"
+    # the colour depends on the texels: many distinct values on each triangle
+    left, right = rgb[:, :48].reshape(-1, 3), rgb[:, 48:].reshape(-1, 3)
+    assert len(np.unique(left, axis=0)) > 20 and len(np.unique(right, axis=0)) > 20
 
 
 def test_axis_aligned_camera_hits_the_nan_paths():
@@ -463,9 +471,19 @@ def test_big_frames_identical_to_reference(scenes):
         assert hashlib.sha256(g["line"].astype("<i4").tobytes()).hexdigest() == frames[key]["line_sha256"]
         sha = hashlib.sha256(g["rgb"].tobytes()).hexdigest()
         print(key, "frame sha256", sha, "reference", frames[key]["sha256"], "kernel ms", g["kernel_ms"])
+        n_diff = 0
         if sha != frames[key]["sha256"]:
-            pytest.xfail("frame differs from the reference in some pixels' last bit (pow); "
-                         "sub-sampled comparison above passed")
+            # Not the reference's bytes: count the differing pixels against the
+            # oracle (bit-identical to the reference on this frame, see
+            # test_oracle_golden.py) and hold them to the pow tolerance.
+            o = orclib.OracleScene(scenes[scene])
+            o.set_lights(scenegen.ROOM_LIGHTS)
+            want = o.render(scenegen.ROOM_CAMERA, W, H)["rgb"]
+            assert hashlib.sha256(want.tobytes()).hexdigest() == frames[key]["sha256"]
+            n_diff = int((g["rgb"] != want).any(axis=-1).sum())
+            assert_rgb_close(g["rgb"], want, key + " (full frame)")
+        print(key, "pixels differing from the reference frame:", n_diff, "of", W * H)
+        assert n_diff <= W * H // 10000
 
 
 @pytest.mark.parametrize("scale,offset", [(1e-4, 0.0), (3e4, 0.0), (1.0, 2.5e6), (7.0, -9.1e5)])

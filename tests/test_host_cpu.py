@@ -138,6 +138,24 @@ def test_octree_and_triangles_equal_the_oracle(scene, scenes):
     assert np.array_equal(f["tri_line_no"], lm[tm["prim_ids"]])
 
 
+def test_programmatic_materials_arrive_as_given():
+    """The ctypes shims must keep every converted array alive across the call:
+    ka, kd, ks and tf are four distinct vectors on the C side, for the facade
+    and for the oracle alike (a freed temporary made them all equal once)."""
+    import orclib
+    ka, kd, ks, tf = (.1, .2, .3), (.4, .5, .6), (.7, .8, .9), (.11, .22, .33)
+    m = M.MythTracer()
+    m.add_material("a", ka, kd, ks, ns=7, refl=.25, tr=.5, tf=tf, ni=1.5)
+    d, has_tex = m.get_material("a")
+    assert not has_tex
+    assert np.array_equal(d, np.array(ka + kd + ks + (7, .25, .5) + tf + (1.5,)))
+    o = orclib.OracleScene()
+    o.add_material("a", ka, kd, ks, ns=7, refl=.25, tr=.5, tf=tf, ni=1.5)
+    name, od, tex = o.materials()[0]
+    assert name == "a" and tex < 0
+    assert np.array_equal(od, d)
+
+
 def test_root_box_always_contains_the_origin():
     """OctTree's root box starts as {0,0,0}-{0,0,0} and only grows (octtree.cc:8-14)."""
     m = M.MythTracer()
