@@ -51,14 +51,8 @@ struct mt_scene {
   int lights_cap = 0;
   unsigned long long *d_counters = nullptr;
   unsigned int *d_work = nullptr;
-  double *d_frames = nullptr;
-  size_t frames_bytes = 0;
-  int32_t *d_hit_prim = nullptr;   // launch 1 -> launch 2 hand-off (per pixel)
-  size_t hit_prim_bytes = 0;
-  double *d_hit_t = nullptr;
-  size_t hit_t_bytes = 0;
-  unsigned int *d_class_list = nullptr;  // [3][n_items]
-  size_t class_list_bytes = 0;
+  char *d_pool = nullptr;          // ray pool scratch of every wave (mt_render.hip)
+  size_t pool_bytes = 0;
   // cost feedback (schedule_kernel): valid for launches of the same geometry
   unsigned int *d_item_cost = nullptr;   // [n_items]
   size_t item_cost_bytes = 0;
@@ -119,16 +113,17 @@ int configure_launch(mt_scene *s) {
   }
   s->waves_per_block = wpb;
   s->lds_bytes = per_wave * wpb;
-  HIP_TRY(hipFuncSetAttribute((const void *)render_kernel<true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-  HIP_TRY(hipFuncSetAttribute((const void *)render_kernel<false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-  HIP_TRY(hipFuncSetAttribute((const void *)primary_kernel<true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-  HIP_TRY(hipFuncSetAttribute((const void *)primary_kernel<false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
-  HIP_TRY(hipFuncSetAttribute((const void *)intersect_kernel,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+  // The attribute is per-function process state: keep it at the largest size
+  // any scene of this process needs (a shallower scene must not lower it).
+  static size_t lds_attr = 0;
+  if (s->lds_bytes > lds_attr) {
+    const void *kernels[] = {(const void *)render_kernel<true>, (const void *)render_kernel<false>,
+                             (const void *)probe_kernel, (const void *)intersect_kernel};
+    for (const void *k : kernels) {
+      HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+    }
+    lds_attr = s->lds_bytes;
+  }
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_kernel<true>,
                                                        wpb * 64, s->lds_bytes));
@@ -178,21 +173,28 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   P.counters = s->d_counters;
   P.work_counter = s->d_work;
   const size_t waves = (size_t)s->grid_blocks * s->waves_per_block;
-  const size_t fbytes = waves * (size_t)(max_depth > 0 ? max_depth : 1) * kFrameSlots * 64 * sizeof(double);
   {
-    int rc = ensure_bytes((void **)&s->d_frames, &s->frames_bytes, fbytes);
+    // Ray pool: records per wave.  64 * (2^(max_depth+1) - 1) is every call of
+    // every pixel's recursion tree at once; beyond kPoolCapMax the kernel's
+    // throttle keeps the pool within the capacity (depth first).
+    const int n_l = s->dev.n_lights;
+    if (n_l > 254) return fail(MT_ERR_UNSUPPORTED, "%d lights: the ray pool addresses at most 254", n_l);
+    constexpr long long kPoolCapMax = 1024;
+    const long long all = 64ll * ((2ll << max_depth) - 1);
+    const long long floor_cap = 64 + 128 + 4ll * (max_depth + 1) + 64;
+    long long cap = all < kPoolCapMax ? all : kPoolCapMax;
+    if (cap < floor_cap) cap = floor_cap;
+    const size_t rec_bytes = (size_t)(kRecFixed + kLightSlot * n_l) * sizeof(double);
+    size_t stride = (size_t)cap * rec_bytes + (size_t)cap * (size_t)(n_l > 0 ? n_l : 1) * 4 + (size_t)cap * 4;
+    stride = (stride + 255) & ~(size_t)255;
+    int rc = ensure_bytes((void **)&s->d_pool, &s->pool_bytes, stride * waves);
     if (rc != MT_OK) return rc;
+    P.pool_scratch = s->d_pool;
+    P.pool_stride = stride;
+    P.pool_cap = (int)cap;
   }
-  P.frames = s->d_frames;
   {
-    const size_t slots_px = (size_t)n_tiles * (size_t)tile_w * (size_t)tile_h;
-    int rc = ensure_bytes((void **)&s->d_hit_prim, &s->hit_prim_bytes, slots_px * sizeof(int32_t));
-    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_hit_t, &s->hit_t_bytes, slots_px * sizeof(double));
-    if (rc == MT_OK) {
-      rc = ensure_bytes((void **)&s->d_class_list, &s->class_list_bytes,
-                        3 * (size_t)P.n_items * sizeof(unsigned int));
-    }
-    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_item_cost, &s->item_cost_bytes, (size_t)P.n_items * 4);
+    int rc = ensure_bytes((void **)&s->d_item_cost, &s->item_cost_bytes, (size_t)P.n_items * 4);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_item, &s->order_item_bytes, (size_t)P.n_items * 16);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_sub, &s->order_sub_bytes, (size_t)P.n_items * 4);
     if (rc != MT_OK) return rc;
@@ -203,8 +205,8 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   P.n_work = s->d_work + 7;
   // The block costs of the previous launch are a valid forecast when that
   // launch had the same geometry (an animation frame, main_local.cc:79-110, or
-  // a repeated benchmark step).  Then one launch does everything, blocks
-  // longest first; otherwise launch 1 classifies the blocks by material first.
+  // a repeated benchmark step); otherwise probe_kernel makes one from 1/64 of
+  // the primary rays.  Either way schedule_kernel turns it into the work order.
   unsigned long long sig = 1469598103934665603ull;
   {
     const long long key[] = {image_w, image_h, rx, ry, rw, rh, tile_w, tile_h, first_tile, tile_stride,
@@ -214,12 +216,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     }
     if (sig == 0) sig = 1;
   }
-  const bool history = s->use_history && s->cost_signature == sig && d_debug == nullptr;
-  P.from_primary = history ? 0 : 1;
-  P.hit_prim = s->d_hit_prim;
-  P.hit_t = s->d_hit_t;
-  P.class_list = s->d_class_list;
-  P.class_count = s->d_work + 4;  // d_work: [0..1] work counters, [4..6] class counts
+  const bool history = s->use_history && s->cost_signature == sig;
   P.item_cycles = nullptr;
   unsigned long long *d_item = nullptr;
   const char *item_dump = getenv("MT_DEBUG_ITEM_CYCLES");
@@ -232,21 +229,26 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   if (P.n_items == 0) return MT_OK;
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
   HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
-  // launch 1: primary rays + cost classes; launch 2: shading, heavy blocks first
+  // [0] -> [1]: forecast (if there is no history) + work order; [1] -> [2]: the frame
   hipEvent_t *ek = s->ev_k[s->launches_timed % mt_scene::kTimedLaunches];
   for (int i = 0; i < 3; i++) {
     if (!ek[i]) HIP_TRY(hipEventCreate(&ek[i]));
   }
   HIP_TRY(hipEventRecord(ek[0], stream));
-  if (history) {
-    float quad_share = 0.8f;  // blocks above this share of an even split are cut into quarters
+  if (!history) {
+    hipLaunchKernelGGL(probe_kernel, dim3((P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream,
+                       s->dev, P);
+    HIP_TRY(hipGetLastError());
+  }
+  {
+    // blocks above quad_share of an even split of the frame are cut into quarters
+    float quad_share = 0.8f, quad_work = 1.25f, quarter_time = 0.35f;
     if (const char *e = getenv("MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
+    if (const char *e = getenv("MT_DEBUG_QUAD_WORK")) quad_work = (float)atof(e);
+    if (const char *e = getenv("MT_DEBUG_QUARTER_TIME")) quarter_time = (float)atof(e);
     hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
-                       s->grid_blocks * s->waves_per_block, quad_share);
-  } else if (s->stats_enabled) {
-    hipLaunchKernelGGL(primary_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
-  } else {
-    hipLaunchKernelGGL(primary_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
+                       s->grid_blocks * s->waves_per_block, quad_share, quad_work, quarter_time);
+    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(ek[1], stream));
   if (s->stats_enabled) {
@@ -340,10 +342,7 @@ void mt_scene_destroy(mt_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void *p : s->allocs) (void)hipFree(p);
-  if (s->d_frames) (void)hipFree(s->d_frames);
-  if (s->d_hit_prim) (void)hipFree(s->d_hit_prim);
-  if (s->d_hit_t) (void)hipFree(s->d_hit_t);
-  if (s->d_class_list) (void)hipFree(s->d_class_list);
+  if (s->d_pool) (void)hipFree(s->d_pool);
   if (s->d_item_cost) (void)hipFree(s->d_item_cost);
   if (s->d_order_item) (void)hipFree(s->d_order_item);
   if (s->d_order_sub) (void)hipFree(s->d_order_sub);

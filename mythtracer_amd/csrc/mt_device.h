@@ -98,7 +98,8 @@ enum {
 // Every data-dependent loop in the kernels carries an iteration bound derived
 // from the scene size, so that a logic error ends the launch with a status code
 // instead of hanging the GPU.
-enum { DEV_OK = 0, DEV_ERR_TRAVERSAL_BOUND = 1, DEV_ERR_UNWIND_BOUND = 2, DEV_ERR_PIXEL_BOUND = 3 };
+enum { DEV_OK = 0, DEV_ERR_TRAVERSAL_BOUND = 1, DEV_ERR_UNWIND_BOUND = 2, DEV_ERR_PIXEL_BOUND = 3,
+       DEV_ERR_POOL = 4 };
 
 // Tiling of one launch (see mt_render_tiles_device in the C ABI).
 struct RenderParams {
@@ -115,20 +116,19 @@ struct RenderParams {
   uint8_t *out_rgb;
   mt_debug_px *out_debug;  // nullable; same slot layout as out_rgb
   unsigned long long *counters;  // ST_COUNT
-  unsigned int *work_counter;     // [0] launch 1, [1] launch 2
-  int32_t *hit_prim;              // primary hit per pixel (slot layout of out_rgb)
-  double *hit_t;
-  unsigned int *class_count;      // [3] blocks per cost class
-  unsigned int *class_list;       // [3][n_items] block ids per class
-  double *frames;          // recursion frames scratch
+  unsigned int *work_counter;     // [1] work units handed out so far
+  // Ray pool scratch (mt_render.hip): per wave pool_cap records, the pool of
+  // pending rays and the free list, pool_stride bytes apart.
+  char *pool_scratch;
+  size_t pool_stride;
+  int32_t pool_cap;
   // Cost feedback between frames of the same launch geometry (see
-  // schedule_kernel): s_memtime ticks each block took in the previous frame,
-  // and the work order derived from them.
+  // schedule_kernel): s_memtime ticks each block took in the previous frame
+  // (or probe_kernel's forecast), and the work order derived from them.
   unsigned int *item_cost;        // [n_items] ticks (>> 6) of the last frame; quarters add up
   unsigned int *order_item;       // [<= 4 n_items] block id of work unit w
-  signed char *order_sub;         // [<= 4 n_items] -1 = whole block, 0..3 = quarter (4 lanes per pixel)
+  signed char *order_sub;         // [<= 4 n_items] -1 = whole block, 0..3 = quarter
   unsigned int *n_work;           // number of work units in order_item/order_sub
-  int32_t from_primary;           // 1: launch 1 ran (hit_prim/hit_t, class lists); 0: order_* lists
   unsigned long long *item_cycles;  // debug (MT_DEBUG_ITEM_CYCLES): s_memtime ticks per work item
 };
 
@@ -138,7 +138,5 @@ struct RenderParams {
 __host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
   return (size_t)depth * 64 * (packed ? 16 : 20) + 4 * 64 * 4;
 }
-
-constexpr int kFrameSlots = 11;  // 10 doubles + 1 packed meta word per frame
 
 }  // namespace mt

@@ -29,6 +29,23 @@
 //                                    (3 f64 each) via Camera::Sensor::GetRay
 //   repeat <n>                       time n renders, report the best
 //   out_time <file>                  JSON with wall-clock seconds of RayTrace
+//   tree <out.bin>                   the finalized octree, breadth-first (the
+//                                    8 children of a node consecutive, root
+//                                    first).  Header: i32 n_nodes; per node:
+//                                    6 f64 aabb (min, max), 3 f64 center,
+//                                    i32 has_children, i32 n_prims, then
+//                                    n_prims x i32 debug_line_no in the order
+//                                    of Node::primitives.  (OctTree::root is
+//                                    private: octtree.h is included with
+//                                    `private` defined away, which does not
+//                                    change the layout of the class.)
+//   wire <out.bin>                   bytes of WorkChunk::SerializeInput for the
+//                                    job's image/chunk (24), Camera::Serialize
+//                                    for its camera (56) and, if out_rgb was
+//                                    rendered, WorkChunk::SerializeOutput
+//   wire_in <file>                   one candidate WorkChunk input blob per
+//                                    24 bytes; appends to the `wire` output one
+//                                    byte per blob: DeserializeInput's verdict
 #include <chrono>
 #include <cmath>
 #include <cstdint>
@@ -40,9 +57,17 @@
 #include <vector>
 #include <omp.h>
 
+#include <deque>
+#include <list>
+#include <memory>
+#include <utility>
+
+// test-only access to OctTree::root for the `tree` dump (see above)
+#define private public
+#include "octtree.h"
+#undef private
 #include "mythtracer.h"
 #include "camera.h"
-#include "octtree.h"
 
 using math3d::V3D;
 using raytracer::Camera;
@@ -61,7 +86,7 @@ struct Job {
   int cx = 0, cy = 0, cw = -1, ch = -1;
   double cam[7] = {0, 0, 0, 0, 0, 0, 60};
   std::vector<Light> lights;
-  std::string out_rgb, out_debug, rays_in, rays_out, sensor_out, out_time;
+  std::string out_rgb, out_debug, rays_in, rays_out, sensor_out, out_time, tree_out, wire_out, wire_in;
   int repeat = 1;
 };
 
@@ -99,6 +124,12 @@ bool ParseJob(const char *path, Job *job) {
       s >> job->rays_in >> job->rays_out;
     } else if (key == "sensor") {
       s >> job->sensor_out;
+    } else if (key == "tree") {
+      s >> job->tree_out;
+    } else if (key == "wire") {
+      s >> job->wire_out;
+    } else if (key == "wire_in") {
+      s >> job->wire_in;
     } else if (key == "repeat") {
       s >> job->repeat;
     } else if (key == "out_time") {
@@ -165,6 +196,7 @@ int main(int argc, char **argv) {
     mt.GetScene()->tree.Finalize();
   }
 
+  std::vector<uint8_t> wire_output;  // SerializeOutput of the rendered chunk
   if (job.W > 0 && (!job.out_rgb.empty() || !job.out_debug.empty() ||
                     !job.out_time.empty())) {
     double best = 1e300;
@@ -183,6 +215,9 @@ int main(int argc, char **argv) {
         !WriteFile(job.out_rgb, chunk.output_bitmap.data(),
                    chunk.output_bitmap.size())) {
       return 1;
+    }
+    if (!job.wire_out.empty() && !job.out_rgb.empty()) {
+      if (!chunk.SerializeOutput(&wire_output)) return 1;
     }
     if (!job.out_debug.empty()) {
       std::vector<uint8_t> buf(chunk.output_debug.size() * 28);
@@ -203,6 +238,59 @@ int main(int argc, char **argv) {
                        (long long)job.cw * job.ch);
       if (!WriteFile(job.out_time, js, (size_t)n)) return 1;
     }
+  }
+
+  if (!job.tree_out.empty()) {
+    using Node = raytracer::OctTree::Node;
+    std::vector<uint8_t> out;
+    auto put = [&out](const void *p, size_t n) {
+      const uint8_t *b = (const uint8_t *)p;
+      out.insert(out.end(), b, b + n);
+    };
+    std::deque<const Node *> queue{&mt.GetScene()->tree.root};
+    std::vector<const Node *> order;
+    while (!queue.empty()) {
+      const Node *n = queue.front();
+      queue.pop_front();
+      order.push_back(n);
+      for (const Node &c : n->nodes) queue.push_back(&c);
+    }
+    int32_t nn = (int32_t)order.size();
+    put(&nn, 4);
+    for (const Node *n : order) {
+      put(n->aabb.min.v, 24);
+      put(n->aabb.max.v, 24);
+      put(n->center.v, 24);
+      int32_t hc = n->nodes.empty() ? 0 : 1, np = (int32_t)n->primitives.size();
+      put(&hc, 4);
+      put(&np, 4);
+      for (const Primitive *p : n->primitives) {
+        int32_t ln = p->debug_line_no;
+        put(&ln, 4);
+      }
+    }
+    if (!WriteFile(job.tree_out, out.data(), out.size())) return 1;
+  }
+
+  if (!job.wire_out.empty()) {
+    std::vector<uint8_t> out, b;
+    WorkChunk chunk{job.W, job.H, job.cx, job.cy, job.cw, job.ch, cam, {}, {}};
+    chunk.SerializeInput(&b);
+    out.insert(out.end(), b.begin(), b.end());
+    cam.Serialize(&b);
+    out.insert(out.end(), b.begin(), b.end());
+    out.insert(out.end(), wire_output.begin(), wire_output.end());
+    if (!job.wire_in.empty()) {
+      std::ifstream in(job.wire_in, std::ios::binary);
+      std::vector<char> raw((std::istreambuf_iterator<char>(in)),
+                            std::istreambuf_iterator<char>());
+      for (size_t i = 0; i + 24 <= raw.size(); i += 24) {
+        WorkChunk w{};
+        std::vector<uint8_t> blob(raw.begin() + i, raw.begin() + i + 24);
+        out.push_back(w.DeserializeInput(blob) ? 1 : 0);
+      }
+    }
+    if (!WriteFile(job.wire_out, out.data(), out.size())) return 1;
   }
 
   if (!job.rays_in.empty()) {

@@ -169,8 +169,87 @@ def big_frames(td):
     json.dump(frames, open(fpath, "w"), indent=1, sort_keys=True)
 
 
+def parse_tree_dump(raw: bytes):
+    """ref_driver's `tree` dump -> arrays (see oracle/ref_driver.cc)."""
+    n = int(np.frombuffer(raw, dtype="<i4", count=1)[0])
+    off = 4
+    aabb, center = np.zeros((n, 6)), np.zeros((n, 3))
+    has_children, n_prims = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    lines = []
+    for i in range(n):
+        aabb[i] = np.frombuffer(raw, dtype="<f8", count=6, offset=off)
+        center[i] = np.frombuffer(raw, dtype="<f8", count=3, offset=off + 48)
+        has_children[i], n_prims[i] = np.frombuffer(raw, dtype="<i4", count=2, offset=off + 72)
+        off += 80
+        lines.append(np.frombuffer(raw, dtype="<i4", count=int(n_prims[i]), offset=off))
+        off += 4 * int(n_prims[i])
+    assert off == len(raw)
+    return dict(aabb=aabb, center=center, has_children=has_children, n_prims=n_prims,
+                lines=np.concatenate(lines) if lines else np.zeros(0, dtype=np.int32))
+
+
+WIRE_CANDIDATES = [
+    [1920, 1080, 128, 256, 128, 128], [0, 10, 0, 0, 1, 1], [10, 10, 0, 0, 0, 1], [10, 10, 5, 5, 6, 1],
+    [100001, 10, 0, 0, 1, 1], [100000, 100000, 0, 0, 1, 1], [10, 10, 11, 0, 1, 1], [10, 10, 10, 0, 1, 1],
+    [10, 10, 0, 0, 11, 1], [10, 10, 0, 0, 10, 10], [10, 10, 9, 9, 1, 1], [10, 10, 9, 9, 2, 1],
+    [7, 5, 0, 4, 7, 1], [7, 5, 0, 5, 7, 1], [0xffffffff, 5, 0, 0, 1, 1], [10, 10, 0xfffffff0, 0, 32, 1],
+]
+
+
+def tree_and_wire_cases(td):
+    """Octree topology (per node: box, centre, ordered debug_line_no list) and the
+    wire bytes of WorkChunk / Camera, dumped from the compiled reference."""
+    scenes = os.path.join(td, "scenes")
+    trees = {}
+    for name in ("cornell", "mini", "room"):
+        obj = CORNELL if name == "cornell" else scenegen.write_scene(name, scenes)["obj"]
+        wd = os.path.join(td, "tree_" + name)
+        os.makedirs(wd, exist_ok=True)
+        job = os.path.join(wd, "job.txt")
+        out = os.path.join(wd, "tree.bin")
+        open(job, "w").write("obj %s\nimage 0 0\ntree %s\n" % (obj, out))
+        import subprocess
+        subprocess.check_call([orclib.REF_DRIVER, job])
+        raw = open(out, "rb").read()
+        t = parse_tree_dump(raw)
+        trees[name] = {"sha256": hashlib.sha256(raw).hexdigest(), "n_nodes": int(len(t["n_prims"])),
+                       "n_prims": int(t["n_prims"].sum())}
+        if name != "room":  # the room's dump is 1.9 MB: its hash is kept, the small trees in full
+            np.savez_compressed(os.path.join(HERE, "tree_%s.npz" % name), **t)
+        print("tree", name, trees[name])
+    json.dump(trees, open(os.path.join(HERE, "trees.json"), "w"), indent=1, sort_keys=True)
+    # wire bytes: one rendered chunk of the Cornell scene
+    wd = os.path.join(td, "wire")
+    os.makedirs(wd, exist_ok=True)
+    cand = np.array(WIRE_CANDIDATES, dtype="<u4")
+    cand.tofile(os.path.join(wd, "cand.bin"))
+    cam = CORNELL_CAM2
+    job = ["obj %s" % CORNELL, "image 96 64", "chunk 13 7 20 9",
+           "camera " + " ".join(repr(float(c)) for c in cam)]
+    for l in CORNELL_LIGHTS2:
+        job.append("light " + " ".join(repr(float(c)) for c in l))
+    job += ["out_rgb %s" % os.path.join(wd, "out.raw"), "wire %s" % os.path.join(wd, "wire.bin"),
+            "wire_in %s" % os.path.join(wd, "cand.bin")]
+    open(os.path.join(wd, "job.txt"), "w").write("\n".join(job) + "\n")
+    import subprocess
+    subprocess.check_call([orclib.REF_DRIVER, os.path.join(wd, "job.txt")])
+    raw = np.fromfile(os.path.join(wd, "wire.bin"), dtype=np.uint8)
+    n_out = 4 + 20 * 9 * 3
+    assert raw.size == 24 + 56 + n_out + len(WIRE_CANDIDATES)
+    np.savez_compressed(os.path.join(HERE, "wire.npz"), image=np.array([96, 64], dtype=np.int32),
+                        chunk=np.array([13, 7, 20, 9], dtype=np.int32), cam=np.array(cam, dtype=np.float64),
+                        lights=np.array(CORNELL_LIGHTS2, dtype=np.float64),
+                        input_bytes=raw[:24], camera_bytes=raw[24:80], output_bytes=raw[80:80 + n_out],
+                        candidates=cand.astype(np.uint32), verdicts=raw[80 + n_out:])
+    print("wire", raw[:24].tobytes().hex(), "verdicts", list(raw[80 + n_out:]))
+
+
 def main():
     assert orclib.have_ref(), "build the reference first: make -C oracle ref"
+    if "--tree-wire-only" in sys.argv:
+        with tempfile.TemporaryDirectory() as td:
+            tree_and_wire_cases(td)
+        return
     with tempfile.TemporaryDirectory() as td:
         scenes = os.path.join(td, "scenes")
         mini = scenegen.write_scene("mini", scenes)
@@ -198,6 +277,7 @@ def main():
         ray_case(td, "rays_room", room["obj"], random_rays(13, 400, (0, 0, 0), (400, 250, 400)))
         meta = {"mini": mini["sha256"], "mini_nomtl": mini_n["sha256"], "room": room["sha256"]}
         json.dump(meta, open(os.path.join(HERE, "scene_hashes.json"), "w"), indent=1, sort_keys=True)
+        tree_and_wire_cases(td)
         if "--big" in sys.argv:
             big_frames(td)
 
