@@ -201,10 +201,24 @@ int mt_scene_read_stats(mt_scene *scene, mt_stats *stats);
  * reference hands rows to a thread pool, mythtracer.cc:244-290.) */
 int mt_scene_set_scheduling(mt_scene *scene, int use_cost_history);
 
+/* Frame engine.  Two implementations of TraceRayWorker's control flow exist;
+ * every pixel goes through the same operations in the same order in both, so
+ * the output does not depend on the choice.  1 = throughput engine: one lane
+ * per pixel runs the recursion as a state machine (lowest cost per ray).  2 =
+ * latency engine: the recursion of every pixel is unrolled into a per-wave pool
+ * of rays, so that a call's shadow loops and child calls are traced side by
+ * side (shortest chain of dependent passes per pixel; wins when a launch has
+ * few blocks per wave, e.g. one rank's share of a multi-GPU frame).  0 =
+ * automatic (default): 2 for launches with fewer than 6 blocks per resident
+ * wave, else 1.  Also forgets the recorded costs.  (No reference counterpart.) */
+int mt_scene_set_engine(mt_scene *scene, int engine);
+
 /* Device durations of the launches made since the previous call (at most the
- * last 64, oldest first; at most max_n): primary_ms[i] = mt::primary_kernel
- * (or mt::schedule_kernel when the launch used the cost history),
- * render_ms[i] = mt::render_kernel of launch i, from HIP events recorded on
+ * last 64, oldest first; at most max_n): primary_ms[i] = the kernels that
+ * prepare the work order (mt::schedule_kernel with cost history, else
+ * mt::primary_kernel; for the latency engine mt::probe_kernel +
+ * mt::pool_schedule_kernel), render_ms[i] = the frame kernel
+ * (mt::render_kernel or mt::pool_kernel) of launch i, from HIP events recorded on
  * the launch's own stream.  Waits for those launches.  Returns the number of
  * entries written, or a negative MT_ERR_*.  (No reference counterpart: the
  * reference times a frame with wall clocks, main_local.cc:86-101.) */
@@ -225,7 +239,8 @@ int mt_intersect_rays(mt_scene *scene, int n, const double *rays,
  * pre-filter, 5 = automatic but every node through a wave step (no
  * lane-parallel scan of small nodes), 6 = automatic but without the block
  * boxes that skip runs of triangles, 7 = automatic but without the subtree
- * boxes that skip children.  Results are identical in every mode; the
+ * boxes that skip children.  Results are identical in every
+ * mode; the
  * counters box_tests / node_visits / tri_tests equal the reference's
  * un-pruned traversal in modes 1, 2, 4 and 7 (no subtree is skipped there)
  * and count only the nodes actually visited in the others. */

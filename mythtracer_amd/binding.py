@@ -20,7 +20,7 @@ HIP_SYMBOLS = [
     "mt_scene_destroy", "mt_scene_set_lights", "mt_render_chunk",
     "mt_render_chunk_device", "mt_render_tiles_device", "mt_blit_tiles_device",
     "mt_scene_read_stats", "mt_intersect_rays", "mt_scene_set_traversal_mode",
-    "mt_scene_kernel_times", "mt_scene_set_scheduling",
+    "mt_scene_kernel_times", "mt_scene_set_scheduling", "mt_scene_set_engine",
 ]
 
 STAT_NAMES = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests",
@@ -123,6 +123,8 @@ class HipAbi:
         L.mt_scene_set_traversal_mode.argtypes = [vp, ci]
         L.mt_scene_kernel_times.argtypes = [vp, ci, vp, vp]
         L.mt_scene_set_scheduling.argtypes = [vp, ci]
+        if hasattr(L, "mt_scene_set_engine"):  # absent from older builds loaded by the A/B scripts
+            L.mt_scene_set_engine.argtypes = [vp, ci]
 
     def last_error(self) -> str:
         return self.lib.mt_last_error().decode(errors="replace")
@@ -248,6 +250,10 @@ class HipAbi:
         st = mt_stats()
         self.check(self.lib.mt_scene_read_stats(h, C.byref(st)))
         return st.as_dict()
+
+    def set_engine(self, h, engine: int):
+        """0 = automatic, 1 = throughput engine (state machine), 2 = latency engine (ray pool)."""
+        self.check(self.lib.mt_scene_set_engine(h, int(engine)))
 
     def set_scheduling(self, h, use_cost_history: bool):
         self.check(self.lib.mt_scene_set_scheduling(h, 1 if use_cost_history else 0))

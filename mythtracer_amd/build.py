@@ -68,6 +68,15 @@ def build_prof(verbose: bool = False) -> str:
     return out
 
 
+def build_diag(verbose: bool = False) -> str:
+    """Diagnostic variant with per-unit step counters (-DMT_DIAG); never used by tests or bench."""
+    out = os.path.join(LIB, "libmythtracer_hip_diag.so")
+    cmd = [HIPCC] + HIP_FLAGS + ["-DMT_DIAG", "-I", INC, "-I", CSRC, "-o", out,
+                                 os.path.join(CSRC, "mt_capi.hip")]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_host(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB, exist_ok=True)
     srcs = _files(os.path.join(HOST, "src"), (".cc",))
@@ -89,6 +98,9 @@ def build_all(force: bool = False, verbose: bool = False):
 
 
 if __name__ == "__main__":
+    if "--diag" in sys.argv:
+        print("built:", build_diag())
+        sys.exit(0)
     if "--prof" in sys.argv:
         print("built:", build_prof())
         sys.exit(0)

@@ -51,8 +51,18 @@ struct mt_scene {
   int lights_cap = 0;
   unsigned long long *d_counters = nullptr;
   unsigned int *d_work = nullptr;
-  char *d_pool = nullptr;          // ray pool scratch of every wave (mt_render.hip)
+  double *d_frames = nullptr;      // throughput engine: recursion frames
+  size_t frames_bytes = 0;
+  int32_t *d_hit_prim = nullptr;   // launch 1 -> launch 2 hand-off (per pixel)
+  size_t hit_prim_bytes = 0;
+  double *d_hit_t = nullptr;
+  size_t hit_t_bytes = 0;
+  unsigned int *d_class_list = nullptr;  // [3][n_items]
+  size_t class_list_bytes = 0;
+  char *d_pool = nullptr;          // latency engine: ray pool scratch of every wave (mt_pool.h)
   size_t pool_bytes = 0;
+  int engine = 0;                  // 0 = automatic, 1 = throughput (state machine), 2 = latency (ray pool)
+  int last_engine = 0;             // engine of the previous launch (cost histories are per engine)
   // cost feedback (schedule_kernel): valid for launches of the same geometry
   unsigned int *d_item_cost = nullptr;   // [n_items]
   size_t item_cost_bytes = 0;
@@ -118,6 +128,8 @@ int configure_launch(mt_scene *s) {
   static size_t lds_attr = 0;
   if (s->lds_bytes > lds_attr) {
     const void *kernels[] = {(const void *)render_kernel<true>, (const void *)render_kernel<false>,
+                             (const void *)primary_kernel<true>, (const void *)primary_kernel<false>,
+                             (const void *)pool_kernel<true>, (const void *)pool_kernel<false>,
                              (const void *)probe_kernel, (const void *)intersect_kernel};
     for (const void *k : kernels) {
       HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
@@ -173,7 +185,32 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   P.counters = s->d_counters;
   P.work_counter = s->d_work;
   const size_t waves = (size_t)s->grid_blocks * s->waves_per_block;
+  // ---- which engine?  Both compute every pixel with the same operations in the
+  // same order (tests render through both).  The state machine (one lane per
+  // pixel, its context in registers) has the lower cost per ray and is the
+  // default; the ray pool has the shorter chain of dependent passes per pixel
+  // and takes over when a launch is bound by its longest work unit rather than
+  // by its amount of work, i.e. when there are few blocks per wave (a rank's
+  // share of a multi-GPU frame, a small chunk).
+  int engine = s->engine;
+  if (const char *e = getenv("MT_ENGINE")) engine = atoi(e);
+  if (engine != 1 && engine != 2) {
+    float per_wave = 6.0f;  // blocks per wave below which a launch is taken to be tail-bound
+    if (const char *e = getenv("MT_DEBUG_POOL_BELOW")) per_wave = (float)atof(e);
+    engine = ((float)P.n_items < per_wave * (float)waves) ? 2 : 1;
+  }
+  const bool pool_engine = engine == 2;
   {
+    int rc = ensure_bytes((void **)&s->d_item_cost, &s->item_cost_bytes, (size_t)P.n_items * 4);
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_item, &s->order_item_bytes, (size_t)P.n_items * 64);
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_sub, &s->order_sub_bytes, (size_t)P.n_items * 16);
+    if (rc != MT_OK) return rc;
+  }
+  P.item_cost = s->d_item_cost;
+  P.order_item = s->d_order_item;
+  P.order_sub = s->d_order_sub;
+  P.n_work = s->d_work + 7;
+  if (pool_engine) {
     // Ray pool: records per wave.  64 * (2^(max_depth+1) - 1) is every call of
     // every pixel's recursion tree at once; beyond kPoolCapMax the kernel's
     // throttle keeps the pool within the capacity (depth first).
@@ -192,76 +229,107 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     P.pool_scratch = s->d_pool;
     P.pool_stride = stride;
     P.pool_cap = (int)cap;
-  }
-  {
-    int rc = ensure_bytes((void **)&s->d_item_cost, &s->item_cost_bytes, (size_t)P.n_items * 4);
-    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_item, &s->order_item_bytes, (size_t)P.n_items * 16);
-    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_sub, &s->order_sub_bytes, (size_t)P.n_items * 4);
+    P.prio_units = (unsigned)(s->n_cu * 4);  // one per SIMD
+  } else {
+    const size_t fbytes = waves * (size_t)(max_depth > 0 ? max_depth : 1) * kFrameSlots * 64 * sizeof(double);
+    const size_t slots_px = (size_t)n_tiles * (size_t)tile_w * (size_t)tile_h;
+    int rc = ensure_bytes((void **)&s->d_frames, &s->frames_bytes, fbytes);
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_hit_prim, &s->hit_prim_bytes, slots_px * sizeof(int32_t));
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_hit_t, &s->hit_t_bytes, slots_px * sizeof(double));
+    if (rc == MT_OK) {
+      rc = ensure_bytes((void **)&s->d_class_list, &s->class_list_bytes,
+                        3 * (size_t)P.n_items * sizeof(unsigned int));
+    }
     if (rc != MT_OK) return rc;
+    P.frames = s->d_frames;
+    P.hit_prim = s->d_hit_prim;
+    P.hit_t = s->d_hit_t;
+    P.class_list = s->d_class_list;
+    P.class_count = s->d_work + 4;  // d_work: [0..1] work counters, [4..6] class counts
   }
-  P.item_cost = s->d_item_cost;
-  P.order_item = s->d_order_item;
-  P.order_sub = s->d_order_sub;
-  P.n_work = s->d_work + 7;
   // The block costs of the previous launch are a valid forecast when that
-  // launch had the same geometry (an animation frame, main_local.cc:79-110, or
-  // a repeated benchmark step); otherwise probe_kernel makes one from 1/64 of
-  // the primary rays.  Either way schedule_kernel turns it into the work order.
+  // launch had the same geometry and engine (an animation frame,
+  // main_local.cc:79-110, or a repeated benchmark step).  Then the blocks are
+  // handed out longest first, the longest in pieces.  Otherwise: the state
+  // machine classifies the blocks by material in a launch of its own
+  // (primary_kernel); the ray pool forecasts from 1/64 of the primary rays
+  // (probe_kernel).
   unsigned long long sig = 1469598103934665603ull;
   {
     const long long key[] = {image_w, image_h, rx, ry, rw, rh, tile_w, tile_h, first_tile, tile_stride,
-                             n_tiles, max_depth, (long long)(size_t)s->d_item_cost, s->dev.n_lights};
+                             n_tiles, max_depth, (long long)(size_t)s->d_item_cost, s->dev.n_lights, engine};
     for (long long v : key) {
       sig = (sig ^ (unsigned long long)v) * 1099511628211ull;
     }
     if (sig == 0) sig = 1;
   }
-  const bool history = s->use_history && s->cost_signature == sig;
+  const bool history = s->use_history && s->cost_signature == sig && (pool_engine || d_debug == nullptr);
+  P.from_primary = history ? 0 : 1;
   P.item_cycles = nullptr;
   unsigned long long *d_item = nullptr;
   const char *item_dump = getenv("MT_DEBUG_ITEM_CYCLES");
   if (item_dump && P.n_items > 0) {
-    HIP_TRY(hipMalloc((void **)&d_item, (size_t)P.n_items * 4 * 16));
-    HIP_TRY(hipMemset(d_item, 0, (size_t)P.n_items * 4 * 16));
+    HIP_TRY(hipMalloc((void **)&d_item, (size_t)P.n_items * 16 * 16 * 3));
+    HIP_TRY(hipMemset(d_item, 0, (size_t)P.n_items * 16 * 16 * 3));
     P.item_cycles = d_item;
   }
   HIP_TRY(hipMemsetAsync(s->d_work, 0, 8 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
   HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
-  // [0] -> [1]: forecast (if there is no history) + work order; [1] -> [2]: the frame
+  // events: [0] -> [1] forecast / classification + work order; [1] -> [2] the frame kernel
   hipEvent_t *ek = s->ev_k[s->launches_timed % mt_scene::kTimedLaunches];
   for (int i = 0; i < 3; i++) {
     if (!ek[i]) HIP_TRY(hipEventCreate(&ek[i]));
   }
   HIP_TRY(hipEventRecord(ek[0], stream));
-  if (!history) {
-    hipLaunchKernelGGL(probe_kernel, dim3((P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream,
-                       s->dev, P);
+  if (pool_engine) {
+    if (!history) {
+      hipLaunchKernelGGL(probe_kernel, dim3((P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream,
+                         s->dev, P);
+      HIP_TRY(hipGetLastError());
+    }
+    // blocks above cut_share of an even split of the frame are handed out in pieces
+    SchedParams sp{0.8f, {1.0f, 0.35f, 0.12f}, {1.0f, 1.1f, 3.0f}, 3.0f};
+    if (const char *e = getenv("MT_DEBUG_CUT_SHARE")) sp.cut_share = (float)atof(e);
+    if (const char *e = getenv("MT_DEBUG_PIECE_TIME")) sscanf(e, "%f,%f", &sp.piece_time[1], &sp.piece_time[2]);
+    if (const char *e = getenv("MT_DEBUG_PIECE_WORK")) sscanf(e, "%f,%f", &sp.piece_work[1], &sp.piece_work[2]);
+    if (const char *e = getenv("MT_DEBUG_CELL_FACTOR")) sp.cell_factor = (float)atof(e);
+    hipLaunchKernelGGL(pool_schedule_kernel, dim3(1), dim3(kPoolSchedThreads), 0, stream, P,
+                       s->grid_blocks * s->waves_per_block, sp);
     HIP_TRY(hipGetLastError());
-  }
-  {
-    // blocks above quad_share of an even split of the frame are cut into quarters
-    float quad_share = 0.8f, quad_work = 1.25f, quarter_time = 0.35f;
-    if (const char *e = getenv("MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
-    if (const char *e = getenv("MT_DEBUG_QUAD_WORK")) quad_work = (float)atof(e);
-    if (const char *e = getenv("MT_DEBUG_QUARTER_TIME")) quarter_time = (float)atof(e);
-    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
-                       s->grid_blocks * s->waves_per_block, quad_share, quad_work, quarter_time);
-    HIP_TRY(hipGetLastError());
-  }
-  HIP_TRY(hipEventRecord(ek[1], stream));
-  if (s->stats_enabled) {
-    hipLaunchKernelGGL(render_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
+    HIP_TRY(hipEventRecord(ek[1], stream));
+    if (s->stats_enabled) {
+      hipLaunchKernelGGL(pool_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
+    } else {
+      hipLaunchKernelGGL(pool_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
+    }
   } else {
-    hipLaunchKernelGGL(render_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
+    if (history) {
+      float quad_share = 0.8f;  // blocks above this share of an even split are cut into quarters
+      if (const char *e = getenv("MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
+      hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
+                         s->grid_blocks * s->waves_per_block, quad_share);
+    } else if (s->stats_enabled) {
+      hipLaunchKernelGGL(primary_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
+    } else {
+      hipLaunchKernelGGL(primary_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ek[1], stream));
+    if (s->stats_enabled) {
+      hipLaunchKernelGGL(render_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
+    } else {
+      hipLaunchKernelGGL(render_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
+    }
   }
   HIP_TRY(hipEventRecord(ek[2], stream));
   HIP_TRY(hipGetLastError());
   s->launches_timed++;
-  s->cost_signature = sig;  // the costs now in d_item_cost belong to this geometry
+  s->cost_signature = sig;  // the costs now in d_item_cost belong to this geometry and engine
+  s->last_engine = engine;
   if (d_item) {  // debug: dump per-item durations (synchronises!)
-    std::vector<unsigned long long> host((size_t)P.n_items * 4 * 2);
+    std::vector<unsigned long long> host((size_t)P.n_items * 16 * 2 * 3);
     HIP_TRY(hipMemcpy(host.data(), d_item, host.size() * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d_item));
     if (FILE *f = fopen(item_dump, "wb")) {
@@ -343,6 +411,10 @@ void mt_scene_destroy(mt_scene *s) {
   (void)hipSetDevice(s->device);
   for (void *p : s->allocs) (void)hipFree(p);
   if (s->d_pool) (void)hipFree(s->d_pool);
+  if (s->d_frames) (void)hipFree(s->d_frames);
+  if (s->d_hit_prim) (void)hipFree(s->d_hit_prim);
+  if (s->d_hit_t) (void)hipFree(s->d_hit_t);
+  if (s->d_class_list) (void)hipFree(s->d_class_list);
   if (s->d_item_cost) (void)hipFree(s->d_item_cost);
   if (s->d_order_item) (void)hipFree(s->d_order_item);
   if (s->d_order_sub) (void)hipFree(s->d_order_sub);
@@ -464,6 +536,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     r.first_child = d->node_first_child[i];
     r.prim_begin = d->node_prim_begin[i];
     r.prim_count = d->node_prim_count[i];
+    r.level = depth_of[i] - 1;
   }
   // Block boxes (mt_device.h kGroupTris): union of the fp64 boxes of each
   // block of kGroupTris consecutive stream triangles, then rounded to fp32
@@ -647,6 +720,13 @@ int mt_scene_set_traversal_mode(mt_scene *s, int mode) {
 int mt_scene_set_scheduling(mt_scene *s, int use_cost_history) {
   if (!s || (use_cost_history != 0 && use_cost_history != 1)) return fail(MT_ERR_ARG, "bad scheduling argument");
   s->use_history = use_cost_history != 0;
+  s->cost_signature = 0;
+  return MT_OK;
+}
+
+int mt_scene_set_engine(mt_scene *s, int engine) {
+  if (!s || engine < 0 || engine > 2) return fail(MT_ERR_ARG, "engine must be 0 (automatic), 1 or 2");
+  s->engine = engine;
   s->cost_signature = 0;
   return MT_OK;
 }

@@ -20,7 +20,8 @@ struct NodeRec {
   int32_t prim_begin;
   int32_t prim_count;
   int32_t child_mask;   // bit c: child c's subtree holds at least one triangle
-  double pad1;
+  int32_t level;        // depth of the node, root = 0
+  int32_t pad1;
 };
 static_assert(sizeof(NodeRec) == 96, "NodeRec must be 96 bytes");
 
@@ -116,18 +117,26 @@ struct RenderParams {
   uint8_t *out_rgb;
   mt_debug_px *out_debug;  // nullable; same slot layout as out_rgb
   unsigned long long *counters;  // ST_COUNT
-  unsigned int *work_counter;     // [1] work units handed out so far
-  // Ray pool scratch (mt_render.hip): per wave pool_cap records, the pool of
-  // pending rays and the free list, pool_stride bytes apart.
+  unsigned int *work_counter;     // [0] launch 1, [1] launch 2 / work units handed out so far
+  // ---- throughput engine (mt_render.hip)
+  int32_t *hit_prim;              // primary hit per pixel (slot layout of out_rgb)
+  double *hit_t;
+  unsigned int *class_count;      // [3] blocks per cost class
+  unsigned int *class_list;       // [3][n_items] block ids per class
+  double *frames;                 // recursion frames scratch
+  int32_t from_primary;           // 1: launch 1 ran (hit_prim/hit_t, class lists); 0: order_* lists
+  // ---- latency engine (mt_pool.h): per wave pool_cap records, the pool of
+  // pending rays and the free list, pool_stride bytes apart
   char *pool_scratch;
   size_t pool_stride;
   int32_t pool_cap;
-  // Cost feedback between frames of the same launch geometry (see
-  // schedule_kernel): s_memtime ticks each block took in the previous frame
-  // (or probe_kernel's forecast), and the work order derived from them.
-  unsigned int *item_cost;        // [n_items] ticks (>> 6) of the last frame; quarters add up
-  unsigned int *order_item;       // [<= 4 n_items] block id of work unit w
-  signed char *order_sub;         // [<= 4 n_items] -1 = whole block, 0..3 = quarter
+  uint32_t prio_units;            // the first prio_units units of the order run at raised wave priority
+  // ---- both: cost feedback between frames of the same launch geometry (see the
+  // schedule kernels): s_memtime ticks each block took in the previous frame
+  // (or a forecast), and the work order derived from them.
+  unsigned int *item_cost;        // [n_items] ticks (>> 6) of the last frame; pieces of a block add up
+  unsigned int *order_item;       // [<= 16 n_items] block id of work unit w
+  signed char *order_sub;         // [<= 16 n_items] -1 = whole block, 0..3 = quarter, 4..19 = 2x2 cell (pool only)
   unsigned int *n_work;           // number of work units in order_item/order_sub
   unsigned long long *item_cycles;  // debug (MT_DEBUG_ITEM_CYCLES): s_memtime ticks per work item
 };
@@ -138,5 +147,7 @@ struct RenderParams {
 __host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
   return (size_t)depth * 64 * (packed ? 16 : 20) + 4 * 64 * 4;
 }
+
+constexpr int kFrameSlots = 11;  // throughput engine: 10 doubles + 1 packed meta word per recursion frame
 
 }  // namespace mt

@@ -6,83 +6,48 @@
 // (mythtracer.cc:13-228) and V3DtoRGB (:235-241).
 //
 // Execution model: persistent waves.  Every wave owns a slice of the block's
-// LDS (its traversal stack) and a scratch area in HBM (its ray pool), and pulls
-// work units (8x8-pixel blocks, or quarters of the longest ones) from one global
-// counter until none are left; waves never synchronise with each other.  The
-// reference's recursion (reflection, refraction) and its shadow loops are
-// unrolled into a pool of pending rays per unit with ONE call site of the
-// wave-synchronous traversal (mt_trace.h): every pass traces up to 64 pending
-// rays of the unit, whatever pixel, recursion level or light they belong to.
+// LDS (its traversal stack) and pulls work units (8x8-pixel blocks, or quarters
+// of the longest ones) from one global counter until none are left; waves never
+// synchronise with each other.  One lane renders one pixel -- or, in a quarter,
+// four lanes render one pixel, each running the shadow loop of one light.  The
+// reference's recursion (reflection, refraction) and its shadow loop are run as
+// a per-lane state machine with ONE call site of the wave-synchronous traversal
+// (mt_trace.h), so that whatever kind of ray each lane needs next, all 64 lanes
+// traverse together.
 #include "mt_shade.h"
+#include "mt_pool.h"
 
 namespace mt {
 
-// ---------------------------------------------------------------------------
-// Ray pool of one wave.
-//
-// TraceRayWorker (mythtracer.cc:13-228) is a recursion: one radiance ray, then
-// per light a shadow loop, then up to two child calls whose results are added
-// after everything else.  What a call RETURNS is a fixed expression of its
-// parts,
-//     color = ((((0 + a1_0) + a2_0) [+ a3_0]) + a1_1 ... ) [+ refl * Refl] [+ refr * Tf * Tr]
-// but none of the parts depends on another one: every light's shadow loop, the
-// reflected ray and the refracted ray are all known the moment the hit is
-// shaded (the child rays depend on the hit, the material, level, in_object and
-// the reflection coefficient only, :181-189, :192-225).  So a call is kept as a
-// RECORD in a per-wave scratch area, its rays are put into a pool, and every
-// pass of the wave traces up to 64 rays of the pool -- whatever pixels, levels
-// and lights they belong to.  A finished part is stored in its record; the ray
-// that completes a record evaluates the expression above in the reference's
-// order and hands the value to the parent record.  Same operations, same
-// operands, same order => same bits; but a pixel's chain of dependent passes
-// is its recursion DEPTH (plus glass crossings of a shadow loop), not the
-// number of rays of its recursion tree, and nothing of a ray's context stays
-// in registers across the traversal.
-//
-// Record layout, in doubles (kRecFixed + kLightSlot * n_lights per record):
-constexpr int R_RO = 0;        // [3] ray origin; after the hit: intersection point
-constexpr int R_RD = 3;        // [3] ray direction; after the hit: shading normal
-constexpr int R_SURF = 6;      // [3] surface colour (:58-64)
-constexpr int R_REFLDOT = 9;   // reflected_direction . towards_camera (:170)
-constexpr int R_COEF = 10;     // current_reflection_coef of this call
-constexpr int R_META = 11;     // u64: parent record | level << 32 | flags (M_*)
-constexpr int R_PM = 12;       // i32 parts still missing | i32 material index
-constexpr int R_RETREFL = 13;  // [3] value returned by the reflection child
-constexpr int R_RETREFR = 16;  // [3] value returned by the refraction child
-constexpr int R_PX = 19;       // u64: output position of the pixel (root records)
-constexpr int R_LIGHTS = 20;    // n_lights slots of kLightSlot doubles
-constexpr int kRecFixed = R_LIGHTS;
-// Per light: while its shadow loop is under way [0..2] start_point, [3..5]
-// light_power, [6] traversing_through_object; afterwards the three terms the
-// light adds to the colour: [0..2] (:83-84), [3..5] (:163-167), [6..8]
-// (:169-177) and [9] != 0 when the third one exists.
-constexpr int kLightSlot = 10;
-constexpr unsigned long long M_NOPARENT = 0xffffffffull;
-constexpr unsigned long long M_IN_OBJECT = 1ull << 40, M_KIND_REFR = 1ull << 41,
-                             M_HAS_REFL = 1ull << 42, M_HAS_REFR = 1ull << 43;
-// Pool entry: record | flags | (light + 1) << 24; light field 0 = the record's radiance ray.
-constexpr unsigned E_REC_MASK = 0xfffffu, E_ALLOC = 1u << 20, E_CONT = 1u << 21, E_NONE = 0xffffffffu;
-constexpr int kRootRecords = 64;
+enum { MODE_RADIANCE = 0, MODE_SHADOW = 1 };
+enum { STAGE_REFL = 0, STAGE_REFR = 1 };
 
-__device__ __forceinline__ V3 ld3(const double *p) { return V3{p[0], p[1], p[2]}; }
-__device__ __forceinline__ void st3(double *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
-__device__ __forceinline__ int lanes_below(unsigned long long mask) {  // set bits of mask below this lane
-  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-}
-// Memory written by one lane and read by another lane of the SAME wave (pool
-// entries, free list, values handed to a parent record): the vector L1 is
-// shared by the CU, so workgroup scope is enough to order them.
-__device__ __forceinline__ void wave_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
-__device__ __forceinline__ void wave_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// Recursion frames (one per level that has a child in flight) live in a
+// global scratch buffer, [wave][level][slot][lane] doubles: coalesced, and
+// touched only once per secondary ray.
+struct FrameIO {
+  double *base;  // this wave's block
+  int lane;
+  __device__ __forceinline__ double *slot(int level, int s) const {
+    return base + ((size_t)level * kFrameSlots + s) * 64 + lane;
+  }
+  __device__ __forceinline__ void put3(int level, int s, V3 v) const {
+    *slot(level, s) = v.x; *slot(level, s + 1) = v.y; *slot(level, s + 2) = v.z;
+  }
+  __device__ __forceinline__ V3 get3(int level, int s) const {
+    return V3{*slot(level, s), *slot(level, s + 1), *slot(level, s + 2)};
+  }
+};
 
 // Work item -> pixel of the calling lane.  An item is an 8x8-pixel block of a
-// tile slot.  sub < 0: the whole block, lane = pixel.  sub = 0..3: the 4x4
-// quarter `sub` of the block on lanes 0..15 (the longest blocks are handed out
-// as four units).
+// tile slot.  sub < 0: one lane per pixel, all 64 pixels.  sub = 0..3: the 4x4
+// quarter `sub` of the block with FOUR lanes per pixel (pixel = lane / 4,
+// role = lane % 4), used to run the shadow loops of up to four lights of a
+// pixel side by side.
 struct ItemGeom {
   int px, py;        // image coordinates of this lane's pixel
   bool inside;       // lane has a pixel
-  size_t px_index;   // position in the output buffers
+  size_t px_index;   // position in the output / hit buffers
 };
 __device__ __forceinline__ ItemGeom item_geometry(const RenderParams &P, unsigned item, int sub, int lane) {
   const int items_per_tile = P.blocks_x * P.blocks_y;
@@ -94,23 +59,40 @@ __device__ __forceinline__ ItemGeom item_geometry(const RenderParams &P, unsigne
   const int cw = min(P.tile_w, P.region_x + P.region_w - tx0);  // edge clipping as
   const int ch = min(P.tile_h, P.region_y + P.region_h - ty0);  // main_net_master.cc:205-206
   int ox, oy;
-  bool lane_used = true;
   if (sub < 0) {
     ox = lane & 7;
     oy = lane >> 3;
   } else {
-    ox = (sub & 1) * 4 + (lane & 3);
-    oy = (sub >> 1) * 4 + ((lane >> 2) & 3);
-    lane_used = lane < 16;
+    const int q = lane >> 2;
+    ox = (sub & 1) * 4 + (q & 3);
+    oy = (sub >> 1) * 4 + (q >> 2);
   }
   const int lx = (b % P.blocks_x) * 8 + ox;
   const int ly = (b / P.blocks_x) * 8 + oy;
   ItemGeom g;
   g.px = tx0 + lx;
   g.py = ty0 + ly;
-  g.inside = lane_used && (lx < cw) && (ly < ch);
+  g.inside = (lx < cw) && (ly < ch);
   g.px_index = (size_t)j * (size_t)P.tile_w * (size_t)P.tile_h + (size_t)ly * (size_t)cw + (size_t)lx;
   return g;
+}
+
+// Value of `v` held by role J of the caller's quad (four adjacent lanes), via
+// DPP quad_perm.  Must be executed by all lanes of the quad together.
+template <int J>
+__device__ __forceinline__ int quad_get_i32(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, J | (J << 2) | (J << 4) | (J << 6), 0xf, 0xf, false);
+}
+template <int J>
+__device__ __forceinline__ double quad_get_f64(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)quad_get_i32<J>((int)(unsigned)b);
+  const unsigned hi = (unsigned)quad_get_i32<J>((int)(unsigned)(b >> 32));
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+template <int J>
+__device__ __forceinline__ V3 quad_get_v3(V3 v) {
+  return V3{quad_get_f64<J>(v.x), quad_get_f64<J>(v.y), quad_get_f64<J>(v.z)};
 }
 
 // Work fetch.  Written WITHOUT a divergent branch: every lane issues the add
@@ -140,57 +122,98 @@ __device__ __forceinline__ void flush_item_stats(LaneStats &st, unsigned long lo
 }
 
 // ---------------------------------------------------------------------------
-// Cost forecast for a launch without history (first frame of a geometry): the
-// primary ray of ONE pixel per 8x8 block is traced (1/64 of the primary rays)
-// and the block is weighted by the material it sees -- reflective and
-// transparent surfaces start recursions -- so that schedule_kernel can hand
-// out the blocks that are probably long first.  The forecast only orders the
-// work; nothing computed for a pixel depends on it.
-__global__ __launch_bounds__(256, 3) void probe_kernel(DevScene S, RenderParams P) {
+// Launch 1 of a frame: the primary ray of every pixel (Sensor::GetRay +
+// the level-0 OctTree::IntersectRay of TraceRayWorker, mythtracer.cc:18-36).
+// Stores the hit (primitive, distance) per pixel, fills the optional debug
+// buffer, and files every 8x8 block under a cost class judged from the
+// materials it sees, so that launch 2 can start with the expensive blocks:
+//   class 2: some pixel hit a transparent material (deep refraction trees),
+//   class 1: some pixel hit a reflective one, class 0: everything else.
+template <bool STATS>
+__global__ __launch_bounds__(256, 3) void primary_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
   stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
-  const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool have = item < P.n_items;
-  ItemGeom g = item_geometry(P, have ? item : 0u, -1, 27);  // pixel (3, 3) of the block
-  if (!g.inside) g = item_geometry(P, have ? item : 0u, -1, 0);
-  const bool want = have && g.inside;
+  const MT_CONST mt_material *mtls = as_const(S.mtls);
+  LaneStats st;
+  st.clear();
   const V3 cam_origin = v3_load(P.sensor.origin);
-  V3 rd = v3(0, 0, 1);
-  if (want) {  // Sensor::GetRay, camera.cc:65-69
-    const V3 d = v3_load(P.sensor.start_point) + (v3_load(P.sensor.delta_scanline) * (double)g.py) +
-                 (v3_load(P.sensor.delta_pixel) * (double)g.px);
-    rd = normalized(d);
-  }
-  const TraceOut to = trace_wave<false>(S.self, stk.base, lane, want, cam_origin.x, cam_origin.y, cam_origin.z,
-                                        rd.x, rd.y, rd.z);
-  if (to.status != DEV_OK && lane == 0) atomicMax(P.counters + ST_STATUS, (unsigned long long)to.status);
-  if (have) {
-    unsigned weight = 1u;  // primary ray only
-    if (want && to.prim >= 0) {
-      const int m = S.tri_mtl[to.prim];
-      if (m >= 0) {
-        weight = 1u + (unsigned)S.n_lights;
-        const mt_material *mm = S.mtls + m;
-        if (mm->transparency > 0.0 || mm->reflectance > 0.0) weight *= (unsigned)(P.max_depth + 1);
-        if (mm->transparency > 0.0) weight *= 2u;  // shadow loops cross the glass as well
+  const V3 s_start = v3_load(P.sensor.start_point);
+  const V3 s_ds = v3_load(P.sensor.delta_scanline);
+  const V3 s_dp = v3_load(P.sensor.delta_pixel);
+  for (;;) {
+    const unsigned item = fetch_work(P.work_counter, lane);
+    if (item >= P.n_items) break;
+    const ItemGeom g = item_geometry(P, item, -1, lane);
+    V3 rd = v3(0, 0, 1);
+    if (g.inside) {  // Sensor::GetRay, camera.cc:65-69
+      const V3 d = s_start + (s_ds * (double)g.py) + (s_dp * (double)g.px);
+      rd = normalized(d);
+    }
+    int prim;
+    double t;
+    const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, g.inside, cam_origin.x, cam_origin.y,
+                                          cam_origin.z, rd.x, rd.y, rd.z);
+    add_trace_stats<STATS>(st, to);
+    prim = to.prim;
+    t = to.t;
+    const int trc = to.status;
+    if (trc != DEV_OK) {
+      if (lane == 0) atomicMax(P.counters + ST_STATUS, (unsigned long long)trc);
+      break;
+    }
+    int cls = 0;
+    if (g.inside) {
+      if (STATS) st.v[ST_RAYS_PRIMARY]++;
+      P.hit_prim[g.px_index] = prim;
+      P.hit_t[g.px_index] = t;
+      if (prim >= 0) {
+        const int m = S.tri_mtl[prim];
+        if (m >= 0) {
+          const MT_CONST mt_material *mm = mtls + m;
+          cls = mm->transparency > 0.0 ? 2 : (mm->reflectance > 0.0 ? 1 : 0);
+        }
+      }
+      if (P.out_debug != nullptr) {  // mythtracer.cc:23-36
+        mt_debug_px *dbg = P.out_debug + g.px_index;
+        dbg->reserved = 0;
+        if (prim < 0) {
+          dbg->line_no = -1;
+          dbg->point[0] = dbg->point[1] = dbg->point[2] = __builtin_nan("");
+        } else {
+          dbg->line_no = S.tri_line[prim];
+          dbg->point[0] = cam_origin.x + rd.x * t;  // primitive_triangle.cc:141
+          dbg->point[1] = cam_origin.y + rd.y * t;
+          dbg->point[2] = cam_origin.z + rd.z * t;
+        }
       }
     }
-    P.item_cost[item] = want ? weight * 256u : 0u;
+    const int item_cls = __builtin_amdgcn_readfirstlane(
+        (__builtin_amdgcn_ballot_w64(cls == 2) != 0ull) ? 2 : ((__builtin_amdgcn_ballot_w64(cls == 1) != 0ull) ? 1 : 0));
+    const unsigned slot = atomicAdd(P.class_count + item_cls, lane == 0 ? 1u : 0u);
+    if (lane == 0) {
+      P.class_list[(size_t)item_cls * P.n_items + slot] = item;
+      // launch 2 adds the block's measured cost; bit 31 = "rendered as quarters"
+      P.item_cost[item] = item_cls == 2 ? 0x80000000u : 0u;
+    }
+    flush_item_stats<STATS>(st, P.counters, lane);
   }
 }
 
 // ---------------------------------------------------------------------------
-// Work order from the block costs of the previous frame (or from
-// probe_kernel's forecast): one block of 1024 threads, a few microseconds.
+// Work order from the previous frame's measured block costs (one block of 1024
+// threads, a few microseconds).  A frame cannot finish before its slowest work
+// item, and the per-pixel ray chains cannot be split, so:
 //   * blocks are handed out longest first (bucket sort on log2 of the cost,
 //     eight buckets per octave);
-//   * a block that took longer than quad_share of an even share of the frame's
-//     work is cut into its four 4x4 quarters, each a unit of its own (a unit is
-//     traced by one wave, pass after pass: the frame cannot end before its
-//     longest unit).
+//   * blocks that took longer than quad_share (0.8) of an even share of the
+//     frame's work are cut into four quarters with FOUR lanes per pixel (the
+//     shadow loops of a pixel's lights run side by side: a shorter chain for
+//     about 1.7x the work, which is why only the few longest blocks get it;
+//     measured on the 1080p room frame: 0.25 -> 13.3 ms, 0.45 -> 11.7, 0.6 ->
+//     10.8, 0.8 -> 10.0, 0.9 -> 10.8, 1.0 -> 12.0, never -> 25.0).
 // The order changes nothing about what is computed for a pixel.  Costs are in
 // units of 64 s_memtime ticks; a block rendered as quarters reports their sum,
 // which is scaled back (kQuadWork) before it is compared again.
@@ -202,8 +225,7 @@ __device__ __forceinline__ int cost_bucket(unsigned c) {  // descending cost = a
   const int f = e >= 3 ? (int)((c >> (e - 3)) & 7u) : 0;      // eighth within it
   return kSchedBuckets - 1 - (e * 8 + f);
 }
-__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves, float quad_share,
-                                                                 float quad_work, float quarter_time) {
+__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves, float quad_share) {
   __shared__ unsigned long long s_sum;
   __shared__ unsigned s_count[kSchedBuckets];
   __shared__ unsigned s_start[kSchedBuckets];
@@ -211,8 +233,8 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
   if (tid == 0) s_sum = 0ull;
   for (int b = tid; b < kSchedBuckets; b += kSchedThreads) s_count[b] = 0u;
   __syncthreads();
-  // costs measured as quarters are sums over four partly filled units
-  const float kQuadWork = quad_work, kQuadShare = quad_share, kQuarterTime = quarter_time;
+  // costs measured in quad mode are sums over four quarters
+  const float kQuadWork = 1.7f, kQuadShare = quad_share, kQuarterTime = 0.45f;
   unsigned long long part = 0ull;
   for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
     unsigned c = P.item_cost[i];
@@ -225,7 +247,7 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
   __syncthreads();
   const float share = (float)s_sum / (float)(n_waves > 0 ? n_waves : 1);
   const float quad_above = share * kQuadShare;
-  // pass 1: bucket counts (a quartered block contributes four units)
+  // pass 1: bucket counts (a quad block contributes four units)
   for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
     unsigned c = P.item_cost[i];
     const bool was_quad = (c >> 31) != 0u;
@@ -270,8 +292,15 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
 
 // ---------------------------------------------------------------------------
 // The frame kernel: TraceRayWorker for every pixel of the launch's tiles and
-// the pixel store.  Persistent waves pull work units in schedule_kernel's
-// order; the first ones (the longest) run at raised wave priority.
+// the pixel store.  With cost history (P.from_primary == 0) it traces the
+// primary rays itself and takes its work units in schedule_kernel's order;
+// without, it continues from primary_kernel's hits: reflective blocks first,
+// then the transparent ones as quarters, then the rest.  Either way the
+// expensive units start first and run at raised wave priority: the frame cannot
+// finish before its slowest unit and a pixel's ray chain cannot be split.
+// (Plain 4x4 quarters with one lane per pixel do not help -- a pass over 16 lanes
+// costs about 80 % of a pass over 64; quarters pay off only with four lanes per
+// pixel, i.e. with the pixel's shadow loops running side by side.)
 template <bool STATS>
 __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -281,21 +310,12 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
   const int wave_id = blockIdx.x * waves_per_block + wave_in_block;
   WaveStack stk;
   stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
+  FrameIO fio;
+  fio.base = P.frames + (size_t)wave_id * (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64;
+  fio.lane = lane;
 
-  // this wave's scratch: records, pool (a stack of entries), free list (a stack of record numbers)
-  const int n_lights = S.n_lights;
-  const int RS = kRecFixed + kLightSlot * n_lights;  // even: records stay 16-byte aligned
-  const int cap = P.pool_cap;
-  char *const scratch = P.pool_scratch + (size_t)wave_id * P.pool_stride;
-  double *const recs = (double *)scratch;
-  unsigned *const pool = (unsigned *)(scratch + (size_t)cap * RS * sizeof(double));
-  unsigned *const freel = pool + (size_t)cap * (n_lights > 0 ? n_lights : 1);
-  auto rec_ptr = [&](unsigned r) -> double * {
-    return (double *)__builtin_assume_aligned(recs + (size_t)r * RS, 16);
-  };
-
-  const mt_material *mtls = S.mtls;
-  const mt_light *lights = S.lights;
+  const MT_CONST mt_material *mtls = as_const(S.mtls);
+  const MT_CONST mt_light *lights = as_const(S.lights);
 
   LaneStats st;
   st.clear();
@@ -304,10 +324,9 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
   const V3 s_start = v3_load(P.sensor.start_point);
   const V3 s_ds = v3_load(P.sensor.delta_scanline);
   const V3 s_dp = v3_load(P.sensor.delta_pixel);
-  const unsigned n_work = *P.n_work;
-  // Records a pass may need on top of those its rays already have, kept back
-  // while the free ones run low (see the throttle below).
-  const int reserve = 4 * (P.max_depth + 1);
+  const bool from_primary = P.from_primary != 0;
+  const unsigned n2 = P.class_count[2], n1 = P.class_count[1], n0 = P.class_count[0];
+  const unsigned n_work = from_primary ? 4u * n2 + n1 + n0 : *P.n_work;
 
   for (;;) {
     const unsigned w = fetch_work(P.work_counter + 1, lane);
@@ -316,400 +335,381 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
       if (lane == 0) { S.hb[wave_id * 4 + 0] = 1 | ((unsigned long long)w << 8); S.hb[wave_id * 4 + 1] = ex; }
     }
     if (w >= n_work) break;
-    const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)P.order_item[w]);
-    const int sub = __builtin_amdgcn_readfirstlane((int)P.order_sub[w]);
-    if (w < (n_work >> 4)) __builtin_amdgcn_s_setprio(3);
-    else if (w < (n_work >> 2)) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(0);
+    unsigned item;
+    int sub = -1;
+    if (!from_primary) {
+      // Order of the previous frame's measured block costs, longest first
+      // (schedule_kernel); the longest blocks come as four quarters.
+      item = P.order_item[w];
+      sub = (int)P.order_sub[w];
+      if (w < (n_work >> 4)) __builtin_amdgcn_s_setprio(3);
+      else if (w < (n_work >> 2)) __builtin_amdgcn_s_setprio(2);
+      else __builtin_amdgcn_s_setprio(0);
+    } else if (w < n1) {
+      // No history: reflective blocks (class 1) first — the longest of them (a
+      // floor that mirrors glass: 30+ sequential rays per pixel) cannot be told
+      // apart beforehand, so all of them start early; then the class-2 blocks,
+      // each as four quarters with four lanes per pixel (a pixel's shadow loops
+      // run side by side, which halves its ray chain); then everything else.
+      item = P.class_list[(size_t)1 * P.n_items + w];
+      __builtin_amdgcn_s_setprio(3);
+    } else if (w < n1 + 4u * n2) {
+      item = P.class_list[(size_t)2 * P.n_items + ((w - n1) >> 2)];
+      sub = (int)((w - n1) & 3u);
+      __builtin_amdgcn_s_setprio(2);
+    } else {
+      item = P.class_list[w - 4u * n2 - n1];
+      __builtin_amdgcn_s_setprio(0);
+    }
+    sub = __builtin_amdgcn_readfirstlane(sub);
+    item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
 
     const unsigned long long item_t0 = __builtin_amdgcn_s_memtime();
     const ItemGeom g = item_geometry(P, item, sub, lane);
+    bool alive = g.inside;
+    const size_t px_index = g.px_index;
 
-    // ---- the unit's root records (one per pixel, record number = lane) and their rays
-    unsigned n_pool = 0, n_free = 0;
-    int hw = kRootRecords;  // records >= hw have not been used in this unit
-    {
-      const unsigned long long in_mask = __ballot(g.inside);
-      if (g.inside) {  // Sensor::GetRay, camera.cc:65-69
-        const V3 d = s_start + (s_ds * (double)g.py) + (s_dp * (double)g.px);
-        double *R = rec_ptr((unsigned)lane);
-        st3(R + R_RO, cam_origin);
-        st3(R + R_RD, normalized(d));
-        R[R_COEF] = 1.0;  // TraceRay: level 0, not in an object, coefficient 1 (:230-233)
-        *(unsigned long long *)(R + R_META) = M_NOPARENT;
-        *(unsigned long long *)(R + R_PX) = (unsigned long long)g.px_index;
-        pool[lanes_below(in_mask)] = (unsigned)lane | (P.max_depth > 0 ? E_ALLOC : 0u);
-      }
-      n_pool = (unsigned)__builtin_popcountll(in_mask);
+    // ---- per-lane state of TraceRayWorker.  R lanes serve one pixel (R = 4
+    // in quad mode, else 1): role 0 owns the pixel and runs the recursion;
+    // during a "light round" role j runs the shadow loop of light round_base+j.
+    const bool quad = sub >= 0;
+    const int R = quad ? 4 : 1;
+    const int role = quad ? (lane & 3) : 0;
+    const bool owner = role == 0;
+    const unsigned long long my_group = quad ? (0xFull << (lane & ~3)) : (1ull << lane);
+    enum { MODE_IDLE = 2 };
+    int mode = owner ? MODE_RADIANCE : MODE_IDLE;
+    int level = 0;
+    bool in_object = false;
+    double coef = 1.0;
+    V3 ro = cam_origin, rd = v3(0, 0, 1);
+    if (alive) {  // Sensor::GetRay, camera.cc:65-69 (same arithmetic as launch 1)
+      const V3 d = s_start + (s_ds * (double)g.py) + (s_dp * (double)g.px);
+      rd = normalized(d);
     }
-    wave_release();
+    V3 Pt = v3(0, 0, 0), Nn = Pt, surf = Pt, color = Pt, Rd = Pt, dir = Pt, L = Pt, start = Pt,
+       lp = Pt;
+    V3 add1 = Pt, add2 = Pt, add3 = Pt;  // this role's contributions to `color`, in the order they are added
+    bool has_light = false, has_add3 = false;
+    double refl_dot = 0.0;
+    int mtl = -1, li = 0, round_base = 0;
+    bool traversing = false;
+    bool want_round = false, waiting_round = false;
 
-    // Bound on passes per unit: every pass traces at least one ray; a pixel has
-    // at most 2^(max_depth+1) radiance rays, each with one shadow loop per light
-    // whose iterations each cross a different surface.
+    // Bound on traversals per item: every ray of a pixel is at most one pass; a
+    // pixel needs at most 2^(max_depth+1) radiance rays, each with one shadow
+    // loop per light whose iterations each cross a different surface.
     const long long pass_bound =
-        64ll * ((2ll << P.max_depth) * (1 + (long long)n_lights * ((long long)S.n_tris + 2)) + 16);
+        (2ll << P.max_depth) * (1 + (long long)S.n_lights * ((long long)S.n_tris + 2)) + 16;
     long long passes = 0;
-    bool failed = false;
-    while (n_pool != 0u) {
-      wave_acquire();
-      // ---- take up to 64 rays from the top of the pool.  A radiance ray below
-      // the last level may need two new records when it is shaded; while free
-      // records are short only as many of those are taken as can be served with
-      // `reserve` records left over, at least one.  Entries are taken from the
-      // top (last in, first out), so the pool then works through the recursion
-      // depth first, which needs at most 2 new records per level and returns
-      // them before the next branch is entered: progress is guaranteed.
-      const unsigned take0 = n_pool < 64u ? n_pool : 64u;
-      unsigned e = E_NONE;
-      if ((unsigned)lane < take0) e = pool[n_pool - 1u - (unsigned)lane];
-      unsigned take = take0;
-      {
-        const int avail = (int)n_free + (cap - hw);
-        const unsigned long long am = __ballot(e != E_NONE && (e & E_ALLOC) != 0u);
-        const int kmax = avail >= reserve + 2 ? (avail - reserve) >> 1 : (avail >= 2 ? 1 : 0);
-        if (__builtin_popcountll(am) > kmax) {
-          unsigned long long r = am;
-          for (int i = 0; i < kmax; i++) r &= r - 1ull;
-          take = (unsigned)__builtin_ctzll(r);  // lanes below the (kmax+1)-th such ray
-        }
-      }
+    while (__ballot(alive) != 0ull) {
+      int prim = -1;
+      double t = 0.0;
       if (S.hb) {
+        const unsigned long long am = __ballot(alive);
         const unsigned long long ex = __builtin_amdgcn_read_exec();
         if (lane == 0) {
           S.hb[wave_id * 4 + 0] = 2 | ((unsigned long long)passes << 8);
-          S.hb[wave_id * 4 + 2] = ((unsigned long long)n_pool << 32) | take;
+          S.hb[wave_id * 4 + 2] = am;
           S.hb[wave_id * 4 + 3] = ex;
         }
       }
-      if (take == 0u || ++passes > pass_bound) {
-        if (lane == 0) atomicMax(P.counters + ST_STATUS, (unsigned long long)(take == 0u ? DEV_ERR_POOL : DEV_ERR_PIXEL_BOUND));
-        failed = true;
-        break;
-      }
-      if ((unsigned)lane >= take) e = E_NONE;
-      n_pool -= take;
-
-      // ---- the ray of each entry
-      const bool active = e != E_NONE;
-      const unsigned rec = e & E_REC_MASK;
-      const int li = (int)(e >> 24) - 1;  // -1: radiance ray
-      const bool is_shadow = active && li >= 0;
-      const bool is_rad = active && li < 0;
-      V3 ro = cam_origin, rd = v3(0, 0, 1);
-      if (active) {
-        const double *R = rec_ptr(rec);
-        ro = ld3(R + R_RO);
-        if (is_rad) {
-          rd = ld3(R + R_RD);
-        } else {  // head of the shadow loop, mythtracer.cc:79-99
-          const mt_light *lt = lights + li;
-          const V3 lpos = v3(lt->position[0], lt->position[1], lt->position[2]);
-          const V3 L = normalized(lpos - ro);  // ro holds the intersection point here
-          const V3 start = (e & E_CONT) ? ld3(R + R_LIGHTS + li * kLightSlot) : ro;
-          ro = start + (L * 0.00001);
-          rd = L;
+      int trc = DEV_OK;
+      const bool tracing = alive && mode != MODE_IDLE;
+      if (passes == 0 && from_primary) {  // the primary hit was found by launch 1
+        prim = tracing ? P.hit_prim[px_index] : -1;
+        t = tracing ? P.hit_t[px_index] : 0.0;
+      } else {
+#if MT_DUP == 6
+        {
+          const TraceOut td = trace_wave<false>(S.self, stk.base, lane, tracing, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+          asm volatile("" :: "v"(td.prim), "v"(td.t));
         }
+#endif
+        const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, tracing, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+        add_trace_stats<STATS>(st, to);
+        prim = to.prim;
+        t = to.t;
+        trc = to.status;
       }
-      const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, active, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
-      add_trace_stats<STATS>(st, to);
-      const int prim = to.prim;
-      const double t = to.t;
       if (S.hb) {
         const unsigned long long ex = __builtin_amdgcn_read_exec();
         if (lane == 0) { S.hb[wave_id * 4 + 0] = 3 | ((unsigned long long)passes << 8); S.hb[wave_id * 4 + 3] = ex; }
       }
-      if (to.status != DEV_OK) {
-        if (lane == 0) atomicMax(P.counters + ST_STATUS, (unsigned long long)to.status);
-        failed = true;
+      if (trc != DEV_OK || ++passes > pass_bound) {
+        if (lane == 0) atomicMax(P.counters + ST_STATUS, (unsigned long long)(trc != DEV_OK ? trc : DEV_ERR_PIXEL_BOUND));
+        alive = false;
         break;
       }
 
-      // ---- consume the traversal results (per lane)
-      bool finish = false;      // this lane hands `retval` of record `rec_c` to its parent
-      bool part_done = false;   // this lane completed one part (a light) of record `rec`
-      unsigned rec_c = rec;
+      // ---- stage 1 (per lane): consume the traversal result
+      bool after_lights = false, do_return = false;
       V3 retval = v3(0, 0, 0);
-      bool fresh = false;       // a radiance hit that was shaded now: its shadow loops start
-      bool again = false;       // shadow loop goes on: same light, next iteration
-      bool need_refl = false, need_refr = false;
-      V3 c_refl_o = retval, c_refl_d = retval, c_refr_o = retval, c_refr_d = retval;
-      double c_refl_coef = 0.0, c_refr_coef = 0.0;
-      unsigned long long c_meta = 0ull;  // level and in_object of the children (kind/parent added below)
-      if (is_rad) {
-        double *R = rec_ptr(rec);
-        const unsigned long long meta = *(const unsigned long long *)(R + R_META);
-        const int level = (int)((meta >> 32) & 0xffull);
-        const bool in_object = (meta & M_IN_OBJECT) != 0ull;
-        if (STATS) {
-          if (level > 0) st.v[ST_RAYS_SECONDARY]++;
-          else st.v[ST_RAYS_PRIMARY]++;
-        }
-        if (level == 0 && P.out_debug != nullptr) {  // mythtracer.cc:23-36
-          mt_debug_px *dbg = P.out_debug + *(const unsigned long long *)(R + R_PX);
-          dbg->reserved = 0;
-          if (prim < 0) {
-            dbg->line_no = -1;
-            dbg->point[0] = dbg->point[1] = dbg->point[2] = __builtin_nan("");
-          } else {
-            dbg->line_no = S.tri_line[prim];
-            dbg->point[0] = ro.x + rd.x * t;  // primitive_triangle.cc:141
-            dbg->point[1] = ro.y + rd.y * t;
-            dbg->point[2] = ro.z + rd.z * t;
+      if (tracing) {
+        if (mode == MODE_RADIANCE) {
+          if (STATS) {  // with launch 1, level 0 was counted there
+            if (level > 0) st.v[ST_RAYS_SECONDARY]++;
+            else if (!from_primary) st.v[ST_RAYS_PRIMARY]++;
           }
-        }
-        if (prim < 0) {  // mythtracer.cc:23-31
-          finish = true;
-        } else {
-          if (STATS) st.v[ST_SHADED_HITS]++;
-          const V3 Pt = ro + rd * t;  // primitive_triangle.cc:141
-          const V3 dir = rd;
-          const double *vtx = S.tri_vertex + (size_t)prim * 9;
-          const Bary bw = barycentric(vtx, Pt);
-          V3 Nn = interpolate(S.tri_normal + (size_t)prim * 9, bw);  // :38
-          const V3 towards_camera = -dir;
-          double normal_ray_dot = dot(Nn, towards_camera);
-          if (normal_ray_dot < 0.0) {  // :42-45
-            Nn = -Nn;
-            normal_ray_dot = dot(Nn, towards_camera);
-          }
-          const int mtl = S.tri_mtl[prim];
-          if (mtl < 0) {  // :49-52
-            normal_ray_dot = (normal_ray_dot + 1.0) * 0.5;
-            retval = v3(normal_ray_dot, normal_ray_dot, normal_ray_dot);
-            finish = true;
+          if (prim < 0) {  // mythtracer.cc:23-31
+            do_return = true;
           } else {
-            const mt_material *m = mtls + mtl;
-            V3 surf = v3(m->ambient[0], m->ambient[1], m->ambient[2]);  // :58
-            if (m->tex >= 0) {  // :59-64
-              const V3 uvw = interpolate(S.tri_uvw + (size_t)prim * 9, bw);
-              surf = surf * texture_color_at(S.texs[m->tex], uvw.x, uvw.y);
+            if (STATS) st.v[ST_SHADED_HITS]++;
+            Pt = ro + rd * t;  // primitive_triangle.cc:141
+            dir = rd;
+            const double *vtx = S.tri_vertex + (size_t)prim * 9;
+            const Bary w = barycentric(vtx, Pt);
+            Nn = interpolate(S.tri_normal + (size_t)prim * 9, w);  // :38
+            const V3 towards_camera = -dir;
+            double normal_ray_dot = dot(Nn, towards_camera);
+            if (normal_ray_dot < 0.0) {  // :42-45
+              Nn = -Nn;
+              normal_ray_dot = dot(Nn, towards_camera);
             }
-            const V3 Rd = dir - Nn * (2 * dot(dir, Nn));  // :68-69
-            const double refl_dot = dot(Rd, towards_camera);  // :170, the same for every light
-            const double coef = R[R_COEF];
-            const double refl = m->reflectance, tr = m->transparency;
-            need_refl = level < P.max_depth && refl > 0.0 && coef > 0.01 && !in_object;  // :181-184
-            need_refr = level < P.max_depth && tr > 0.0;                                  // :193
-            if (need_refl) {  // :70-74, :185-188
-              c_refl_o = Pt + (Rd * 0.0001);
-              c_refl_d = Rd;
-              c_refl_coef = coef * refl;
-            }
-            if (need_refr) {  // :208-224 (direction unchanged, re-normalised)
-              const V3 rdir = normalized(dir);
-              c_refr_o = Pt + rdir * 0.00001;
-              c_refr_d = rdir;
-              c_refr_coef = coef;
-            }
-            c_meta = ((unsigned long long)(level + 1) << 32) | (in_object ? M_IN_OBJECT : 0ull);
-            st3(R + R_RO, Pt);
-            st3(R + R_RD, Nn);
-            st3(R + R_SURF, surf);
-            R[R_REFLDOT] = refl_dot;
-            *(unsigned long long *)(R + R_META) =
-                meta | (need_refl ? M_HAS_REFL : 0ull) | (need_refr ? M_HAS_REFR : 0ull);
-            const int parts = n_lights + (need_refl ? 1 : 0) + (need_refr ? 1 : 0);
-            *(unsigned long long *)(R + R_PM) =
-                (unsigned long long)(unsigned)parts | ((unsigned long long)(unsigned)mtl << 32);
-            if (parts == 0) finish = true;  // no lights, no children: colour (0, 0, 0)
-            else fresh = n_lights > 0;
-          }
-        }
-      } else if (is_shadow) {  // ---- one iteration of the shadow loop, mythtracer.cc:94-156
-        if (STATS) st.v[ST_RAYS_SHADOW]++;
-        double *R = rec_ptr(rec);
-        double *slot = R + R_LIGHTS + li * kLightSlot;
-        const mt_light *lt = lights + li;
-        const V3 lpos = v3(lt->position[0], lt->position[1], lt->position[2]);
-        const V3 Pt = ld3(R + R_RO);
-        const V3 L = rd;  // light_direction, as set up before the traversal
-        const bool cont = (e & E_CONT) != 0u;
-        V3 start = cont ? ld3(slot) : Pt;
-        V3 lp = cont ? ld3(slot + 3) : v3(1.0, 1.0, 1.0);
-        bool traversing = cont ? (slot[6] != 0.0) : false;
-        bool light_done = false, in_shadow = false;
-        if (prim < 0) {
-          light_done = true;  // :109-112
-        } else {
-          const double light_distance = distance(start, lpos);  // :101-102
-          if (t > light_distance) {
-            light_done = true;  // :115-118
-          } else {
-            // :121 dereferences shadow_primitive->mtl unconditionally (a
-            // crash for material-less occluders); defined here as opaque.
-            const int sm = S.tri_mtl[prim];
-            const double s_tr = sm >= 0 ? mtls[sm].transparency : 0.0;
-            if (s_tr == 0.0) {
-              lp = v3(0, 0, 0);
-              in_shadow = true;
-              light_done = true;
+            mtl = S.tri_mtl[prim];
+            if (mtl < 0) {  // :49-52
+              normal_ray_dot = (normal_ray_dot + 1.0) * 0.5;
+              retval = v3(normal_ray_dot, normal_ray_dot, normal_ray_dot);
+              do_return = true;
             } else {
-              if (!traversing) {  // :129-132
-                const mt_material *smm = mtls + sm;
-                const V3 tf = v3(smm->transmission_filter[0], smm->transmission_filter[1],
-                                 smm->transmission_filter[2]);
-                lp = lp * (tf * s_tr);
+              const MT_CONST mt_material *m = mtls + mtl;
+              surf = v3(m->ambient[0], m->ambient[1], m->ambient[2]);  // :58
+              if (m->tex >= 0) {  // :59-64
+                const V3 uvw = interpolate(S.tri_uvw + (size_t)prim * 9, w);
+                surf = surf * texture_color_at(S.texs[m->tex], uvw.x, uvw.y);
               }
-              traversing = !traversing;
-              const V3 sp = ro + rd * t;
-              start = sp + (L * 0.0000001);  // :137
-              if (sqr_distance(Pt, start) > sqr_distance(Pt, lpos)) {
-                light_done = true;  // :141-145
-              } else if (lp.x <= 0.001 && lp.y <= 0.001 && lp.z <= 0.001) {
-                lp = v3(0, 0, 0);  // :149-155
+              Rd = dir - Nn * (2 * dot(dir, Nn));  // :68-69
+              refl_dot = dot(Rd, towards_camera);  // :170, the same for every light
+              color = v3(0, 0, 0);
+              round_base = 0;
+              if (S.n_lights > 0) want_round = true;
+              else after_lights = true;
+              mode = MODE_IDLE;
+            }
+          }
+        } else {  // ---- one iteration of the shadow loop, mythtracer.cc:94-156
+          if (STATS) st.v[ST_RAYS_SHADOW]++;
+          const MT_CONST mt_light *lt = lights + li;
+          const V3 lpos = v3(lt->position[0], lt->position[1], lt->position[2]);
+          bool light_done = false, in_shadow = false;
+          if (prim < 0) {
+            light_done = true;  // :109-112
+          } else {
+            const double light_distance = distance(start, lpos);  // :101-102
+            if (t > light_distance) {
+              light_done = true;  // :115-118
+            } else {
+              // :121 dereferences shadow_primitive->mtl unconditionally (a
+              // crash for material-less occluders); defined here as opaque.
+              const int sm = S.tri_mtl[prim];
+              const double s_tr = sm >= 0 ? mtls[sm].transparency : 0.0;
+              if (s_tr == 0.0) {
+                lp = v3(0, 0, 0);
                 in_shadow = true;
                 light_done = true;
-              } else {  // next iteration, :95-99
-                st3(slot, start);
-                st3(slot + 3, lp);
-                slot[6] = traversing ? 1.0 : 0.0;
-                again = true;
+              } else {
+                if (!traversing) {  // :129-132
+                  const MT_CONST mt_material *smm = mtls + sm;
+                  const V3 tf = v3(smm->transmission_filter[0], smm->transmission_filter[1],
+                                   smm->transmission_filter[2]);
+                  lp = lp * (tf * s_tr);
+                }
+                traversing = !traversing;
+                const V3 sp = ro + rd * t;
+                start = sp + (L * 0.0000001);  // :137
+                if (sqr_distance(Pt, start) > sqr_distance(Pt, lpos)) {
+                  light_done = true;  // :141-145
+                } else if (lp.x <= 0.001 && lp.y <= 0.001 && lp.z <= 0.001) {
+                  lp = v3(0, 0, 0);  // :149-155
+                  in_shadow = true;
+                  light_done = true;
+                } else {
+                  ro = start + (L * 0.00001);  // next iteration, :95-99
+                  rd = L;
+                }
               }
             }
           }
-        }
-        if (light_done) {
-          // The three terms this light adds to `color` (:83-84, :163-167,
-          // :169-177), computed exactly as written there; they are added in
-          // light order when the record is complete.
-          const int mtl = *((const int *)(R + R_PM) + 1);
-          const mt_material *m = mtls + mtl;
-          const V3 surf = ld3(R + R_SURF);
-          const V3 Nn = ld3(R + R_RD);
-          const double refl_dot = R[R_REFLDOT];
-          const V3 amb = v3(lt->ambient[0], lt->ambient[1], lt->ambient[2]);
-          st3(slot, amb * surf);
-          lp.x = std_max(lp.x, amb.x);  // :159-161
-          lp.y = std_max(lp.y, amb.y);
-          lp.z = std_max(lp.z, amb.z);
-          const V3 kd = v3(m->diffuse[0], m->diffuse[1], m->diffuse[2]);
-          const V3 ld = v3(lt->diffuse[0], lt->diffuse[1], lt->diffuse[2]);
-          st3(slot + 3, kd * surf * dot(L, Nn) * ld * lp);
-          double has3 = 0.0;
-          if (!in_shadow && refl_dot > 0) {
-            const V3 ks = v3(m->specular[0], m->specular[1], m->specular[2]);
-            const V3 ls = v3(lt->specular[0], lt->specular[1], lt->specular[2]);
-            st3(slot + 6, ks * surf * ::pow(refl_dot, m->specular_exp) * ls);
-            has3 = 1.0;
+          if (light_done) {
+            // The three terms this light adds to `color` (:83-84, :163-167,
+            // :169-177), computed exactly as written there; the pixel's owner
+            // adds them in light order.
+            const MT_CONST mt_material *m = mtls + mtl;
+            const V3 amb = v3(lt->ambient[0], lt->ambient[1], lt->ambient[2]);
+            add1 = amb * surf;
+            lp.x = std_max(lp.x, amb.x);  // :159-161
+            lp.y = std_max(lp.y, amb.y);
+            lp.z = std_max(lp.z, amb.z);
+            const V3 kd = v3(m->diffuse[0], m->diffuse[1], m->diffuse[2]);
+            const V3 ld = v3(lt->diffuse[0], lt->diffuse[1], lt->diffuse[2]);
+            add2 = kd * surf * dot(L, Nn) * ld * lp;
+            has_add3 = false;
+            if (!in_shadow && refl_dot > 0) {
+              const V3 ks = v3(m->specular[0], m->specular[1], m->specular[2]);
+              const V3 ls = v3(lt->specular[0], lt->specular[1], lt->specular[2]);
+              add3 = ks * surf * ::pow(refl_dot, m->specular_exp) * ls;
+              has_add3 = true;
+            }
+            mode = MODE_IDLE;
           }
-          slot[9] = has3;
-          part_done = true;
         }
       }
 
-      // ---- records for the child calls (free list first, then unused ones)
-      unsigned e_refl = E_NONE, e_refr = E_NONE;
+      // ---- stage 2 (all lanes of the wave together: quad broadcasts)
+      // (a) a round is complete when no role of the pixel is still in a shadow
+      //     loop: the owner adds the roles' terms in light order.
       {
-        const unsigned long long m1 = __ballot(need_refl), m2 = __ballot(need_refr);
-        const unsigned n1 = (unsigned)__builtin_popcountll(m1), total = n1 + (unsigned)__builtin_popcountll(m2);
-        if (total != 0u) {
-          const unsigned j1 = (unsigned)lanes_below(m1), j2 = n1 + (unsigned)lanes_below(m2);
-          const unsigned child_alloc = ((int)((c_meta >> 32) & 0xffull) < P.max_depth) ? E_ALLOC : 0u;
-          if (need_refl) {
-            const unsigned r = j1 < n_free ? freel[n_free - 1u - j1] : (unsigned)hw + (j1 - n_free);
-            double *C = rec_ptr(r);
-            st3(C + R_RO, c_refl_o);
-            st3(C + R_RD, c_refl_d);
-            C[R_COEF] = c_refl_coef;
-            *(unsigned long long *)(C + R_META) = (unsigned long long)rec | c_meta;
-            e_refl = r | child_alloc;
+        const unsigned long long busy = __ballot(alive && mode == MODE_SHADOW);
+        const bool round_done = owner && waiting_round && ((busy & my_group) == 0ull);
+        const int hl0 = has_light ? 1 : 0, h30 = has_add3 ? 1 : 0;
+        // role 0 is the owner itself
+        if (round_done && has_light) {
+          color = color + add1;
+          color = color + add2;
+          if (has_add3) color = color + add3;
+        }
+        if (quad) {
+          const int hl1 = quad_get_i32<1>(hl0), hl2 = quad_get_i32<2>(hl0), hl3 = quad_get_i32<3>(hl0);
+          const int h31 = quad_get_i32<1>(h30), h32 = quad_get_i32<2>(h30), h33 = quad_get_i32<3>(h30);
+          const V3 a11 = quad_get_v3<1>(add1), a21 = quad_get_v3<1>(add2), a31 = quad_get_v3<1>(add3);
+          const V3 a12 = quad_get_v3<2>(add1), a22 = quad_get_v3<2>(add2), a32 = quad_get_v3<2>(add3);
+          const V3 a13 = quad_get_v3<3>(add1), a23 = quad_get_v3<3>(add2), a33 = quad_get_v3<3>(add3);
+          if (round_done) {
+            if (hl1) { color = color + a11; color = color + a21; if (h31) color = color + a31; }
+            if (hl2) { color = color + a12; color = color + a22; if (h32) color = color + a32; }
+            if (hl3) { color = color + a13; color = color + a23; if (h33) color = color + a33; }
           }
-          if (need_refr) {
-            const unsigned r = j2 < n_free ? freel[n_free - 1u - j2] : (unsigned)hw + (j2 - n_free);
-            double *C = rec_ptr(r);
-            st3(C + R_RO, c_refr_o);
-            st3(C + R_RD, c_refr_d);
-            C[R_COEF] = c_refr_coef;
-            *(unsigned long long *)(C + R_META) = ((unsigned long long)rec | c_meta | M_KIND_REFR) ^ M_IN_OBJECT;
-            e_refr = r | child_alloc;
+        }
+        if (round_done) {
+          waiting_round = false;
+          round_base += R;
+          if (round_base < S.n_lights) want_round = true;
+          else after_lights = true;
+        }
+      }
+      // (b) start of a round: the owner's shading point goes to every role, each
+      //     role with a light sets up its shadow loop (head of the light loop,
+      //     mythtracer.cc:78-99).
+      {
+        int wr = (owner && want_round) ? 1 : 0;
+        int rb = round_base, mt_ = mtl;
+        V3 bP = Pt, bN = Nn, bS = surf;
+        double bR = refl_dot;
+        if (quad) {
+          wr = quad_get_i32<0>(wr);
+          rb = quad_get_i32<0>(rb);
+          mt_ = quad_get_i32<0>(mt_);
+          bP = quad_get_v3<0>(bP);
+          bN = quad_get_v3<0>(bN);
+          bS = quad_get_v3<0>(bS);
+          bR = quad_get_f64<0>(bR);
+        }
+        if (alive && wr) {
+          Pt = bP; Nn = bN; surf = bS; refl_dot = bR; mtl = mt_;
+          li = rb + role;
+          has_light = li < S.n_lights;
+          has_add3 = false;
+          if (has_light) {
+            const MT_CONST mt_light *lt = lights + li;
+            const V3 lpos = v3(lt->position[0], lt->position[1], lt->position[2]);
+            L = normalized(lpos - Pt);
+            lp = v3(1.0, 1.0, 1.0);
+            traversing = false;
+            start = Pt;
+            ro = start + (L * 0.00001);
+            rd = L;
+            mode = MODE_SHADOW;
+          } else {
+            mode = MODE_IDLE;
           }
-          const unsigned from_free = total < n_free ? total : n_free;
-          n_free -= from_free;
-          hw += (int)(total - from_free);
+          if (owner) {
+            want_round = false;
+            waiting_round = true;
+          }
         }
       }
 
-      // ---- completed records hand their value upwards (at most one level per round)
-      wave_release();
-      bool complete = false;  // every part of record rec_c is there: evaluate it
-      if (part_done) {
-        const int old = atomicSub((int *)(rec_ptr(rec) + R_PM), 1);
-        complete = old == 1;
-      }
-      for (int round = 0; round <= P.max_depth + 1; round++) {
-        if (__ballot(complete || finish) == 0ull) break;
-        wave_acquire();
-        if (complete) {
-          // TraceRayWorker's colour, :76-226: the lights in order, then the
-          // reflection, then the refraction.
-          const double *R = rec_ptr(rec_c);
-          V3 color = v3(0, 0, 0);
-          for (int l = 0; l < n_lights; l++) {
-            const double *slot = R + R_LIGHTS + l * kLightSlot;
-            color = color + ld3(slot);
-            color = color + ld3(slot + 3);
-            if (slot[9] != 0.0) color = color + ld3(slot + 6);
+      // ---- stage 3 (owner, per lane): recursion decisions and returns
+      if (alive && owner) {
+        if (after_lights) {
+          const MT_CONST mt_material *m = mtls + mtl;
+          const double refl = m->reflectance, tr = m->transparency;
+          if (level < P.max_depth && refl > 0.0 && coef > 0.01 && !in_object) {  // :181-189
+            fio.put3(level, 0, color);
+            fio.put3(level, 3, Pt);
+            fio.put3(level, 6, dir);
+            *fio.slot(level, 9) = coef;
+            *(long long *)fio.slot(level, 10) =
+                (long long)mtl | ((long long)(in_object ? 1 : 0) << 32) | ((long long)STAGE_REFL << 33);
+            ro = Pt + (Rd * 0.0001);  // :70-74
+            rd = Rd;
+            coef = coef * refl;
+            level++;
+            mode = MODE_RADIANCE;
+          } else if (level < P.max_depth && tr > 0.0) {  // :192-225
+            fio.put3(level, 0, color);
+            *(long long *)fio.slot(level, 10) =
+                (long long)mtl | ((long long)(in_object ? 1 : 0) << 32) | ((long long)STAGE_REFR << 33);
+            const V3 rdir = normalized(dir);  // :208-212 (direction unchanged, re-normalised)
+            ro = Pt + rdir * 0.00001;
+            rd = rdir;
+            in_object = !in_object;
+            level++;
+            mode = MODE_RADIANCE;
+          } else {
+            retval = color;
+            do_return = true;
           }
-          const unsigned long long meta = *(const unsigned long long *)(R + R_META);
-          const mt_material *m = mtls + *((const int *)(R + R_PM) + 1);
-          if (meta & M_HAS_REFL) color = color + ld3(R + R_RETREFL) * m->reflectance;  // :185-188
-          if (meta & M_HAS_REFR) {                                                      // :220-224
-            const V3 tf = v3(m->transmission_filter[0], m->transmission_filter[1], m->transmission_filter[2]);
-            color = color + ld3(R + R_RETREFR) * tf * m->transparency;
-          }
-          retval = color;
-          finish = true;
-          complete = false;
         }
-        unsigned parent = 0u;
-        bool to_parent = false;
-        if (finish) {
-          const double *R = rec_ptr(rec_c);
-          const unsigned long long meta = *(const unsigned long long *)(R + R_META);
-          if ((meta & 0xffffffffull) == M_NOPARENT) {
-            uint8_t *o = P.out_rgb + *(const unsigned long long *)(R + R_PX) * 3;  // V3DtoRGB + chunk-local store, :301
+
+        while (do_return) {  // unwinding TraceRayWorker returns
+          if (level == 0) {
+            uint8_t *o = P.out_rgb + px_index * 3;  // V3DtoRGB + chunk-local store, :301
             o[0] = channel_to_u8(retval.x);
             o[1] = channel_to_u8(retval.y);
             o[2] = channel_to_u8(retval.z);
-          } else {
-            parent = (unsigned)(meta & 0xffffffffull);
-            st3(rec_ptr(parent) + ((meta & M_KIND_REFR) ? R_RETREFR : R_RETREFL), retval);
-            to_parent = true;
+            alive = false;
+            break;
           }
-          finish = false;
-        }
-        {  // the finished child records go back to the free list
-          const unsigned long long fm = __ballot(to_parent);
-          if (to_parent) freel[n_free + (unsigned)lanes_below(fm)] = rec_c;
-          n_free += (unsigned)__builtin_popcountll(fm);
-        }
-        wave_release();
-        if (to_parent) {
-          const int old = atomicSub((int *)(rec_ptr(parent) + R_PM), 1);
-          complete = old == 1;
-          rec_c = parent;
+          level--;
+          const long long meta = *(long long *)fio.slot(level, 10);
+          const int fm = (int)(meta & 0xffffffffll);
+          const bool f_in = ((meta >> 32) & 1) != 0;
+          const int stage = (int)((meta >> 33) & 1);
+          const MT_CONST mt_material *m = mtls + fm;
+          const V3 fcolor = fio.get3(level, 0);
+          if (stage == STAGE_REFL) {
+            color = fcolor + retval * m->reflectance;  // :185-188
+            const double tr = m->transparency;
+            if (tr > 0.0) {  // level < max_depth holds: this frame pushed a child
+              Pt = fio.get3(level, 3);
+              dir = fio.get3(level, 6);
+              coef = *fio.slot(level, 9);
+              fio.put3(level, 0, color);
+              *(long long *)fio.slot(level, 10) =
+                  (long long)fm | ((long long)(f_in ? 1 : 0) << 32) | ((long long)STAGE_REFR << 33);
+              const V3 rdir = normalized(dir);
+              ro = Pt + rdir * 0.00001;
+              rd = rdir;
+              in_object = !f_in;
+              level++;
+              mode = MODE_RADIANCE;
+              do_return = false;
+            } else {
+              retval = color;
+            }
+          } else {
+            const V3 tf = v3(m->transmission_filter[0], m->transmission_filter[1],
+                             m->transmission_filter[2]);
+            retval = fcolor + retval * tf * m->transparency;  // :220-224
+          }
         }
       }
-
-      // ---- new rays, bottom to top: refraction children, reflection children,
-      // then the shadow rays light by light, light 0 on top -- the next pass
-      // starts with rays of one light from neighbouring pixels.
-      {
-        const unsigned long long m2 = __ballot(e_refr != E_NONE);
-        if (e_refr != E_NONE) pool[n_pool + (unsigned)lanes_below(m2)] = e_refr;
-        n_pool += (unsigned)__builtin_popcountll(m2);
-        const unsigned long long m1 = __ballot(e_refl != E_NONE);
-        if (e_refl != E_NONE) pool[n_pool + (unsigned)lanes_below(m1)] = e_refl;
-        n_pool += (unsigned)__builtin_popcountll(m1);
-        for (int l = n_lights - 1; l >= 0; l--) {
-          const bool mine = fresh || (again && li == l);
-          const unsigned long long ml = __ballot(mine);
-          if (mine) pool[n_pool + (unsigned)lanes_below(ml)] = rec | ((unsigned)(l + 1) << 24) | (again ? E_CONT : 0u);
-          n_pool += (unsigned)__builtin_popcountll(ml);
-        }
+      // helpers leave with their owner
+      if (quad) {
+        const int oa = quad_get_i32<0>(alive ? 1 : 0);
+        if (!owner) alive = alive && (oa != 0);
       }
-      wave_release();
     }
 
     if (S.hb && lane == 0) S.hb[wave_id * 4 + 0] = 4;
@@ -726,7 +726,6 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
       }
     }
     flush_item_stats<STATS>(st, P.counters, lane);
-    if (failed) break;
   }
   if (S.hb && lane == 0) S.hb[wave_id * 4 + 0] = 5;
 }
@@ -806,5 +805,9 @@ __global__ void blit_tiles_kernel(int image_w, int image_h, int tile_w, int tile
 
 template __global__ void render_kernel<true>(DevScene, RenderParams);
 template __global__ void render_kernel<false>(DevScene, RenderParams);
+template __global__ void primary_kernel<true>(DevScene, RenderParams);
+template __global__ void primary_kernel<false>(DevScene, RenderParams);
+template __global__ void pool_kernel<true>(DevScene, RenderParams);
+template __global__ void pool_kernel<false>(DevScene, RenderParams);
 
 }  // namespace mt

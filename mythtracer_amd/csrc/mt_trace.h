@@ -1068,10 +1068,123 @@ __device__ __attribute__((noinline)) ScanOut scan_small_lane_call(const double *
 // (subtree_may_hit, applied inside order_children to the children some lane
 // enters).
 
-// Regular-mode ordering, inlined into the traversal (small: ~35 VGPRs); the
-// exact-mode variant below stays a function of its own.
+// Regular-mode ordering WITH subtree boxes, survivors first.  order_children
+// evaluates all eight children (slab test, subtree test, 28-pair rank sort:
+// ~490 vector instructions), although a ray enters at most four octants and
+// most of those hold nothing it can hit.  Here the cheap conservative test
+// comes first -- the fp32 subtree boxes of the non-empty children -- and the
+// reference's slab arithmetic, validity test and sort (octtree.cc:204-216) run
+// only for the children that survive it, lane by lane: typically one or two.
+// The result is the same list: a child is on it iff its slab test passes
+// (identical products and comparisons as order_children<1>) and its subtree
+// may be hit; the order is by (tmin, child index), which is what the stable
+// sort of a NaN-free key gives.
+__device__ __forceinline__ unsigned order_children_culled(const NodeRec *N, const RayRegs &r, const float *sub,
+                                                          const Filter32 &f, bool uniform_node) {
+  const bool sx = __builtin_signbit(r.ix), sy = __builtin_signbit(r.iy), sz = __builtin_signbit(r.iz);
+  const unsigned cm = (unsigned)(uniform_node ? as_const(uniform_ptr(N))->child_mask : N->child_mask) & 0xffu;
+  // 1. survivors of the subtree test (near / far planes picked by the lane's direction signs)
+  const float *bn_x = sub + (sx ? 3 : 0), *bf_x = sub + (sx ? 0 : 3);
+  const float *bn_y = sub + (sy ? 4 : 1), *bf_y = sub + (sy ? 1 : 4);
+  const float *bn_z = sub + (sz ? 5 : 2), *bf_z = sub + (sz ? 2 : 5);
+  unsigned km = 0u;
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    const bool nonempty = ((cm >> c) & 1u) != 0u;
+    if (__ballot(nonempty) == 0ull) continue;  // wave-uniform
+    const float tnx = __builtin_fmaf(bn_x[c * 6], f.ix, f.cnx), tfx = __builtin_fmaf(bf_x[c * 6], f.ix, f.cfx);
+    const float tny = __builtin_fmaf(bn_y[c * 6], f.iy, f.cny), tfy = __builtin_fmaf(bf_y[c * 6], f.iy, f.cfy);
+    const float tnz = __builtin_fmaf(bn_z[c * 6], f.iz, f.cnz), tfz = __builtin_fmaf(bf_z[c * 6], f.iz, f.cfz);
+    const float lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+    const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+    const bool may = !(hi < 0.0f) && !(lo > hi);  // NaN: keep
+    km |= (nonempty && may) ? (1u << c) : 0u;
+  }
+  if (__ballot(km != 0u) == 0ull) return 0u;
+  // 2. the nine plane distances of NodeIntersectRay, shared by the children (as in order_children)
+  const MT_CONST NodeRec *Nc = as_const(uniform_node ? uniform_ptr(N) : N);
+  double xmin[2], xmax[2], ymin[2], ymax[2], zmin[2], zmax[2];
+  {
+    const double t0 = (Nc->lo[0] - r.ox) * r.ix, tc = (Nc->c[0] - r.ox) * r.ix, t1 = (Nc->hi[0] - r.ox) * r.ix;
+    xmax[0] = __builtin_fmax(t0, tc); xmin[0] = __builtin_fmin(t0, tc);
+    xmax[1] = __builtin_fmax(tc, t1); xmin[1] = __builtin_fmin(tc, t1);
+  }
+  {
+    const double t0 = (Nc->lo[1] - r.oy) * r.iy, tc = (Nc->c[1] - r.oy) * r.iy, t1 = (Nc->hi[1] - r.oy) * r.iy;
+    ymax[0] = __builtin_fmax(t0, tc); ymin[0] = __builtin_fmin(t0, tc);
+    ymax[1] = __builtin_fmax(tc, t1); ymin[1] = __builtin_fmin(tc, t1);
+  }
+  {
+    const double t0 = (Nc->lo[2] - r.oz) * r.iz, tc = (Nc->c[2] - r.oz) * r.iz, t1 = (Nc->hi[2] - r.oz) * r.iz;
+    zmax[0] = __builtin_fmax(t0, tc); zmin[0] = __builtin_fmin(t0, tc);
+    zmax[1] = __builtin_fmax(tc, t1); zmin[1] = __builtin_fmin(tc, t1);
+  }
+  // 3. slab test of each lane's k-th survivor (ascending child index)
+  double st[8];
+  unsigned sc[8];
+  bool sv[8];
+  unsigned work = km;
+  int K = 0;  // wave-uniform: slots in use
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    st[k] = 0.0; sc[k] = 0u; sv[k] = false;
+  }
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (__ballot(work != 0u) == 0ull) break;
+    K = k + 1;
+    const bool has = work != 0u;
+    const unsigned c = has ? (unsigned)__builtin_ctz(work) : 0u;
+    work &= work - 1u;
+    const bool xh = (c & 1u) != 0u, zh = (c & 2u) != 0u, yh = (c & 4u) != 0u;  // octtree.cc:61-100
+    const double tmax = __builtin_fmin(__builtin_fmin(xh ? xmax[1] : xmax[0], yh ? ymax[1] : ymax[0]),
+                                       zh ? zmax[1] : zmax[0]);
+    const double tmin = __builtin_fmax(__builtin_fmax(xh ? xmin[1] : xmin[0], yh ? ymin[1] : ymin[0]),
+                                       zh ? zmin[1] : zmin[0]);
+    st[k] = tmin;
+    sc[k] = c;
+    sv[k] = has && (tmax >= 0.0) && (tmin <= tmax);
+  }
+  // 4. rank by (tmin, child index) among the valid slots; slots are in ascending child index
+  unsigned rank[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) rank[k] = 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+#pragma unroll
+    for (int j = i + 1; j < 8; j++) {
+      if (j >= K) continue;  // wave-uniform
+      const bool both = sv[i] && sv[j];
+      const bool j_first = st[j] < st[i];
+      rank[i] += (both && j_first) ? 1u : 0u;
+      rank[j] += (both && !j_first) ? 1u : 0u;
+    }
+  }
+  unsigned ord = 0u, cnt = 0u;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (k >= K) continue;  // wave-uniform
+    if (sv[k]) {
+      ord |= sc[k] << (3u * rank[k]);
+      cnt++;
+    }
+  }
+  return (ord & 0x00ffffffu) | (cnt << 24);
+}
+
+#ifdef MT_SURVIVORS_FIRST
+constexpr bool kSurvivorsFirst = true;
+#else
+constexpr bool kSurvivorsFirst = false;  // experimental: slower on whole frames
+#endif
+// Regular-mode ordering, inlined into the traversal; the exact-mode variant
+// below stays a function of its own.
 __device__ __forceinline__ unsigned order_children_regular(const NodeRec *N, const RayRegs &r, const float *sub,
-                                                           const Filter32 &f, bool uniform_node) {
+                                                           const Filter32 &f, bool uniform_node,
+                                                           bool survivors_first) {
+  if (sub != nullptr && survivors_first) {
+    return order_children_culled(N, r, uniform_node ? uniform_ptr(sub) : sub, f, uniform_node);
+  }
   unsigned keep = 0xffu, um = 0xffu;
   if (sub != nullptr) {
     // children with an empty subtree (NodeRec::child_mask) are dropped by the
@@ -1266,6 +1379,114 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
     o.t_b += (unsigned)(__builtin_amdgcn_s_memtime() - tg1);
 #endif
   }
+  o.mt_tests = st.v[ST_MT_TESTS];
+  return o;
+}
+
+
+#ifdef MT_VEC_SCAN
+constexpr bool kVecScan = true;
+#else
+constexpr bool kVecScan = false;  // experimental: slower than the scalar-load scans on whole frames
+#endif
+// ---- big node, ray-parallel, boxes through vector loads -----------------------
+// The scalar-load scans above fetch four boxes per round trip to the scalar
+// cache; a node step was a chain of ~9 dependent round trips and the wave spent
+// most of its time waiting for them.  Here every LANE fetches one box -- lane j
+// the j-th block box of the node, later lane k the k-th triangle box of the live
+// blocks -- so that 64 boxes cost ONE round trip, and the loop then hands box
+// after box to all rays with v_readlane (six per box; the box becomes a scalar
+// operand of the same ten fp32 filter instructions as before).  When the lanes
+// that want the node share a sign octant, every lane swaps its box's planes to
+// (near, far) ONCE, before the loop, so one loop serves all eight octants.
+// Same tests on the same boxes in the same order as scan_grouped_call: block box
+// (may reject all 16 members), fp32 triangle box (conservative), exact fp64 box
+// test, Möller–Trumbore for the survivors in stream order.
+// Must be called by ALL 64 lanes (`in` = lanes that want this node).
+template <bool STATS>
+__device__ __forceinline__ ScanOut scan_big_vec(const DevScene &S, int lane, int pb, int pc, bool in,
+                                                const RayRegs &r, const Filter32 &f, bool one_octant,
+                                                int sx, int sy, int sz) {
+  ScanOut o{-1, 0.0, 0u};
+  LaneStats st;
+  st.clear();
+  int pend = -1;
+  unsigned long long pmask = 0ull;  // lanes holding a parked candidate
+  const unsigned long long inmask = __builtin_amdgcn_ballot_w64(in);
+  const unsigned long long me = 1ull << lane;
+  const int b0 = pb / kGroupTris, nb = (pb + pc - 1) / kGroupTris - b0 + 1;
+  const float *gp = S.grp_aabb32 + (size_t)b0 * 6;
+  // fp32 verdict of all rays for the box held by lane j of (n0..f2): planes as
+  // (near xyz, far xyz) when one_octant, else (min xyz, max xyz)
+  auto verdict = [&](float n0, float n1, float n2, float f0, float f1, float f2, int j) -> unsigned long long {
+    const float b[6] = {readlane_f32(n0, j), readlane_f32(n1, j), readlane_f32(n2, j),
+                        readlane_f32(f0, j), readlane_f32(f1, j), readlane_f32(f2, j)};
+    return (one_octant ? filter32_pass<0>(b, f) : filter32_pass<8>(b, f)) & inmask;
+  };
+  for (int g0 = 0; g0 < nb; g0 += 64) {
+    const int n = (nb - g0) < 64 ? (nb - g0) : 64;
+    unsigned long long live = 0ull;
+    {
+      const float *bp = gp + (size_t)(g0 + (lane < n ? lane : n - 1)) * 6;
+      const float x0 = bp[0], y0 = bp[1], z0 = bp[2], x1 = bp[3], y1 = bp[4], z1 = bp[5];
+      const float n0 = (one_octant && sx) ? x1 : x0, f0 = (one_octant && sx) ? x0 : x1;
+      const float n1 = (one_octant && sy) ? y1 : y0, f1 = (one_octant && sy) ? y0 : y1;
+      const float n2 = (one_octant && sz) ? z1 : z0, f2 = (one_octant && sz) ? z0 : z1;
+      for (int j = 0; j < n; j++) {
+        if (verdict(n0, n1, n2, f0, f1, f2, j) != 0ull) live |= 1ull << j;
+      }
+    }
+#ifdef MT_PROF
+    o.n_groups += (unsigned)n;
+    o.n_live += (unsigned)__builtin_popcountll(live);
+#endif
+    // the triangles of the live blocks, four blocks (64 triangles) per step
+    while (live != 0ull) {
+      constexpr int kSlices = 64 / kGroupTris;
+      const int slice = lane / kGroupTris;
+      int myq = -1;
+#pragma unroll
+      for (int q = 0; q < kSlices; q++) {
+        if (live != 0ull) {
+          const int blk = g0 + __builtin_ctzll(live);
+          live &= live - 1;
+          if (slice == q) myq = blk;
+        }
+      }
+      const int tri = (b0 + myq) * kGroupTris + (lane % kGroupTris);  // stream position
+      const bool ok = myq >= 0 && tri >= pb && tri < pb + pc;
+      const int tri_c = ok ? tri : pb;
+      const float *bp = S.tri_aabb32 + (size_t)tri_c * 6;
+      const float x0 = bp[0], y0 = bp[1], z0 = bp[2], x1 = bp[3], y1 = bp[4], z1 = bp[5];
+      const float n0 = (one_octant && sx) ? x1 : x0, f0 = (one_octant && sx) ? x0 : x1;
+      const float n1 = (one_octant && sy) ? y1 : y0, f1 = (one_octant && sy) ? y0 : y1;
+      const float n2 = (one_octant && sz) ? z1 : z0, f2 = (one_octant && sz) ? z0 : z1;
+      unsigned long long todo = __builtin_amdgcn_ballot_w64(ok);  // ascending lane = ascending stream position
+#ifdef MT_PROF
+      o.n_ranges++;
+      o.n_range_tris += (unsigned)__builtin_popcountll(todo);
+#endif
+      while (todo != 0ull) {
+        const int j = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const unsigned long long m = verdict(n0, n1, n2, f0, f1, f2, j);
+        if (m == 0ull) continue;
+        // exact fp64 test (primitive_triangle.cc:83-108) for the rays the filter let through
+        const int tj = __builtin_amdgcn_readlane(tri_c, j);
+        const MT_CONST double *a = as_const(S.tri_aabb) + (size_t)tj * 6;
+        const double bx[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
+        const unsigned long long pm = slab_pass<1, 0>(bx, r) & m;
+        if (pm == 0ull) continue;
+        if (pm & pmask) {  // some lane would need a second slot: resolve first
+          flush_candidates<STATS>(S, r, pend, o.best, o.best_t, st);
+          pmask = 0ull;
+        }
+        if ((pm & me) != 0ull) pend = tj;
+        pmask |= pm;
+      }
+    }
+  }
+  if (pmask) flush_candidates<STATS>(S, r, pend, o.best, o.best_t, st);
   o.mt_tests = st.v[ST_MT_TESTS];
   return o;
 }
@@ -1479,12 +1700,13 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   const int szl = __builtin_signbit(r.iz) ? 1 : 0;
 
   // Record of the node a lane has to process next (valid while cur >= 0).
-  int cur_fc = 0, cur_pb = 0, cur_pc = 0;
+  int cur_fc = 0, cur_pb = 0, cur_pc = 0, cur_level = 0;
   auto load_record = [&](int node) {
-    const int *q = (const int *)(S.nodes + node) + 18;  // NodeRec: first_child, prim_begin, prim_count
+    const int *q = (const int *)(S.nodes + node) + 18;  // NodeRec: first_child, prim_begin, prim_count, (mask), level
     cur_fc = q[0];
     cur_pb = q[1];
     cur_pc = q[2];
+    cur_level = q[4];
   };
   if (cur >= 0) load_record(cur);
 
@@ -1560,6 +1782,171 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   // node at most once per query, so 64 * n_nodes steps can never be exceeded.
   const long long step_bound = 64ll * (long long)S.n_nodes + 64;
   long long steps = 0;
+#ifdef MT_DIAG
+  unsigned diag_a_trips = 0, diag_transposed = 0, diag_vec = 0;
+#endif
+  // Main loop.  (A) every lane works through the small nodes on its path by
+  // itself.  (B) When all lanes wait at big nodes, the wave takes the
+  // SHALLOWEST tree level at which some lane waits and scans every distinct
+  // node of that level, each for the lanes that wait at it; then the children
+  // of all those nodes are ordered and all those lanes step on (finish_node)
+  // TOGETHER.  Nodes of one level are disjoint subtrees, so a lane that leaves
+  // one of them can never arrive at another one of the same batch: taking the
+  // whole level at once loses none of the sharing that "lowest-numbered node
+  // first" gives (lanes above still catch up with lanes waiting deeper), but
+  // the ordering/unwind code runs once per level instead of once per node --
+  // with incoherent rays (20..50 distinct big nodes per traversal) that is a
+  // large part of the time.  EXPERIMENTAL (-DMT_LEVEL_LOOP): measured slower
+  // than the node-at-a-time loop below on whole frames.
+#ifdef MT_LEVEL_LOOP
+  {
+  for (;;) {
+    // ---- phase A: every lane works through its own small nodes
+    if (lane_phase) {
+      for (int guard = 0; cur >= 0 && cur_pc < kBigNode; guard++) {
+        if (guard > S.n_nodes) {
+          cur = -2;
+          break;
+        }
+#ifdef MT_DIAG
+        diag_a_trips++;
+#endif
+        const ScanOut o = (use_filter && S.force_mode != 4)
+            ? scan_small_lane_f32_call<STATS>(S.self, cur_pb, cur_pc, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
+            : all_regular
+            ? scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz)
+            : scan_small_lane_call<true, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz);
+        if (STATS) {
+          __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)cur_pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        unsigned ordw = 0;
+        const int fc = cur_fc;
+        if (fc != 0) {
+          if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          const NodeRec *Np = S.nodes + cur;
+          const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
+          ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, S.force_mode != 9)
+                             : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                              irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr);
+        }
+        finish_node(fc, ordw, o.best, o.best_t);
+      }
+      if (__ballot(cur == -2) != 0ull) {
+        status = DEV_ERR_UNWIND_BOUND;
+        break;
+      }
+    }
+    // ---- phase B: the big nodes of the shallowest level some lane waits at
+    const int lvl = wave_min_i32(cur >= 0 ? cur_level : 0x7fffffff);
+    if (lvl == 0x7fffffff) break;
+    const bool at = cur >= 0 && cur_level == lvl;
+    int best = -1;
+    double best_t = 0.0;
+    const int my_node = cur, my_fc = cur_fc, my_pb = cur_pb, my_pc = cur_pc;
+    bool pend = at;
+    for (;;) {
+      const int n = wave_min_i32(pend ? my_node : 0x7fffffff);
+      if (n == 0x7fffffff) break;
+      if (++steps > step_bound || n < 0 || n >= S.n_nodes) {
+        status = DEV_ERR_TRAVERSAL_BOUND;
+        break;
+      }
+      const bool in = pend && (my_node == n);
+      pend = pend && !in;
+      const unsigned long long inmask = __ballot(in);
+      const int src = __builtin_ctzll(inmask);
+      const int pb = __builtin_amdgcn_readlane(my_pb, src);
+      const int pc = __builtin_amdgcn_readlane(my_pc, src);
+      if (STATS) {
+        st.wave_node_steps++;
+        st.wave_tri_steps += (unsigned)pc;
+      }
+      // wave-uniform mode choice for this node
+      int mode = 0;
+      int sx = 0, sy = 0, sz = 0;
+      if (all_regular) {
+        mode = 1;
+        if (S.force_mode != 2) {
+          const unsigned long long mxs = __ballot(in && sxl), mys = __ballot(in && syl), mzs = __ballot(in && szl);
+          if ((mxs == 0 || mxs == inmask) && (mys == 0 || mys == inmask) && (mzs == 0 || mzs == inmask)) {
+            mode = 2;
+            sx = mxs != 0; sy = mys != 0; sz = mzs != 0;
+          }
+        }
+      }
+      const int n_in = __builtin_popcountll(inmask);
+      const int chunks = (pc + 63) >> 6;
+      const bool blocks_ok = all_regular && use_filter && pc >= kBigNode && S.force_mode != 6;
+      const int nblk = (pb + pc - 1) / kGroupTris - pb / kGroupTris + 1;
+      const bool blocks_irr = irr_boxes && pc >= kBigNode && n_in <= 16;
+      const bool transposed =
+          (S.force_mode != 3) && pc > 0 &&
+          (blocks_irr ? true
+           : blocks_ok ? (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk)
+                       : (n_in * (30 + 45 * chunks) < 20 * pc));
+      const bool vec_scan = !transposed && blocks_ok && (mode == 1 || mode == 2) && kVecScan;
+#ifdef MT_DIAG
+      if (transposed) diag_transposed++;
+      if (vec_scan) diag_vec++;
+#endif
+      ScanOut o{-1, 0.0, 0u};
+      if constexpr (kVecScan) {
+        if (vec_scan) o = scan_big_vec<STATS>(S, lane, pb, pc, in, r, f32, mode == 2, sx, sy, sz);
+      }
+      if (vec_scan) {
+      } else if (transposed) {
+        if (STATS) st.wave_tri_steps += (unsigned)(n_in * chunks) - (unsigned)pc;  // replaces the pc counted above
+        o = blocks_ok
+            ? scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
+            : blocks_irr
+            ? scan_transposed_blocks_call<true, STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
+            : (mode == 0)
+            ? scan_transposed_call<true, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), MT_RAY_ARGS(r))
+            : scan_transposed_call<false, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), MT_RAY_ARGS(r));
+      } else if (in) {
+        const int oct = sx | (sy << 1) | (sz << 2);
+        const float *g32 = nullptr;
+        if (pc >= kBigNode && S.force_mode != 6) g32 = S.grp_aabb32;
+        if (mode == 2 && use_filter) o = scan_filtered_dispatch<STATS>(S, oct, g32, pb, pc, r, f32);
+        else if (mode == 1 && use_filter && g32 != nullptr) o = scan_filtered_dispatch<STATS>(S, 8, g32, pb, pc, r, f32);
+        else if (mode == 2) o = scan_octant_dispatch<STATS>(S, oct, pb, pc, r);
+        else if (mode == 1) o = scan_exact_call<1, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
+        else o = scan_exact_call<0, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
+      }
+      if (in) {
+        best = o.best;
+        best_t = o.best_t;
+        if (STATS) {
+          __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+      }
+    }
+    if (status != DEV_OK) break;
+    // ---- the children of every node of the batch, then all its lanes step on
+    if (at) {
+      unsigned ordw = 0;
+      if (my_fc != 0) {
+        if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const NodeRec *Np = S.nodes + my_node;
+        const float *sub = cull ? S.sub_aabb32 + (size_t)my_fc * 6 : nullptr;
+        ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, S.force_mode != 9)
+                           : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                            irr_boxes ? S.sub_aabb32 + (size_t)my_fc * 6 : nullptr);
+      }
+      finish_node(my_fc, ordw, best, best_t);
+    }
+    if (__ballot(cur == -2) != 0ull) {
+      status = DEV_ERR_UNWIND_BOUND;
+      break;
+    }
+  }
+  }
+#else
+  {
   for (;;) {
     // ---- phase A: every lane works through its own small nodes
     if (lane_phase) {
@@ -1569,6 +1956,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           cur = -2;
           break;
         }
+#ifdef MT_DIAG
+        diag_a_trips++;
+#endif
 #if MT_DUP == 2
         if (use_filter && S.force_mode != 4) {
           const ScanOut od = scan_small_lane_f32_call<STATS>(S.self, cur_pb, cur_pc, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
@@ -1592,9 +1982,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           const NodeRec *Np = S.nodes + cur;
           const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
 #if MT_DUP == 1
-          if (all_regular) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, false)));
+          if (all_regular) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, false, kSurvivorsFirst)));
 #endif
-          ordw = all_regular ? order_children_regular(Np, r, sub, f32, false)
+          ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, kSurvivorsFirst)
                              : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                               irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr);
         }
@@ -1662,6 +2052,24 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     int best = -1;
     double best_t = 0.0;
     MT_PROF_BEGIN(prof_t1);
+    // regular rays + block boxes: boxes by vector load, one per lane (scan_big_vec)
+    const bool vec_scan = !transposed && blocks_ok && (mode == 1 || mode == 2) && kVecScan;
+#ifdef MT_DIAG
+    if (transposed) diag_transposed++;
+    if (vec_scan) diag_vec++;
+#endif
+    if constexpr (kVecScan) if (vec_scan) {
+      const ScanOut o = scan_big_vec<STATS>(S, lane, pb, pc, in, r, f32, mode == 2, sx, sy, sz);
+      best = o.best;
+      best_t = o.best_t;
+      if (STATS && in && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#ifdef MT_PROF
+      MT_PROF_COUNT(PROF_G_GROUPS, __builtin_amdgcn_readfirstlane(o.n_groups));
+      MT_PROF_COUNT(PROF_G_LIVE, __builtin_amdgcn_readfirstlane(o.n_live));
+      MT_PROF_COUNT(PROF_G_RANGES, __builtin_amdgcn_readfirstlane(o.n_ranges));
+      MT_PROF_COUNT(PROF_G_RANGE_TRIS, __builtin_amdgcn_readfirstlane(o.n_range_tris));
+#endif
+    }
     if (transposed) {
       MT_PROF_COUNT(PROF_N_TRANSPOSED, 1);
       MT_PROF_COUNT(PROF_N_CHUNKS, n_in * chunks);
@@ -1698,7 +2106,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
-      if (!transposed) {
+      if (!transposed && !vec_scan) {
         const int oct = sx | (sy << 1) | (sz << 2);
         ScanOut o;
         const float *g32 = nullptr;
@@ -1755,11 +2163,11 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         const NodeRec *Np = S.nodes + n;
         const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
 #if MT_DUP == 1
-        if (mode != 0) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, true)));
+        if (mode != 0) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, true, kSurvivorsFirst)));
 #endif
         ordw = (mode == 0) ? order_children_exact_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                        irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr)
-                           : order_children_regular(Np, r, sub, f32, true);
+                           : order_children_regular(Np, r, sub, f32, true, kSurvivorsFirst);
       }
       finish_node(fc, ordw, best, best_t);
     }
@@ -1769,6 +2177,15 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       break;
     }
   }
+  }
+#endif
+#ifdef MT_DIAG
+  {  // wave-uniform diagnostics packed into wave_tri_steps: A-phase trips (max over lanes) | transposed << 12 | vec << 22
+    unsigned mx = diag_a_trips;
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+    st.wave_tri_steps = (mx & 0xfffu) | ((diag_transposed & 0x3ffu) << 12) | ((diag_vec & 0x3ffu) << 22);
+  }
+#endif
   if (status != DEV_OK) break;
   }  // rounds
   MT_PROF_END(PROF_TRACE, prof_t0);

@@ -20,8 +20,8 @@ passes = (a[:, 1] >> np.uint64(40)).astype(np.float64)
 sub = (a[:, 1] & np.uint64(0xff)).astype(np.int64) - 1
 print("kernel_ms", g.get("kernel_ms"), "rays", rays, {k: int(st[k]) for k in st if k.startswith("rays") or k in ("node_visits", "wave_node_steps", "wave_tri_steps", "mt_tests", "shaded_hits")})
 print("units %d passes total %.0f -> rays per pass %.1f" % (len(d), passes.sum(), rays / passes.sum()))
-print("cycles total %.3e -> cycles per pass %.0f" % (d.sum(), d.sum() / passes.sum()))
-for name, sel in (("whole blocks", sub < 0), ("quarters", sub >= 0)):
+print("cycles total %.3e -> cycles per pass %.0f ; longest unit %.3e ; perfect balance over 3072 waves %.3e" % (d.sum(), d.sum() / passes.sum(), d.max(), d.sum() / 3072))
+for name, sel in (("whole blocks", sub < 0), ("quarters", (sub >= 0) & (sub < 4)), ("2x2 cells", sub >= 4)):
     if sel.sum():
         print(" %s: units %d passes %.0f cycles %.3e (%.1f%% of all) cycles/pass %.0f" % (
             name, sel.sum(), passes[sel].sum(), d[sel].sum(), 100 * d[sel].sum() / d.sum(), d[sel].sum() / passes[sel].sum()))

@@ -34,6 +34,15 @@ def _libs(native_libs):
     assert M.hip_abi().device_count() >= 1, "no GPU visible: the HIP path cannot run"
 
 
+@pytest.fixture(params=["state_machine", "ray_pool"], autouse=True)
+def engine(request, monkeypatch):
+    """Every test runs through both frame engines (include/mythtracer_hip.h,
+    mt_scene_set_engine): the per-lane state machine and the per-wave ray pool
+    must give the same pixels, debug buffers and counters."""
+    monkeypatch.setenv("MT_ENGINE", "1" if request.param == "state_machine" else "2")
+    return request.param
+
+
 PRUNED = ("box_tests", "node_visits", "tri_tests")
 
 
