@@ -75,6 +75,9 @@ __device__ __forceinline__ V3 texel(const DevTexture &t, size_t idx) {
 }
 
 __device__ __forceinline__ V3 texture_color_at(const DevTexture &t, double u, double v) {
+  // NaN coordinates (degenerate triangles): the reference's (size_t)NaN index makes
+  // colors.at() throw; defined here, like every out-of-range texel, as a NaN colour.
+  if (u != u || v != v) return V3{__builtin_nan(""), __builtin_nan(""), __builtin_nan("")};
   u = fmod1(u);
   v = fmod1(v);
   if (u < 0.0) u += 1.0;

@@ -66,7 +66,10 @@ class MythTracer {
   bool RayTrace(WorkChunk* chunk);
 
   // --- extensions (not in the reference)
-  void SetDevice(int hip_device) { device_ = hip_device; }
+  void SetDevice(int hip_device) {
+    device_ = hip_device;
+    scene.tree.SetDevice(hip_device);
+  }
   void SetMaxRecursionLevel(int level) { max_level_ = level; }  // default MAX_RECURSION_LEVEL
   void SetQuiet(bool quiet) {                                   // no progress text on stdout
     quiet_ = quiet;

@@ -48,6 +48,8 @@ class OctTree {
   bool IsFinalized() const { return finalized_; }
   // extension: no "Triangles: N" line on stdout
   void SetQuiet(bool quiet) { quiet_ = quiet; }
+  // extension: HIP device of the standalone IntersectRay(s) (MythTracer::SetDevice forwards to it)
+  void SetDevice(int hip_device) { device_ = hip_device; }
 
   // Closest hit of one ray, on the GPU (a batch of one; see IntersectRays for
   // the efficient form).  nullptr when nothing is hit or no GPU is usable (the
@@ -74,6 +76,7 @@ class OctTree {
   FlatTree flat_;
   bool finalized_ = false;
   bool quiet_ = false;
+  int device_ = 0;
   mutable mt_scene* geometry_only_ = nullptr;  // for standalone IntersectRay
   mutable std::string error_;
 };

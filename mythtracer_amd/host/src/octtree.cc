@@ -158,7 +158,7 @@ bool OctTree::IntersectRays(int n, const double* rays, const Primitive** prims, 
     memset(&d, 0, sizeof d);
     d.struct_size = sizeof d;
     d.abi_version = MT_ABI_VERSION;
-    d.device = 0;
+    d.device = device_;
     d.n_nodes = (int32_t)f.NodeCount();
     d.n_tris = (int32_t)nt;
     d.tree_depth = f.depth;

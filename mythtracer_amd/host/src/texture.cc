@@ -75,14 +75,22 @@ Texture* DecodeBMP(const std::vector<uint8_t>& d) {
   if (d.size() < 54) return nullptr;
   const uint32_t data_off = Le32(&d[10]);
   const uint32_t hdr = Le32(&d[14]);
-  if (hdr < 40) return nullptr;
+  if (hdr < 40 || (uint64_t)data_off < 14ull + hdr) return nullptr;  // pixels may not overlap the headers
   const int32_t w = (int32_t)Le32(&d[18]);
   int32_t h = (int32_t)Le32(&d[22]);
   const uint16_t bpp = Le16(&d[28]);
   const uint32_t compression = Le32(&d[30]);
+  if (h == INT32_MIN) return nullptr;  // -h would overflow
   const bool top_down = h < 0;
   if (top_down) h = -h;
   if (!SaneSize(w, h) || (bpp != 24 && bpp != 32) || (compression != 0 && compression != 3)) return nullptr;
+  if (compression == 3) {
+    // BI_BITFIELDS: only the standard layout (stored B, G, R, A) is read below.
+    // The masks follow the 40-byte header (or sit inside a V4/V5 header).
+    if (bpp != 32 || d.size() < 54 + 12) return nullptr;
+    if (Le32(&d[54]) != 0x00ff0000u || Le32(&d[58]) != 0x0000ff00u || Le32(&d[62]) != 0x000000ffu) return nullptr;
+    if (hdr == 40 && data_off < 54 + 12) return nullptr;
+  }
   const size_t bytes_pp = bpp / 8;
   const size_t stride = ((size_t)w * bytes_pp + 3) & ~(size_t)3;
   if (d.size() < (size_t)data_off + stride * (size_t)h) return nullptr;

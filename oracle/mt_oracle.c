@@ -984,6 +984,9 @@ static v3 tri_interpolate(const triangle *t, const v3 attr[3], v3 point) {
 
 /* Texture::GetColorAt, texture.cc:11-58.  UNPINNED (texture.cc not buildable). */
 static v3 tex_color_at(const texture *t, double u, double v) {
+  if (u != u || v != v) { /* (size_t)NaN is undefined; colors.at() throws in the reference */
+    return v3_make(NAN, NAN, NAN);
+  }
   u = fmod(u, 1.0);
   v = fmod(v, 1.0);
   if (u < 0.0) u += 1.0;

@@ -282,5 +282,33 @@ def main():
             big_frames(td)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--depth4" not in sys.argv:
     main()
+
+
+def depth4_frames():
+    """BASELINE configs[3] (recursion depth 4): the reference's depth is a
+    compile-time 5 (mythtracer.h:11), so these vectors come from the ORACLE
+    (oracle/mt_oracle.c, max_level = 4), which is pinned bit-for-bit to the
+    reference at depth 5 by everything else in this directory:
+        python tests/golden/make_golden.py --depth4"""
+    with tempfile.TemporaryDirectory() as td:
+        info = scenegen.write_scene("room", os.path.join(td, "scenes"))
+        o = orclib.OracleScene(info["obj"])
+        o.set_lights(scenegen.ROOM_LIGHTS)
+        W, H = 1920, 1080
+        r = o.render(scenegen.ROOM_CAMERA, W, H, max_level=4, debug=True)
+        fpath = os.path.join(HERE, "frames.json")
+        frames = json.load(open(fpath))
+        key = "room_%dx%d_d4" % (W, H)
+        frames[key] = {"sha256": sha(r["rgb"]), "line_sha256": sha(r["line"].astype("<i4")),
+                       "scene_sha256": info["sha256"], "made_by": "oracle (max_level 4), not the reference",
+                       "rays": {k: r["counters"][k] for k in ("rays_primary", "rays_secondary", "rays_shadow")}}
+        np.savez_compressed(os.path.join(HERE, key + "_sub16.npz"), rgb=r["rgb"][::16, ::16],
+                            line=r["line"][::16, ::16], point=r["point"][::16, ::16])
+        json.dump(frames, open(fpath, "w"), indent=1, sort_keys=True)
+        print(key, frames[key])
+
+
+if "--depth4" in sys.argv and __name__ == "__main__":
+    depth4_frames()

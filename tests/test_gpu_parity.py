@@ -637,3 +637,91 @@ def test_tiles_and_blit_equal_single_launch(scenes):
 def test_smoke_entry():
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_room_at_recursion_depth_4(scenes):
+    """BASELINE.json configs[3]: the room, 3 lights, recursion depth 4
+    (MAX_RECURSION_LEVEL is a compile-time 5 in the reference, mythtracer.h:11,
+    so the checker is the oracle at max_level 4 -- bit-identical to the
+    reference at depth 5 on every golden).  240x135 compared in full with a live
+    oracle render; 1920x1080 against the committed oracle fixture (every 16th
+    pixel + sha256 of frame and first-hit buffer) and its ray counts."""
+    import hashlib
+    m = M.MythTracer(scenes["room"])
+    m.set_max_level(4)
+    o = orclib.OracleScene(scenes["room"])
+    m.set_lights(scenegen.ROOM_LIGHTS)
+    o.set_lights(scenegen.ROOM_LIGHTS)
+    g = m.render(scenegen.ROOM_CAMERA, 240, 135, debug=True)
+    r = o.render(scenegen.ROOM_CAMERA, 240, 135, max_level=4, debug=True)
+    counters_match(g["counters"], r["counters"])
+    assert np.array_equal(g["line"], r["line"]) and np.array_equal(g["point"], r["point"], equal_nan=True)
+    assert_rgb_close(g["rgb"], r["rgb"], "room 240x135 depth 4")
+    r5 = o.render(scenegen.ROOM_CAMERA, 240, 135, max_level=5)
+    assert r5["counters"]["rays_secondary"] > r["counters"]["rays_secondary"]  # the depth matters here
+    frames = json.load(open(os.path.join(GOLDEN, "frames.json")))["room_1920x1080_d4"]
+    g = m.render(scenegen.ROOM_CAMERA, 1920, 1080, debug=True)
+    sub = load("room_1920x1080_d4_sub16")
+    assert np.array_equal(g["line"][::16, ::16], sub["line"])
+    assert np.array_equal(g["point"][::16, ::16], sub["point"], equal_nan=True)
+    assert_rgb_close(g["rgb"][::16, ::16], sub["rgb"], "room 1920x1080 depth 4, every 16th pixel")
+    assert hashlib.sha256(g["line"].astype("<i4").tobytes()).hexdigest() == frames["line_sha256"]
+    assert {k: g["counters"][k] for k in RAY_KEYS} == frames["rays"]
+    sha = hashlib.sha256(g["rgb"].tobytes()).hexdigest()
+    print("room depth 4 frame sha256", sha, "oracle", frames["sha256"], "kernel ms", g["kernel_ms"])
+    if sha != frames["sha256"]:  # count against the oracle, hold to the pow tolerance
+        want = o.render(scenegen.ROOM_CAMERA, 1920, 1080, max_level=4)["rgb"]
+        assert hashlib.sha256(want.tobytes()).hexdigest() == frames["sha256"]
+        assert_rgb_close(g["rgb"], want, "room 1920x1080 depth 4 (full frame)")
+
+
+def _build_seam_driver(tmp_path):
+    import subprocess
+    from mythtracer_amd import build
+    exe = str(tmp_path / "seam_driver")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "seam", "seam_driver.cc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(build.HOST, "include"), "-I", build.INC,
+                           "-o", exe, src, "-L", build.LIB, "-lmythtracer_host", "-lmythtracer_hip",
+                           "-Wl,-rpath," + build.LIB])
+    return exe
+
+
+def test_seam_driver_like_main_local(scenes, tmp_path):
+    """The drop-in claim, executed: a C++ program written against the reference's
+    API (the calls of main_local.cc:34-35,72-110,122,127-132 and of
+    main_net_worker.cc:148-150) is compiled against OUR headers and library,
+    run on the GPU, and its raw frame dump is the reference's frame."""
+    import hashlib
+    import subprocess
+    exe = _build_seam_driver(tmp_path)
+
+    def run(obj, W, H, cam, lights, chunk=None):
+        out = str(tmp_path / "frame.raw")
+        cmd = [exe, obj, str(W), str(H)] + [repr(float(c)) for c in cam] + [str(len(lights))]
+        for l in lights:
+            cmd += [repr(float(c)) for c in l]
+        cmd.append(out)
+        if chunk:
+            cmd += [str(c) for c in chunk] + [str(tmp_path / "chunk.raw"), str(tmp_path / "chunk.dbg")]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 0, r.stderr.decode()
+        return np.fromfile(out, dtype=np.uint8).reshape(H, W, 3), r.stdout.decode()
+
+    # Cornell 256x256: SURVEY 8c's cross-check hash of the reference's frame
+    gold = load("cornell_256")
+    img, stdout = run(CORNELL, 256, 256, CORNELL_CAM, CORNELL_LIGHTS, chunk=(37, 21, 101, 67))
+    assert hashlib.sha256(img.tobytes()).hexdigest() == "5ed1d7bc14717479bb9312fbc1a709a6e3c0f46acf88302d31d9cd941155d201"
+    assert np.array_equal(img, gold["rgb"])
+    assert "Triangles: 12" in stdout and "0.000000 0.000000 0.000000 x 100.000000 100.000000 100.000000" in stdout
+    # the worker's call on a ragged chunk: PXLS bytes + debug buffer
+    crgb = np.fromfile(str(tmp_path / "chunk.raw"), dtype=np.uint8).reshape(67, 101, 3)
+    assert np.array_equal(crgb, gold["rgb"][21:21 + 67, 37:37 + 101])
+    dbg = np.fromfile(str(tmp_path / "chunk.dbg"), dtype=np.dtype([("line", "<i4"), ("point", "<f8", 3)]))
+    assert np.array_equal(dbg["line"].reshape(67, 101), gold["line"][21:21 + 67, 37:37 + 101])
+    assert np.array_equal(dbg["point"].reshape(67, 101, 3), gold["point"][21:21 + 67, 37:37 + 101], equal_nan=True)
+    # one view of the room (golden made by the reference)
+    view = load("room_view_back")
+    W, H = (int(v) for v in view["image"])
+    img, _ = run(scenes["room"], W, H, view["cam"], view["lights"])
+    assert_rgb_close(img, view["rgb"], "seam driver, room_view_back")
+    assert np.array_equal(img, view["rgb"])

@@ -156,6 +156,88 @@ def test_programmatic_materials_arrive_as_given():
     assert np.array_equal(od, d)
 
 
+def _facade_tree_dump(m):
+    """The facade's octree in the format of ref_driver's `tree` directive."""
+    t = m.tree()
+    _, line, _ = m.triangles()
+    out = [np.array([len(t["first_child"])], dtype="<i4").tobytes()]
+    for i in range(len(t["first_child"])):
+        out.append(t["aabb"][i].astype("<f8").tobytes())
+        out.append(t["center"][i].astype("<f8").tobytes())
+        b, n = int(t["prim_begin"][i]), int(t["prim_count"][i])
+        out.append(np.array([1 if t["first_child"][i] != 0 else 0, n], dtype="<i4").tobytes())
+        out.append(line[t["prim_ids"][b:b + n]].astype("<i4").tobytes())
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("scene", ["cornell", "mini", "room"])
+def test_octree_equals_the_reference_node_for_node(scene, scenes):
+    """OctTree::Finalize / Node::AttemptSplit (octtree.cc:16-24,52-135) pinned
+    to the COMPILED REFERENCE: ref_driver dumped its finalized tree breadth-first
+    (per node: box, centre, child flag, ordered debug_line_no list;
+    tests/golden/trees.json + tree_*.npz).  The facade's tree and the oracle's
+    must be that tree, byte for byte."""
+    import hashlib
+    want = json_load("trees.json")[scene]
+    m = M.MythTracer(scenes[scene])
+    raw = _facade_tree_dump(m)
+    assert raw[:4] == np.array([want["n_nodes"]], dtype="<i4").tobytes()
+    assert hashlib.sha256(raw).hexdigest() == want["sha256"]
+    o = orclib.OracleScene(scenes[scene])
+    to, tm = o.tree(), m.tree()
+    for k in ("aabb", "center", "first_child", "prim_begin", "prim_count", "prim_ids"):
+        assert np.array_equal(to[k], tm[k]), k
+    if scene != "room":
+        g = np.load(os.path.join(GOLDEN, "tree_%s.npz" % scene), allow_pickle=False)
+        tt = m.tree()
+        _, line, _ = m.triangles()
+        assert np.array_equal(g["aabb"], tt["aabb"]) and np.array_equal(g["center"], tt["center"])
+        assert np.array_equal(g["has_children"], (tt["first_child"] != 0).astype(np.int32))
+        assert np.array_equal(g["n_prims"], tt["prim_count"])
+        assert np.array_equal(g["lines"], line[tt["prim_ids"]])
+
+
+def json_load(name):
+    import json
+    return json.load(open(os.path.join(GOLDEN, name)))
+
+
+def test_wire_bytes_equal_the_reference():
+    """WorkChunk::SerializeInput/Output, DeserializeInput's verdicts and
+    Camera::Serialize (mythtracer.cc:314-429, camera.cc:71-96) against the bytes
+    the compiled reference produced (tests/golden/wire.npz, ref_driver `wire`)."""
+    g = np.load(os.path.join(GOLDEN, "wire.npz"), allow_pickle=False)
+    L = M.host_lib()
+    f6 = np.concatenate([g["image"], g["chunk"]]).astype(np.int32)
+    buf = np.zeros(24, dtype=np.uint8)
+    assert L.mth_chunk_serialize_input(f6.ctypes.data, buf.ctypes.data) == 24
+    assert np.array_equal(buf, g["input_bytes"])
+    cam = np.ascontiguousarray(g["cam"], dtype=np.float64)
+    cbuf = np.zeros(56, dtype=np.uint8)
+    back = np.zeros(7)
+    assert L.mth_camera_roundtrip(cam.ctypes.data, cbuf.ctypes.data, back.ctypes.data) == 56
+    assert np.array_equal(cbuf, g["camera_bytes"]) and np.array_equal(back, cam)
+    got = np.zeros(6, dtype=np.int32)
+    for cand, verdict in zip(g["candidates"], g["verdicts"]):
+        raw = np.ascontiguousarray(cand.astype("<u4")).view(np.uint8)
+        assert L.mth_chunk_deserialize_input(raw.ctypes.data, 24, got.ctypes.data) == int(verdict), list(cand)
+    # output packet: the reference rendered this chunk; its bytes = length + the pixels
+    ob = g["output_bytes"]
+    cw, ch = int(g["chunk"][2]), int(g["chunk"][3])
+    rgb = np.ascontiguousarray(ob[4:])
+    packet = np.zeros(ob.size, dtype=np.uint8)
+    out = np.zeros(rgb.size, dtype=np.uint8)
+    n = L.mth_chunk_output_roundtrip(cw, ch, rgb.ctypes.data, rgb.size, packet.ctypes.data, packet.size,
+                                     out.ctypes.data)
+    assert n == ob.size and np.array_equal(packet, ob) and np.array_equal(out, rgb)
+    assert L.mth_chunk_deserialize_output(cw, ch, np.ascontiguousarray(ob).ctypes.data, ob.size) == 1
+    # ... and the oracle renders the same pixels for that chunk
+    o = orclib.OracleScene(os.path.join(ROOT, "tests", "scenes", "cornell_n.obj"))
+    o.set_lights(g["lights"])
+    r = o.render(g["cam"], int(g["image"][0]), int(g["image"][1]), chunk=tuple(int(v) for v in g["chunk"]))
+    assert np.array_equal(r["rgb"].reshape(-1), rgb)
+
+
 def test_root_box_always_contains_the_origin():
     """OctTree's root box starts as {0,0,0}-{0,0,0} and only grows (octtree.cc:8-14)."""
     m = M.MythTracer()
@@ -260,6 +342,24 @@ def test_texture_loaders(tmp_path):
         assert tex.dtype == np.uint8 and np.array_equal(tex, rgb), f.name
     (tmp_path / "m.mtl").write_text("newmtl a\nmap_Ka missing.ppm\n")
     assert not M.MythTracer().load_obj(str(tmp_path / "m.obj"))
+    # damaged / unsupported BMPs are refused, not mis-read
+    def bmp32(h=2, compression=0, masks=None, data_off=None, hdr_size=40):
+        pix = bytes(range(3 * 2 * 4))
+        extra = b"".join(m.to_bytes(4, "little") for m in masks) if masks else b""
+        off = 54 + len(extra) if data_off is None else data_off
+        return (b"BM" + (off + len(pix)).to_bytes(4, "little") + b"\0\0\0\0" + off.to_bytes(4, "little") +
+                hdr_size.to_bytes(4, "little") + (3).to_bytes(4, "little") + (h & 0xffffffff).to_bytes(4, "little") +
+                (1).to_bytes(2, "little") + (32).to_bytes(2, "little") + compression.to_bytes(4, "little") +
+                b"\0" * 20 + extra + pix)
+    cases = {"ok32.bmp": (bmp32(), True),
+             "bitfields_bgra.bmp": (bmp32(compression=3, masks=(0x00ff0000, 0x0000ff00, 0x000000ff)), True),
+             "bitfields_rgb565ish.bmp": (bmp32(compression=3, masks=(0x000000ff, 0x0000ff00, 0x00ff0000)), False),
+             "height_int_min.bmp": (bmp32(h=-2 ** 31), False),
+             "pixels_inside_header.bmp": (bmp32(data_off=40), False)}
+    for name, (blob, ok) in cases.items():
+        (tmp_path / name).write_bytes(blob)
+        (tmp_path / "m.mtl").write_text("newmtl a\nKa 1 1 1\nmap_Ka %s\n" % name)
+        assert M.MythTracer().load_obj(str(tmp_path / "m.obj")) == ok, name
 
 
 def test_wire_formats():
