@@ -1,30 +1,30 @@
 #!/usr/bin/env python3
-"""bench.py — the hot path on BASELINE.json's headline configuration.
+"""bench.py — the hot path on BASELINE.json's headline configurations.
 
 One "step" = one frame through MythTracer::RayTrace's pixel loop on the GPU
-(mt_render_chunk_device / mt_render_tiles_device of the C ABI): default
-workload = configs[2] of BASELINE.json: the ~100k-triangle room (synthetic
-stand-in for the unavailable living-room model, mythtracer_amd/scenegen.py),
-1920x1080, 3 lights with shadow rays, the reference's MAX_RECURSION_LEVEL = 5.
-Scene, lights and sensor are resident in HBM before the timed region; the
-frame stays in HBM (the PCIe-inclusive rate is in DESIGN.md).
+(mt_render_chunk_device / mt_render_tiles_device of the C ABI).  Scene, lights
+and sensor are resident in HBM before the timed region; the frame stays in HBM
+(the PCIe-inclusive rate is in DESIGN.md).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, every rank holds a scene replica (as every worker
-does in the reference, main_net_worker.cc:29-32), renders the 64x64 tiles
-k = rank (mod N) of ONE frame, and the tile buffers are gathered to rank 0 over
-RCCL and blitted into the frame (main_net_master.cc:223-236) — the reference's
-only exchange step.  Pixels are independent units, so the default is WEAK
-scaling: the frame grows with N at the same camera and aspect (16k x 9k pixels,
-k = round(120 sqrt(N)): 1920x1080, 2720x1530, 3840x2160 = BASELINE configs[4],
-5440x3060), i.e. every GPU keeps about one 1080p frame's worth of pixels.
---scaling strong keeps the 1920x1080 frame for every N instead; that variant is
-bounded by the longest per-pixel ray chain (about 8 ms of the 9.7 ms frame, see
-DESIGN.md section 6), not by the GPUs.
+Workloads (the ~100k-triangle room of mythtracer_amd/scenegen.py stands in for
+the unavailable living-room model; 3 lights with shadow rays, the reference's
+MAX_RECURSION_LEVEL = 5):
 
-Rank 0 prints ONE JSON line.
+  N = 1   BASELINE configs[2]: 1920x1080, one launch for the whole frame.
+  N > 1   BASELINE configs[4]: 3840x2160, STRONG scaling: every rank holds a
+          scene replica (as every worker does in the reference,
+          main_net_worker.cc:29-32), renders the 64x64 tiles k = rank (mod N) of
+          the ONE frame, and the tile buffers are gathered to rank 0 over RCCL
+          and blitted into the frame (main_net_master.cc:223-236) -- the
+          reference's only exchange step.  `--scaling weak` grows the frame with
+          N instead (16k x 9k pixels, k = round(120 sqrt(N))).
+  --width/--height/--max-depth/--scene select the other BASELINE configurations.
+
+Rank 0 prints ONE JSON line; the process exits non-zero if the frame does not
+match the golden frame of the reference.
 """
 from __future__ import annotations
 
@@ -32,6 +32,7 @@ import argparse
 import ctypes
 import hashlib
 import json
+import math
 import os
 import sys
 import tempfile
@@ -41,24 +42,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+RAY_KEYS = ("rays_primary", "rays_secondary", "rays_shadow")
 
 
-def algorithmic_bytes(c: dict, pixels: int) -> int:
-    """bytes the reference's algorithm touches per frame —
+def reference_bytes(c: dict, pixels: int) -> int:
+    """bytes the REFERENCE's un-pruned algorithm touches per frame —
     48 B per node/child box test, 48 B per triangle pre-filter test, 72 B per
     Möller–Trumbore test, vertices+normals+material per shaded hit, 3 B/pixel."""
     return (48 * c["box_tests"] + 48 * c["tri_tests"] + 72 * c["mt_tests"] +
             (72 + 72 + 136) * c["shaded_hits"] + 3 * pixels)
 
 
-def cpu_baseline(scene_obj, cam, lights, W, H, chunk, rays_in_chunk, max_depth):
-    """Times the reference itself (oracle/_ref, built from /root/reference in
-    the build container) on a bounded sample; falls back to our CPU port."""
+def cpu_baseline(scene_obj, cam, lights, W, H, chunk, max_depth, rays_in_chunk):
+    """Times the reference itself (oracle/_ref, compiled from /root/reference in
+    the build container) on the host cores; falls back to our CPU port when the
+    prebuilt reference is absent or the depth is not the reference's compile-time 5."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import orclib
     cores = os.cpu_count() or 1
-    sample = "chunk x=%d y=%d %dx%d of the %dx%d frame, all host threads" % (*chunk, W, H)
-    if orclib.have_ref() and max_depth == 5:  # the reference's depth is a compile-time 5
+    whole = chunk[2] == W and chunk[3] == H
+    sample = ("the whole %dx%d frame" % (W, H) if whole else
+              "chunk x=%d y=%d %dx%d of the %dx%d frame" % (*chunk, W, H)) + ", all host threads (OpenMP rows)"
+    if orclib.have_ref() and max_depth == 5:
         with tempfile.TemporaryDirectory() as td:
             r = orclib.run_ref(td, scene_obj, (W, H), chunk=chunk, cam=cam, lights=lights)
         if r.get("returncode") == 0:
@@ -69,7 +74,7 @@ def cpu_baseline(scene_obj, cam, lights, W, H, chunk, rays_in_chunk, max_depth):
     o = orclib.OracleScene(scene_obj)
     o.set_lights(lights)
     r = o.render(cam, W, H, chunk=chunk, max_level=max_depth)
-    rays = sum(r["counters"][k] for k in ("rays_primary", "rays_secondary", "rays_shadow"))
+    rays = sum(r["counters"][k] for k in RAY_KEYS)
     return {"value": rays / r["seconds"] / 1e6, "unit": "Mray/s", "cores": cores,
             "kind": "port", "sample": sample, "seconds": r["seconds"]}
 
@@ -77,15 +82,20 @@ def cpu_baseline(scene_obj, cam, lights, W, H, chunk, rays_in_chunk, max_depth):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--width", type=int, default=0, help="default: 1920, or scaled with --gpus (weak scaling)")
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--width", type=int, default=0, help="default: 1920 at N = 1, 3840 at N > 1")
     ap.add_argument("--height", type=int, default=0)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--scene", default="room")
     ap.add_argument("--tile", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", choices=("full", "band"), default="full",
+                    help="reference timed on the whole frame (about 30 s) or on a quarter-frame band")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras (cold frame, moving camera, reference-work counts)")
+    ap.add_argument("--moving-frames", type=int, default=12)
     args = ap.parse_args()
 
     import numpy as np
@@ -115,7 +125,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1:  # before anything else touches the device
         if emulate:
             dist.init_process_group("gloo")
         else:
@@ -124,11 +134,17 @@ def main():
 
     if args.width > 0 and args.height > 0:
         W, H = args.width, args.height
+        scaling = "strong"
+    elif world == 1:
+        W, H = 1920, 1080
+        scaling = "strong"
     elif args.scaling == "weak":
         k = int(round(120.0 * (world ** 0.5)))
-        W, H = 16 * k, 9 * k          # N=1: 1920x1080, N=4: 3840x2160
+        W, H = 16 * k, 9 * k          # N=4: 3840x2160
+        scaling = "weak"
     else:
-        W, H = 1920, 1080
+        W, H = 3840, 2160             # BASELINE configs[4]
+        scaling = "strong"
     scene_dir = os.path.join(tempfile.gettempdir(), "mt_bench_scene_%d_%d" % (os.getuid(), rank))
     info = scenegen.write_scene(args.scene, scene_dir)
     cam, lights = scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS
@@ -145,14 +161,15 @@ def main():
 
     tw = th = args.tile
     first, stride, n_mine = tiling.rank_tiles(W, H, tw, th, rank, world)
-    n_max = tiling.max_tiles_per_rank(W, H, tw, th, world)
+    n_max = tiling.max_tiles_per_rank(W, H, tw, th, world)   # equal slot counts on every rank
     frame = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
     if world > 1:
         mine = torch.zeros(n_max * tiling.slot_bytes(tw, th), dtype=torch.uint8, device=dev)
         gathered = ([torch.zeros_like(mine, device=xdev) for _ in range(world)] if rank == 0 else None)
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for _ in range(args.steps)]
+    def E():
+        return torch.cuda.Event(enable_timing=True)
+    ev = [(E(), E(), E()) for _ in range(args.steps)]  # before render, after render, after gather + blit
 
     def step(i=None):
         if i is not None:
@@ -173,6 +190,8 @@ def main():
                 if emulate:
                     torch.cuda.synchronize()  # `slots` is a temporary here
             multi.gather_and_blit(dist, mine.to(xdev), gathered, rank, world, W, H, tw, th, blit)
+        if i is not None:
+            ev[i][2].record()
 
     def fence():
         torch.cuda.synchronize()
@@ -192,17 +211,20 @@ def main():
     elapsed = time.perf_counter() - t0
     counters = abi.read_stats(h)   # this rank, all timed steps
     # per-kernel device durations of the timed steps: HIP events the library
-    # records on the launch stream around each of its two kernels
-    k_primary, k_render = abi.kernel_times(h, 64)
+    # records on the launch stream around each of its kernels (at most the last 64)
+    k_order, k_frame = abi.kernel_times(h, 64)
 
     keys = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests", "node_visits",
-            "tri_tests", "mt_tests", "shaded_hits", "wave_node_steps", "wave_tri_steps"]
+            "tri_tests", "mt_tests", "shaded_hits", "wave_node_steps", "wave_tri_steps",
+            "bytes_scalar", "bytes_vector"]
     vec = torch.tensor([float(counters[k]) for k in keys], dtype=torch.float64, device=xdev)
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
-    kmax = torch.tensor([float(k_render.mean()) if len(k_render) else 0.0,
-                         float(k_primary.mean()) if len(k_primary) else 0.0,
-                         sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=xdev)
+    render_ms = [a.elapsed_time(b) for a, b, _ in ev]
+    exchange_ms = [b.elapsed_time(c) for _, b, c in ev]
+    kmax = torch.tensor([float(k_frame.mean()) if len(k_frame) else 0.0,
+                         float(k_order.mean()) if len(k_order) else 0.0,
+                         sum(render_ms) / max(len(render_ms), 1),
+                         sum(exchange_ms) / max(len(exchange_ms), 1)], dtype=torch.float64, device=xdev)
     if world > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -211,127 +233,176 @@ def main():
     tot = {k: int(v) for k, v in zip(keys, vec.tolist())}
     per_frame = {k: v // max(args.steps, 1) for k, v in tot.items()}
     rays = tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"]
+    mismatch = False
 
     if rank == 0:
         img = frame.cpu().numpy()
         sha = hashlib.sha256(img.tobytes()).hexdigest()
         sha_cmp, parity_ok = sha, "frame identical to the reference's"
-        golden = None
+        golden, golden_from = None, None
         gpath = os.path.join(ROOT, "tests", "golden", "frames.json")
         if os.path.exists(gpath):
+            frames = json.load(open(gpath))
             key = "%s_%dx%d_d%d" % (args.scene, W, H, args.max_depth)
-            golden = json.load(open(gpath)).get(key, {}).get("sha256")
+            golden = frames.get(key, {}).get("sha256")
+            golden_from = frames.get(key, {}).get("made_by", "the compiled reference")
             if golden is None and (W, H) == (3840, 2160):
                 # Sensor::GetRay divides the same corner vectors by W and H: the ray of
                 # 4K pixel (2x, 2y) is bit-for-bit that of 1080p pixel (x, y), so the even
                 # pixels of this frame must be the reference's 1080p frame
-                golden = json.load(open(gpath)).get("%s_1920x1080_d%d" % (args.scene, args.max_depth), {}).get("sha256")
+                k2 = "%s_1920x1080_d%d" % (args.scene, args.max_depth)
+                golden = frames.get(k2, {}).get("sha256")
+                golden_from = frames.get(k2, {}).get("made_by", "the compiled reference")
                 sha_cmp = hashlib.sha256(np.ascontiguousarray(img[::2, ::2]).tobytes()).hexdigest()
-                parity_ok = "even pixels identical to the reference's 1920x1080 frame"
-        # A step is two launches: mt::primary_kernel (primary rays, block cost
-        # classes) and mt::render_kernel (shading, shadow + secondary rays) —
-        # the dominant one.  Per-launch figures of THIS rank at N=1; at N>1 the
-        # slowest rank's durations.
-        k_ms, k_primary_ms, k_step_ms = (float(x) for x in kmax.tolist())
-        my = counters if world == 1 else None
+                parity_ok = "even pixels identical to the 1920x1080 golden frame"
+            if golden is not None and golden_from != "the compiled reference":
+                parity_ok += " (golden made by: %s)" % golden_from
+        mismatch = golden is not None and golden != sha_cmp
+        k_ms, k_order_ms, k_step_ms, k_exchange_ms = (float(x) for x in kmax.tolist())
+
+        # ---- roofline of the dominant kernel (the frame kernel).  Numerator: the
+        # bytes the kernel REQUESTS per launch, counted by the kernel itself at its
+        # load/store sites (mt_stats.bytes_scalar + bytes_vector; DESIGN.md section 5
+        # lists them) -- the work this kernel does, not the reference's.
+        req = per_frame["bytes_scalar"] + per_frame["bytes_vector"]
+        if world > 1:
+            req = None  # summed over ranks: not a per-launch figure
         roof = None
         if world == 1:
-            pf = {k: my[k] // max(args.steps, 1) for k in keys}
-            # Algorithmic work = the reference's un-pruned traversal:
-            # counted by untimed frames in traversal mode 7, which visits every
-            # subtree the reference visits (the timed frames skip those a ray
-            # provably cannot hit; the image is the same).  A second one with no
-            # lights and recursion 0 traces the primary rays only and gives
-            # primary_kernel's share.
-            scratch = torch.zeros_like(frame)
-            evaluated = {k: pf[k] for k in ("box_tests", "node_visits", "tri_tests", "mt_tests")}
-            abi.set_traversal_mode(h, 7)
-            abi.render_chunk_device(h, sens, W, H, (0, 0, W, H), args.max_depth,
-                                    ctypes.c_void_p(scratch.data_ptr()), None, stream)
-            torch.cuda.synchronize()
-            full = abi.read_stats(h)
-            reference_evaluates = {k: full[k] for k in ("box_tests", "node_visits", "tri_tests", "mt_tests")}
-            abi.set_lights(h, [])
-            abi.render_chunk_device(h, sens, W, H, (0, 0, W, H), 0,
-                                    ctypes.c_void_p(scratch.data_ptr()), None, stream)
-            torch.cuda.synchronize()
-            prim = abi.read_stats(h)
-            abi.kernel_times(h)
-            abi.set_lights(h, lights)
-            abi.set_traversal_mode(h, 0)
-            pf = {k: full[k] for k in keys}
-            # With cost history (every timed step of a default run) render_kernel
-            # traces the primary rays too and the first kernel of the step is the
-            # 50-us schedule_kernel; without it they belong to primary_kernel.
-            primary_inside = k_primary_ms * 20.0 < k_ms
-            if not primary_inside:
-                for k in ("box_tests", "tri_tests", "mt_tests"):
-                    pf[k] -= prim[k]
-            alg = algorithmic_bytes(pf, W * H)
-            alg_primary = 48 * prim["box_tests"] + 48 * prim["tri_tests"] + 72 * prim["mt_tests"] + 12 * W * H
-            traffic = None
+            ach = req / (k_ms * 1e-3) / 1e9
+            wl_key = "%s_%dx%d_d%d" % (args.scene, W, H, args.max_depth)
+            traffic, pmc = None, None
             tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tpath):
-                traffic = json.load(open(tpath)).get("%s_%dx%d_d%d" % (args.scene, W, H, args.max_depth))
-            ach = alg / (k_ms * 1e-3) / 1e9
+                t = json.load(open(tpath)).get(wl_key)
+                if isinstance(t, dict):
+                    traffic, pmc = t.get("hbm_bytes_per_launch"), t
+                else:
+                    traffic = t
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                    "kernel": "mt::render_kernel", "kernel_ms": k_ms,
-                    "algorithmic_bytes_per_launch": alg,
-                    "launches_averaged": int(len(k_render)),
-                    "primary_rays_traced_by_this_kernel": bool(primary_inside),
-                    "other_kernels": {"mt::schedule_kernel (mt::primary_kernel in a launch without cost history)": {
-                        "kernel_ms": k_primary_ms},
-                        "primary_rays_algorithmic_bytes": alg_primary},
+                    "kernel": "mt::render_kernel (throughput engine) / mt::pool_kernel (latency engine)",
+                    "kernel_ms": k_ms, "launches_averaged": int(len(k_frame)),
+                    "requested_bytes_per_launch": {"scalar_wave_uniform": per_frame["bytes_scalar"],
+                                                   "vector_per_lane": per_frame["bytes_vector"]},
+                    "other_kernels_ms": {"work order (schedule / probe / primary)": k_order_ms},
                     "step_ms_device": k_step_ms,
-                    "note": "algorithmic bytes = SURVEY 8(d) bytes of the reference's un-pruned "
-                            "traversal (counted by an untimed frame in traversal mode 7); the kernel "
-                            "serves one box to 64 rays with a scalar load and rules out most blocks and "
-                            "subtrees by 24-byte union boxes, so it is latency/VALU bound, not HBM bound "
-                            "(DESIGN.md section 5); traffic = memory-side bytes per launch from the "
-                            "rocprofv3 PMC passes under profiles/",
-                    # both normalisations -- the bytes of the nodes this kernel
-                    # actually visits (subtrees it can rule out are not counted) ...
-                    "achieved_own_counters": (48 * evaluated["box_tests"] + 48 * evaluated["tri_tests"]
-                                              + 72 * evaluated["mt_tests"]) / (k_step_ms * 1e-3) / 1e9,
-                    "frame_work_visited_by_the_kernels": evaluated,
-                    "frame_work_of_the_reference": reference_evaluates}
+                    "note": "achieved = bytes requested by the frame kernel per launch (its own counters) / its "
+                            "average duration; most are served by the scalar cache, L1 and L2 (working set 33 MB), "
+                            "so the HBM fraction is low by construction: the kernel is bound by VALU issue and "
+                            "dependent-load latency, see binding_resource and DESIGN.md section 5"}
+            if pmc:
+                roof["binding_resource"] = {k: pmc[k] for k in pmc if k != "hbm_bytes_per_launch"}
+
         out = {
             "metric": "Mray/s (primary+shadow+secondary; ray = one OctTree::IntersectRay)",
             "value": rays / elapsed / 1e6, "unit": "Mray/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
             "higher_is_better": True,
-            "scaling": args.scaling if not (args.width > 0 and args.height > 0) else "strong",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s scene (%d triangles, synthetic stand-in for the living-room "
-                                   ".obj), %dx%d, %d lights with shadow rays, max recursion %d"
-                                   % (args.scene, info["triangles"], W, H, len(lights), args.max_depth),
-                       "tile": "%dx%d interleaved over %d rank(s)" % (tw, th, world) if world > 1
-                               else "whole frame per launch, 8x8-pixel work items",
+                                   ".obj), %dx%d, %d lights with shadow rays, max recursion %d%s"
+                                   % (args.scene, info["triangles"], W, H, len(lights), args.max_depth,
+                                      " = BASELINE configs[2]" if (W, H, args.max_depth, world) == (1920, 1080, 5, 1)
+                                      else (" = BASELINE configs[4]" if (W, H, args.max_depth) == (3840, 2160, 5) and world > 1
+                                            else "")),
+                       "tile": "%dx%d tiles interleaved over %d ranks, gathered to rank 0 (RCCL) and blitted" % (tw, th, world)
+                               if world > 1 else "whole frame per launch, 8x8-pixel work items",
+                       "regime": "warm: every timed step re-renders the same frame and is scheduled from the block "
+                                 "costs measured in the previous step (cold_frame_ms / moving_camera below give "
+                                 "the other regimes)",
                        "scene_sha256": info["sha256"]},
             "frame_ms_wall": elapsed / max(args.steps, 1) * 1e3,
-            "rays_per_frame": {k: per_frame[k] for k in ("rays_primary", "rays_secondary", "rays_shadow")},
+            "render_ms_device": k_step_ms,
+            "rays_per_frame": {k: per_frame[k] for k in RAY_KEYS},
             "Mray_s_primary_plus_shadow": (tot["rays_primary"] + tot["rays_shadow"]) / elapsed / 1e6,
             "frame_sha256": sha,
-            "parity": (None if golden is None else (parity_ok if golden == sha_cmp else "MISMATCH vs reference")),
+            "parity": (None if golden is None else ("MISMATCH vs golden frame" if mismatch else parity_ok)),
             "scene_load_s": t_load,
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            chunk = (0, (H * 3) // 8, W, max(H // 4, 1))  # middle band, a quarter of the frame
+        if world > 1:
+            out["exchange_ms_device"] = {"gather_plus_blit_rank0": k_exchange_ms,
+                                         "bytes_gathered": int(n_max * tiling.slot_bytes(tw, th) * world)}
+
+    # ---- untimed extras, one GPU only
+    if world == 1 and rank == 0 and not args.no_extras:
+        extras = {}
+        scratch = torch.zeros_like(frame)
+        sp = ctypes.c_void_p(scratch.data_ptr())
+
+        def timed_frame(sensor12):
+            abi.render_chunk_device(h, sensor12, W, H, (0, 0, W, H), args.max_depth, sp, None, stream)
+            torch.cuda.synchronize()
+            a, b = abi.kernel_times(h)
+            return float(a[-1] + b[-1])
+
+        # (1) cold frame: no cost history (first frame of a geometry)
+        abi.set_scheduling(h, True)  # forgets the recorded costs
+        extras["cold_frame_ms"] = timed_frame(sens)
+        # (2) moving camera: the reference's loop turns the camera 2 degrees per frame
+        # (main_local.cc:51-76); every frame is scheduled from the PREVIOUS frame's costs.
+        # Each frame is checked on a crop against the oracle.
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import orclib
+        orc = orclib.OracleScene(info["obj"])
+        orc.set_lights(lights)
+        mv, crops_ok = [], True
+        for f in range(args.moving_frames):
+            cam_f = list(cam)
+            cam_f[4] = cam[4] + 2.0 * (f + 1)  # yaw
+            s_f = host_sensor(cam_f, W, H)
+            mv.append(timed_frame(s_f))
+            cw, ch = 96, 48
+            cx, cy = (211 * f) % (W - cw), (H // 3 + 37 * f) % (H - ch)
+            want = orc.render(cam_f, W, H, chunk=(cx, cy, cw, ch), max_level=args.max_depth)["rgb"]
+            got = scratch[cy:cy + ch, cx:cx + cw].cpu().numpy()
+            crops_ok = crops_ok and bool(np.array_equal(got, want))
+        extras["moving_camera"] = {"frames": args.moving_frames, "yaw_step_deg": 2.0,
+                                   "ms_mean": sum(mv) / len(mv), "ms_max": max(mv), "ms_min": min(mv),
+                                   "every_frame_crop_equals_oracle": crops_ok}
+        mismatch = mismatch or not crops_ok
+        # (3) the work of the REFERENCE's un-pruned traversal on this frame (traversal
+        # mode 7 visits every subtree the reference visits; the image is the same)
+        abi.read_stats(h)  # drop the counts of the frames above
+        abi.set_traversal_mode(h, 7)
+        abi.render_chunk_device(h, sens, W, H, (0, 0, W, H), args.max_depth, sp, None, stream)
+        torch.cuda.synchronize()
+        full = abi.read_stats(h)
+        abi.set_traversal_mode(h, 0)
+        abi.kernel_times(h)
+        ref_b = reference_bytes(full, W * H)
+        extras["reference_equivalent"] = {
+            "bytes_per_frame": ref_b, "GBps_at_this_frame_time": ref_b / (out["roofline"]["kernel_ms"] * 1e-3) / 1e9,
+            "work_of_the_reference": {k: full[k] for k in ("box_tests", "node_visits", "tri_tests", "mt_tests")},
+            "work_visited_by_this_kernel": {k: per_frame[k] for k in ("box_tests", "node_visits", "tri_tests", "mt_tests")},
+            "note": "SURVEY 8(d) bytes of the reference's traversal (no block / subtree boxes, one box per ray); "
+                    "NOT this kernel's traffic -- shown for comparison only"}
+        out["extras"] = extras
+        if not args.no_cpu_baseline:
+            chunk = (0, 0, W, H) if args.cpu_sample == "full" else (0, (H * 3) // 8, W, max(H // 4, 1))
             g = abi.render_chunk(h, sens, W, H, chunk=chunk, max_depth=args.max_depth)
-            rc = sum(g["stats"][k] for k in ("rays_primary", "rays_secondary", "rays_shadow"))
+            rc = sum(g["stats"][k] for k in RAY_KEYS)
             try:
-                out["cpu_baseline"] = cpu_baseline(info["obj"], cam, lights, W, H, chunk, rc, args.max_depth)
+                out["cpu_baseline"] = cpu_baseline(info["obj"], cam, lights, W, H, chunk, args.max_depth, rc)
                 out["cpu_baseline"]["gpu_same_sample_Mray_s"] = rc / (g["stats"]["kernel_ms"] * 1e-3) / 1e6
             except Exception as e:  # the bench line must still come out
                 out["cpu_baseline"] = {"error": repr(e)}
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        flag = torch.tensor([1.0 if mismatch else 0.0], dtype=torch.float64, device=xdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        mismatch = bool(flag.item() > 0)
         dist.barrier()
         dist.destroy_process_group()
+    if mismatch:
+        if rank == 0:
+            print("bench.py: PARITY MISMATCH (see the \"parity\" / \"extras\" fields)", file=sys.stderr)
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MT_ABI_VERSION 1
+#define MT_ABI_VERSION 2
 
 enum {
   MT_OK = 0,
@@ -100,6 +100,13 @@ typedef struct mt_stats {
   uint64_t wave_tri_steps; /* wave-level triangle slab evaluations (GPU only) */
   double kernel_ms;        /* device time of the kernel(s), HIP events */
   double total_ms;         /* wall time of the call incl. copies */
+  /* Bytes the kernels REQUESTED (counted at the load/store instructions of the
+   * path, whatever cache served them): by wave-uniform scalar loads -- one box
+   * or node record fetched once for all rays of a wave -- and by per-lane
+   * vector accesses (boxes, vertices, node records, shading inputs, per-ray
+   * state), summed over lanes.  bench.py's roofline numerator. */
+  uint64_t bytes_scalar;
+  uint64_t bytes_vector;
 } mt_stats;
 
 /* Flattened scene: what Scene{tree, materials, textures} (scene.h:9-15) holds

@@ -11,7 +11,7 @@ HIP_LIB = os.path.join(PKG, "lib", "libmythtracer_hip.so")
 HOST_LIB = os.path.join(PKG, "lib", "libmythtracer_host.so")
 
 MT_OK = 0
-MT_ABI_VERSION = 1
+MT_ABI_VERSION = 2
 MT_TEX_RGB8, MT_TEX_F64 = 0, 1
 
 # every symbol include/mythtracer_hip.h declares
@@ -58,7 +58,8 @@ class mt_sensor(C.Structure):
 class mt_stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in STAT_NAMES] + [
         ("wave_node_steps", C.c_uint64), ("wave_tri_steps", C.c_uint64),
-        ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+        ("kernel_ms", C.c_double), ("total_ms", C.c_double),
+        ("bytes_scalar", C.c_uint64), ("bytes_vector", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -66,6 +66,9 @@ struct mt_scene {
   // cost feedback (schedule_kernel): valid for launches of the same geometry
   unsigned int *d_item_cost = nullptr;   // [n_items]
   size_t item_cost_bytes = 0;
+  unsigned int *d_item_forecast = nullptr;  // [n_items]
+  size_t item_forecast_bytes = 0;
+  mt_sensor cost_sensor{};               // camera of the launch that measured the costs
   unsigned int *d_order_item = nullptr;  // [4 n_items]
   size_t order_item_bytes = 0;
   signed char *d_order_sub = nullptr;    // [4 n_items]
@@ -202,11 +205,13 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   const bool pool_engine = engine == 2;
   {
     int rc = ensure_bytes((void **)&s->d_item_cost, &s->item_cost_bytes, (size_t)P.n_items * 4);
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_item_forecast, &s->item_forecast_bytes, (size_t)P.n_items * 4);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_item, &s->order_item_bytes, (size_t)P.n_items * 64);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_sub, &s->order_sub_bytes, (size_t)P.n_items * 16);
     if (rc != MT_OK) return rc;
   }
   P.item_cost = s->d_item_cost;
+  P.item_forecast = s->d_item_forecast;
   P.order_item = s->d_order_item;
   P.order_sub = s->d_order_sub;
   P.n_work = s->d_work + 7;
@@ -283,6 +288,14 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (!ek[i]) HIP_TRY(hipEventCreate(&ek[i]));
   }
   HIP_TRY(hipEventRecord(ek[0], stream));
+  // Has the camera moved since the costs were measured?  Then forecast_kernel
+  // re-projects them (radius 1 block; 2 when the origin moved too: parallax).
+  int reproject = 0, radius = 0;
+  if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {
+    reproject = 1;
+    radius = memcmp(s->cost_sensor.origin, sensor->origin, sizeof sensor->origin) != 0 ? 2 : 1;
+    if (const char *e = getenv("MT_DEBUG_FORECAST_RADIUS")) radius = atoi(e);
+  }
   if (pool_engine) {
     if (!history) {
       hipLaunchKernelGGL(probe_kernel, dim3((P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream,
@@ -295,6 +308,8 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (const char *e = getenv("MT_DEBUG_PIECE_TIME")) sscanf(e, "%f,%f", &sp.piece_time[1], &sp.piece_time[2]);
     if (const char *e = getenv("MT_DEBUG_PIECE_WORK")) sscanf(e, "%f,%f", &sp.piece_work[1], &sp.piece_work[2]);
     if (const char *e = getenv("MT_DEBUG_CELL_FACTOR")) sp.cell_factor = (float)atof(e);
+    hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
+                       reproject, radius, 1, sp.piece_work[1], sp.piece_work[2], 16000u);
     hipLaunchKernelGGL(pool_schedule_kernel, dim3(1), dim3(kPoolSchedThreads), 0, stream, P,
                        s->grid_blocks * s->waves_per_block, sp);
     HIP_TRY(hipGetLastError());
@@ -308,6 +323,8 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (history) {
       float quad_share = 0.8f;  // blocks above this share of an even split are cut into quarters
       if (const char *e = getenv("MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
+      hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
+                         reproject, radius, 0, 1.7f, 1.0f, 16000u);
       hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
                          s->grid_blocks * s->waves_per_block, quad_share);
     } else if (s->stats_enabled) {
@@ -328,6 +345,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   s->launches_timed++;
   s->cost_signature = sig;  // the costs now in d_item_cost belong to this geometry and engine
   s->last_engine = engine;
+  s->cost_sensor = *sensor;
   if (d_item) {  // debug: dump per-item durations (synchronises!)
     std::vector<unsigned long long> host((size_t)P.n_items * 16 * 2 * 3);
     HIP_TRY(hipMemcpy(host.data(), d_item, host.size() * 8, hipMemcpyDeviceToHost));
@@ -381,6 +399,8 @@ void fill_stats(const unsigned long long *c, mt_stats *st) {
   st->shaded_hits = c[ST_SHADED_HITS];
   st->wave_node_steps = c[ST_WAVE_NODE_STEPS];
   st->wave_tri_steps = c[ST_WAVE_TRI_STEPS];
+  st->bytes_scalar = c[ST_BYTES_SCALAR];
+  st->bytes_vector = c[ST_BYTES_VECTOR];
 }
 
 int check_image_args(const mt_scene *s, const mt_sensor *sensor, int image_w, int image_h) {
@@ -416,6 +436,7 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_hit_t) (void)hipFree(s->d_hit_t);
   if (s->d_class_list) (void)hipFree(s->d_class_list);
   if (s->d_item_cost) (void)hipFree(s->d_item_cost);
+  if (s->d_item_forecast) (void)hipFree(s->d_item_forecast);
   if (s->d_order_item) (void)hipFree(s->d_order_item);
   if (s->d_order_sub) (void)hipFree(s->d_order_sub);
   if (s->d_rgb) (void)hipFree(s->d_rgb);

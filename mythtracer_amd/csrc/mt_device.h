@@ -90,8 +90,10 @@ enum {
   ST_TRI_TESTS,
   ST_MT_TESTS,
   ST_SHADED_HITS,
+  ST_BYTES_VECTOR,   // bytes requested by per-lane (vector) loads and stores of the path, summed over lanes
   ST_WAVE_NODE_STEPS,
   ST_WAVE_TRI_STEPS,
+  ST_BYTES_SCALAR,   // bytes requested by wave-uniform (scalar) loads: one box serves all rays of a wave
   ST_STATUS,  // 0 = ok, else a DEV_ERR_* code: a loop bound tripped (never expected)
   ST_COUNT
 };
@@ -135,6 +137,7 @@ struct RenderParams {
   // schedule kernels): s_memtime ticks each block took in the previous frame
   // (or a forecast), and the work order derived from them.
   unsigned int *item_cost;        // [n_items] ticks (>> 6) of the last frame; pieces of a block add up
+  unsigned int *item_forecast;    // [n_items] expected cost of the block as ONE unit in the coming frame
   unsigned int *order_item;       // [<= 16 n_items] block id of work unit w
   signed char *order_sub;         // [<= 16 n_items] -1 = whole block, 0..3 = quarter, 4..19 = 2x2 cell (pool only)
   unsigned int *n_work;           // number of work units in order_item/order_sub
@@ -143,9 +146,9 @@ struct RenderParams {
 
 // Bytes of LDS one wave needs for its traversal stack: 20-byte frames, or 16-byte
 // ones when a node index and a triangle index fit one word together
-// (DevScene::pack_shift != 0), plus four per-lane work counters.
+// (DevScene::pack_shift != 0), plus five per-lane work counters.
 __host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
-  return (size_t)depth * 64 * (packed ? 16 : 20) + 4 * 64 * 4;
+  return (size_t)depth * 64 * (packed ? 16 : 20) + 5 * 64 * 4;
 }
 
 constexpr int kFrameSlots = 11;  // throughput engine: 10 doubles + 1 packed meta word per recursion frame

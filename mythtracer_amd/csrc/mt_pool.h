@@ -128,6 +128,7 @@ __device__ __forceinline__ void pool_flush_item_stats(LaneStats &st, unsigned lo
     if (lane == 0) {
       atomicAdd(counters + ST_WAVE_NODE_STEPS, (unsigned long long)st.wave_node_steps);
       atomicAdd(counters + ST_WAVE_TRI_STEPS, (unsigned long long)st.wave_tri_steps);
+      atomicAdd(counters + ST_BYTES_SCALAR, (unsigned long long)st.bytes_scalar);
     }
     st.clear();
   }
@@ -211,10 +212,10 @@ struct SchedParams {
   float piece_work[3];  // measured cost of all pieces of a block relative to the whole block
   float cell_factor;    // quarters above cell_factor x the threshold are cut again
 };
-__device__ __forceinline__ void sched_decide(unsigned word, float cut_above, const SchedParams &sp, int &level,
-                                             unsigned &unit_cost) {
+__device__ __forceinline__ void sched_decide(unsigned word, unsigned forecast, float cut_above, const SchedParams &sp,
+                                             int &level, unsigned &unit_cost) {
   const int was = (int)(word >> 30);
-  const float c = (float)(word & 0x3fffffffu) / sp.piece_work[was < 3 ? was : 0];  // as a whole block
+  const float c = (float)forecast;  // as a whole block (forecast_kernel)
   const float thr = was > 0 ? 0.7f * cut_above : cut_above;
   // 2x2 cells (level 2) only for blocks whose QUARTERS would each exceed the
   // threshold several times over: a pass costs about the same whether it
@@ -232,11 +233,7 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
   for (int b = tid; b < kPoolSchedBuckets; b += kPoolSchedThreads) s_count[b] = 0u;
   __syncthreads();
   unsigned long long part = 0ull;
-  for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) {
-    const unsigned word = P.item_cost[i];
-    const int was = (int)(word >> 30);
-    part += (unsigned long long)((float)(word & 0x3fffffffu) / sp.piece_work[was < 3 ? was : 0]);
-  }
+  for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) part += P.item_forecast[i];
   atomicAdd(&s_sum, part);
   __syncthreads();
   const float share = (float)s_sum / (float)(n_waves > 0 ? n_waves : 1);
@@ -245,7 +242,7 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
   for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) {
     int level;
     unsigned unit;
-    sched_decide(P.item_cost[i], cut_above, sp, level, unit);
+    sched_decide(P.item_cost[i], P.item_forecast[i], cut_above, sp, level, unit);
     atomicAdd(&s_count[pool_cost_bucket(unit)], level == 0 ? 1u : (level == 1 ? 4u : 16u));
   }
   __syncthreads();
@@ -263,7 +260,7 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
   for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) {
     int level;
     unsigned unit;
-    sched_decide(P.item_cost[i], cut_above, sp, level, unit);
+    sched_decide(P.item_cost[i], P.item_forecast[i], cut_above, sp, level, unit);
     const unsigned n = level == 0 ? 1u : (level == 1 ? 4u : 16u);
     const unsigned at = atomicAdd(&s_start[pool_cost_bucket(unit)], n);
     for (unsigned q = 0; q < n; q++) {
@@ -468,6 +465,7 @@ __global__ __launch_bounds__(256, 3) void pool_kernel(DevScene S, RenderParams P
         if (STATS) {
           if (level > 0) st.v[ST_RAYS_SECONDARY]++;
           else st.v[ST_RAYS_PRIMARY]++;
+          st.v[ST_BYTES_VECTOR] += 4u + 48u + 16u;  // pool entry, ray, meta
         }
         if (level == 0 && P.out_debug != nullptr) {  // mythtracer.cc:23-36
           mt_debug_px *dbg = P.out_debug + *(const unsigned long long *)(R + R_PX);
@@ -485,7 +483,10 @@ __global__ __launch_bounds__(256, 3) void pool_kernel(DevScene S, RenderParams P
         if (prim < 0) {  // mythtracer.cc:23-31
           finish = true;
         } else {
-          if (STATS) st.v[ST_SHADED_HITS]++;
+          if (STATS) {
+            st.v[ST_SHADED_HITS]++;
+            st.v[ST_BYTES_VECTOR] += 72u + 72u + 4u + 64u + 120u;  // vertices, normals, material (index), record fields written
+          }
           const V3 Pt = ro + rd * t;  // primitive_triangle.cc:141
           const V3 dir = rd;
           const double *vtx = S.tri_vertex + (size_t)prim * 9;
@@ -541,7 +542,10 @@ __global__ __launch_bounds__(256, 3) void pool_kernel(DevScene S, RenderParams P
           }
         }
       } else if (is_shadow) {  // ---- one iteration of the shadow loop, mythtracer.cc:94-156
-        if (STATS) st.v[ST_RAYS_SHADOW]++;
+        if (STATS) {
+          st.v[ST_RAYS_SHADOW]++;
+          st.v[ST_BYTES_VECTOR] += 96u + 4u + 32u + 2u * 80u + 80u;  // light, occluder material, record fields read twice, slot written
+        }
         double *R = rec_ptr(rec);
         double *slot = R + R_LIGHTS + li * kLightSlot;
         const mt_light *lt = lights + li;

@@ -116,6 +116,7 @@ __device__ __forceinline__ void flush_item_stats(LaneStats &st, unsigned long lo
     if (lane == 0) {
       atomicAdd(counters + ST_WAVE_NODE_STEPS, (unsigned long long)st.wave_node_steps);
       atomicAdd(counters + ST_WAVE_TRI_STEPS, (unsigned long long)st.wave_tri_steps);
+      atomicAdd(counters + ST_BYTES_SCALAR, (unsigned long long)st.bytes_scalar);
     }
     st.clear();
   }
@@ -217,6 +218,86 @@ __global__ __launch_bounds__(256, 3) void primary_kernel(DevScene S, RenderParam
 // The order changes nothing about what is computed for a pixel.  Costs are in
 // units of 64 s_memtime ticks; a block rendered as quarters reports their sum,
 // which is scaled back (kQuadWork) before it is compared again.
+// Cost forecast from the previous frame's measured block costs.  When the
+// camera has not moved a block's forecast is its own last cost.  When it has
+// (an animation: main_local.cc:51-76 turns it 2 degrees per frame, 25..70
+// pixels depending on where in the picture), what was expensive in block b is
+// now somewhere else: the centre ray of every block of the NEW frame is
+// projected into the OLD camera's image (exact for a rotation; a translation
+// adds parallax, hence `radius`), and the forecast is the maximum over the old
+// blocks within `radius` of that position -- or, for a direction the old frame
+// did not see, `unseen`, the mean cost of a block.  The forecast only orders
+// the work and picks the blocks handed out in pieces.
+// pool != 0: cost words of the latency engine (granularity in bits 30-31).
+__global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, int radius, int pool, float w1,
+                                float w2, unsigned unseen) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_items) return;
+  auto cost_of = [&](unsigned word) -> unsigned {
+    if (pool) {
+      const unsigned lvl = word >> 30;
+      const float c = (float)(word & 0x3fffffffu);
+      return (unsigned)(lvl == 1u ? c / w1 : (lvl >= 2u ? c / w2 : c));
+    }
+    const float c = (float)(word & 0x7fffffffu);
+    return (unsigned)((word >> 31) ? c / w1 : c);
+  };
+  if (!reproject) {
+    P.item_forecast[i] = cost_of(P.item_cost[i]);
+    return;
+  }
+  const int per_tile = P.blocks_x * P.blocks_y;
+  const int j = (int)(i / (unsigned)per_tile), b = (int)(i % (unsigned)per_tile);
+  const int tile = P.first_tile + j * P.tile_stride;
+  const int tx0 = P.region_x + (tile % P.tiles_x) * P.tile_w, ty0 = P.region_y + (tile / P.tiles_x) * P.tile_h;
+  const double px = tx0 + (b % P.blocks_x) * 8 + 4.0, py = ty0 + (b / P.blocks_x) * 8 + 4.0;  // block centre
+  double d[3], m[3][3];
+  for (int k = 0; k < 3; k++) {
+    d[k] = P.sensor.start_point[k] + P.sensor.delta_scanline[k] * py + P.sensor.delta_pixel[k] * px;
+    m[k][0] = old.delta_pixel[k];
+    m[k][1] = old.delta_scanline[k];
+    m[k][2] = -d[k];
+  }
+  // old.start + old.dp * x + old.ds * y = lambda * d   (Cramer's rule)
+  auto det3 = [](const double a[3][3]) {
+    return a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+           a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+  };
+  const double D = det3(m);
+  unsigned best = unseen;
+  if (D != 0.0) {
+    double mx[3][3], my[3][3], ml[3][3];
+    for (int k = 0; k < 3; k++) {
+      for (int c = 0; c < 3; c++) mx[k][c] = my[k][c] = ml[k][c] = m[k][c];
+      mx[k][0] = -old.start_point[k];
+      my[k][1] = -old.start_point[k];
+      ml[k][2] = -old.start_point[k];
+    }
+    const double ox = det3(mx) / D, oy = det3(my) / D, lambda = det3(ml) / D;
+    // old pixel -> old block of the SAME launch geometry (single-chunk launches and tiles alike)
+    if (lambda > 0.0 && ox >= P.region_x && oy >= P.region_y && ox < P.region_x + P.region_w && oy < P.region_y + P.region_h) {
+      bool any = false;
+      unsigned mxc = 0u;
+      for (int dy = -radius; dy <= radius; dy++) {
+        for (int dx = -radius; dx <= radius; dx++) {
+          const double qx = ox + 8.0 * dx, qy = oy + 8.0 * dy;
+          if (qx < P.region_x || qy < P.region_y || qx >= P.region_x + P.region_w || qy >= P.region_y + P.region_h) continue;
+          const int tx = ((int)qx - P.region_x) / P.tile_w, ty = ((int)qy - P.region_y) / P.tile_h;
+          const int t = ty * P.tiles_x + tx;
+          if (t < P.first_tile || (t - P.first_tile) % P.tile_stride != 0) continue;  // another rank's tile
+          const int jj = (t - P.first_tile) / P.tile_stride;
+          if (jj >= P.n_tiles) continue;
+          const int lx = ((int)qx - P.region_x) % P.tile_w, ly = ((int)qy - P.region_y) % P.tile_h;
+          mxc = max(mxc, cost_of(P.item_cost[(size_t)jj * per_tile + (size_t)(ly / 8) * P.blocks_x + lx / 8]));
+          any = true;
+        }
+      }
+      if (any) best = mxc;
+    }
+  }
+  P.item_forecast[i] = best;
+}
+
 constexpr int kSchedThreads = 1024;
 constexpr int kSchedBuckets = 8 * 32;
 __device__ __forceinline__ int cost_bucket(unsigned c) {  // descending cost = ascending bucket
@@ -233,26 +314,18 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
   if (tid == 0) s_sum = 0ull;
   for (int b = tid; b < kSchedBuckets; b += kSchedThreads) s_count[b] = 0u;
   __syncthreads();
-  // costs measured in quad mode are sums over four quarters
-  const float kQuadWork = 1.7f, kQuadShare = quad_share, kQuarterTime = 0.45f;
+  // (forecast_kernel has scaled the costs measured in quad mode -- sums over four
+  // quarters, kQuadWork = 1.7 -- back to whole blocks)
+  const float kQuadShare = quad_share, kQuarterTime = 0.45f;
   unsigned long long part = 0ull;
-  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
-    unsigned c = P.item_cost[i];
-    const bool was_quad = (c >> 31) != 0u;
-    c &= 0x7fffffffu;
-    if (was_quad) c = (unsigned)((float)c / kQuadWork);
-    part += c;
-  }
+  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) part += P.item_forecast[i];
   atomicAdd(&s_sum, part);
   __syncthreads();
   const float share = (float)s_sum / (float)(n_waves > 0 ? n_waves : 1);
   const float quad_above = share * kQuadShare;
   // pass 1: bucket counts (a quad block contributes four units)
   for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
-    unsigned c = P.item_cost[i];
-    const bool was_quad = (c >> 31) != 0u;
-    c &= 0x7fffffffu;
-    if (was_quad) c = (unsigned)((float)c / kQuadWork);
+    const unsigned c = P.item_forecast[i];
     const bool quad = (float)c > quad_above && c > 0u;
     const unsigned unit = quad ? (unsigned)((float)c * kQuarterTime) : c;
     atomicAdd(&s_count[cost_bucket(unit)], quad ? 4u : 1u);
@@ -270,10 +343,7 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
   // pass 2: scatter, and reset the costs for the coming frame (bit 31 notes
   // that the block will be measured as quarters)
   for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
-    unsigned c = P.item_cost[i];
-    const bool was_quad = (c >> 31) != 0u;
-    c &= 0x7fffffffu;
-    if (was_quad) c = (unsigned)((float)c / kQuadWork);
+    const unsigned c = P.item_forecast[i];
     const bool quad = (float)c > quad_above && c > 0u;
     const unsigned unit = quad ? (unsigned)((float)c * kQuarterTime) : c;
     const unsigned at = atomicAdd(&s_start[cost_bucket(unit)], quad ? 4u : 1u);
@@ -454,7 +524,10 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
           if (prim < 0) {  // mythtracer.cc:23-31
             do_return = true;
           } else {
-            if (STATS) st.v[ST_SHADED_HITS]++;
+            if (STATS) {
+              st.v[ST_SHADED_HITS]++;
+              st.v[ST_BYTES_VECTOR] += 72u + 72u + 4u + 64u;  // vertices, normals, material index, material
+            }
             Pt = ro + rd * t;  // primitive_triangle.cc:141
             dir = rd;
             const double *vtx = S.tri_vertex + (size_t)prim * 9;
@@ -488,7 +561,10 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
             }
           }
         } else {  // ---- one iteration of the shadow loop, mythtracer.cc:94-156
-          if (STATS) st.v[ST_RAYS_SHADOW]++;
+          if (STATS) {
+            st.v[ST_RAYS_SHADOW]++;
+            st.v[ST_BYTES_VECTOR] += 96u + 4u + 32u;  // light, occluder's material index and transparency
+          }
           const MT_CONST mt_light *lt = lights + li;
           const V3 lpos = v3(lt->position[0], lt->position[1], lt->position[2]);
           bool light_done = false, in_shadow = false;
@@ -635,6 +711,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
           const MT_CONST mt_material *m = mtls + mtl;
           const double refl = m->reflectance, tr = m->transparency;
           if (level < P.max_depth && refl > 0.0 && coef > 0.01 && !in_object) {  // :181-189
+            if (STATS) st.v[ST_BYTES_VECTOR] += 2u * 88u;  // recursion frame, written now and read at the return
             fio.put3(level, 0, color);
             fio.put3(level, 3, Pt);
             fio.put3(level, 6, dir);
@@ -664,6 +741,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
 
         while (do_return) {  // unwinding TraceRayWorker returns
           if (level == 0) {
+            if (STATS) st.v[ST_BYTES_VECTOR] += 3u;
             uint8_t *o = P.out_rgb + px_index * 3;  // V3DtoRGB + chunk-local store, :301
             o[0] = channel_to_u8(retval.x);
             o[1] = channel_to_u8(retval.y);
@@ -778,6 +856,7 @@ __global__ __launch_bounds__(256, 3) void intersect_kernel(DevScene S, int n, co
     if (lane == 0) {
       atomicAdd(counters + ST_WAVE_NODE_STEPS, (unsigned long long)st.wave_node_steps);
       atomicAdd(counters + ST_WAVE_TRI_STEPS, (unsigned long long)st.wave_tri_steps);
+      atomicAdd(counters + ST_BYTES_SCALAR, (unsigned long long)st.bytes_scalar);
     }
   }
 }

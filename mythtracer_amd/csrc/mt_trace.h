@@ -155,10 +155,10 @@ __device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
 // Per-lane work counters of one wave (see mt_stats).
 struct LaneStats {
   unsigned v[ST_WAVE_NODE_STEPS];  // the per-lane ones
-  unsigned wave_node_steps, wave_tri_steps;  // wave-uniform
+  unsigned wave_node_steps, wave_tri_steps, bytes_scalar;  // wave-uniform
   __device__ void clear() {
     for (int i = 0; i < ST_WAVE_NODE_STEPS; i++) v[i] = 0;
-    wave_node_steps = wave_tri_steps = 0;
+    wave_node_steps = wave_tri_steps = bytes_scalar = 0;
   }
 };
 
@@ -167,6 +167,9 @@ struct ScanOut {
   int best;           // stream index of the closest hit in the list, -1 none
   double best_t;
   unsigned mt_tests;  // Möller–Trumbore evaluations performed for this lane
+  // bytes this scan requested: per lane (vector loads) and once for the wave
+  // (scalar loads; wave-uniform).  Counted in the STATS instantiations only.
+  unsigned bytes_v = 0, bytes_s = 0;
 #ifdef MT_PROF
   unsigned n_groups = 0, n_live = 0, n_ranges = 0, n_range_tris = 0;
   unsigned t_a = 0, t_b = 0, t_c = 0;  // section times (s_memtime ticks)
@@ -260,7 +263,10 @@ __device__ __forceinline__ void flush_candidates(const DevScene &S, const RayReg
                                                  LaneStats &st) {
   if (pend >= 0) {
     double t;
-    if (STATS) st.v[ST_MT_TESTS]++;
+    if (STATS) {
+      st.v[ST_MT_TESTS]++;
+      st.v[ST_BYTES_VECTOR] += 72u;
+    }
     if (moller_trumbore(S.tri_vertex + (size_t)pend * 9, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &t)) {
       // octtree.cc:186-195: keep the old one only if it exists and is
       // strictly closer.
@@ -385,6 +391,7 @@ __device__ __forceinline__ void scan_node_prims(const DevScene &S, const RayRegs
   PairRegs A, B;
   issue_pair(A, p);
   await_pair(A);
+  if (STATS) st.bytes_scalar += 96u * (unsigned)((pc + 1) / 2 + 1);  // two fp64 boxes per fetch, one look-ahead
   for (int k = 0;;) {
     issue_pair(B, p + 12);
     scan_pair<MODE, OCT, STATS>(S, r, A, pb, k, pc, pend, pmask, best, best_t, st);
@@ -593,6 +600,7 @@ __device__ __forceinline__ void scan_quad(const DevScene &S, const RayRegs &r, c
     if (m[j] == 0ull) continue;  // wave-uniform
     const MT_CONST double *a = boxes + j * 6;
     const double b[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
+    if (STATS) st.bytes_scalar += 48u;
     const unsigned long long pm = slab_pass<(OCT == 8 ? 1 : 2), (OCT == 8 ? 0 : OCT)>(b, r) & m[j];
     if (pm == 0ull) continue;
     if (pm & pmask) {  // some lane would need a second slot: resolve first
@@ -616,6 +624,7 @@ __device__ __forceinline__ void scan_node_filtered(const DevScene &S, const RayR
   QuadRegs A, B;
   issue_quad(A, p);
   await_quad(A);
+  if (STATS) st.bytes_scalar += 96u * (unsigned)((pc + 3) / 4 + 1);  // four fp32 boxes per fetch, one look-ahead
   for (int k = 0;;) {
     issue_quad(B, p + 24);  // unconditional look-ahead: the stream is padded
     scan_quad<OCT, STATS>(S, r, f, A, B, pb, k, pc, pend, pmask, best, best_t, st);
@@ -700,6 +709,7 @@ __device__ __forceinline__ void scan_node_transposed(const DevScene &S, const Ra
       const int tri_c = tri < pc ? tri : pc - 1;
       const double *bp = boxes + (size_t)tri_c * 6;
       const double b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
+      if (STATS) st.v[ST_BYTES_VECTOR] += 48u;
       const unsigned long long pm =
           slab_pass<EX ? 0 : 1, 0>(b, u) & __builtin_amdgcn_ballot_w64(tri < pc);
       if (pm != 0ull) {
@@ -708,6 +718,7 @@ __device__ __forceinline__ void scan_node_transposed(const DevScene &S, const Ra
         double t = 0.0;
         bool hit = false;
         if (mine) {
+          if (STATS) st.v[ST_BYTES_VECTOR] += 72u;
           hit = moller_trumbore(S.tri_vertex + (size_t)(pb + tri_c) * 9, u.ox, u.oy, u.oz, u.dx, u.dy, u.dz, &t);
         }
         unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
@@ -774,6 +785,7 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
     for (int g0 = 0; g0 < nb; g0 += 64) {
       const int g = g0 + lane;
       const float *bp = blk + (size_t)(g < nb ? g : nb - 1) * 6;
+      if (STATS) st.v[ST_BYTES_VECTOR] += 24u;
       const float tnx = __builtin_fmaf(bp[nx], fix, cnx), tfx = __builtin_fmaf(bp[fx], fix, cfx);
       const float tny = __builtin_fmaf(bp[ny], fiy, cny), tfy = __builtin_fmaf(bp[fy], fiy, cfy);
       const float tnz = __builtin_fmaf(bp[nz], fiz, cnz), tfz = __builtin_fmaf(bp[fz], fiz, cfz);
@@ -805,12 +817,14 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
         const int tri_c = ok ? tri : pb;
         const double *bx = S.tri_aabb + (size_t)tri_c * 6;
         const double b[6] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]};
+        if (STATS) st.v[ST_BYTES_VECTOR] += 48u;
         const unsigned long long pm = slab_pass<EX ? 0 : 1, 0>(b, u) & __builtin_amdgcn_ballot_w64(ok);
         if (pm == 0ull) continue;
         if (STATS) mt_count += (unsigned)__builtin_popcountll(pm);
         const bool mine = ((pm >> lane) & 1ull) != 0;
         double t = 0.0;
         bool hit = false;
+        if (STATS && mine) st.v[ST_BYTES_VECTOR] += 72u;
         if (mine) hit = moller_trumbore(S.tri_vertex + (size_t)tri_c * 9, u.ox, u.oy, u.oz, u.dx, u.dy, u.dz, &t);
         unsigned long long hm = __builtin_amdgcn_ballot_w64(hit);
         while (hm != 0ull) {  // ascending lane = ascending stream position
@@ -1036,6 +1050,7 @@ __device__ __attribute__((noinline)) ScanOut scan_small_lane_call(const double *
   r.ix = ix; r.iy = iy; r.iz = iz;
   ScanOut o{-1, 0.0, 0u};
   for (int k = 0; k < pc; k += 3) {
+    if (STATS) o.bytes_v += 3u * 48u;
     double b[3][6];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -1048,7 +1063,10 @@ __device__ __attribute__((noinline)) ScanOut scan_small_lane_call(const double *
     for (int j = 0; j < 3; j++) {
       if (k + j >= pc) break;
       if (!slab_pass_lane<EX>(b[j], r)) continue;
-      if (STATS) o.mt_tests++;
+      if (STATS) {
+        o.mt_tests++;
+        o.bytes_v += 72u;
+      }
       double t;
       if (moller_trumbore(vtx + (size_t)(pb + k + j) * 9, ox, oy, oz, dx, dy, dz, &t)) {
         if (!(o.best >= 0 && t > o.best_t)) {
@@ -1280,6 +1298,7 @@ __device__ __forceinline__ ScanOut scan_small_lane_f32_call(const DevScene *self
   const bool sx = __builtin_signbit(r.ix), sy = __builtin_signbit(r.iy), sz = __builtin_signbit(r.iz);
   ScanOut o{-1, 0.0, 0u};
   for (int k = 0; k < pc; k += 4) {
+    if (STATS) o.bytes_v += 4u * 24u;
     float b[4][6];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -1294,8 +1313,12 @@ __device__ __forceinline__ ScanOut scan_small_lane_f32_call(const DevScene *self
       if (!subtree_may_hit(b[j], f, sx, sy, sz)) continue;  // the same conservative test, per lane
       const double *bx = S.tri_aabb + (size_t)(pb + k + j) * 6;
       const double e[6] = {bx[0], bx[1], bx[2], bx[3], bx[4], bx[5]};
+      if (STATS) o.bytes_v += 48u;
       if (!slab_pass_lane<false>(e, r)) continue;
-      if (STATS) o.mt_tests++;
+      if (STATS) {
+        o.mt_tests++;
+        o.bytes_v += 72u;
+      }
       double t;
       if (moller_trumbore(S.tri_vertex + (size_t)(pb + k + j) * 9, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &t)) {
         if (!(o.best >= 0 && t > o.best_t)) {
@@ -1319,6 +1342,8 @@ __device__ __attribute__((noinline)) ScanOut scan_filtered_call(const DevScene *
   ScanOut o{-1, 0.0, 0u};
   scan_node_filtered<OCT, STATS>(S, r, f, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
   o.mt_tests = st.v[ST_MT_TESTS];
+  o.bytes_v = st.v[ST_BYTES_VECTOR];
+  o.bytes_s = st.bytes_scalar;
   return o;
 }
 
@@ -1354,6 +1379,7 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
     const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
 #endif
     unsigned long long live = group_live_mask<OCT>(gp + (size_t)(b0 + g0) * 6, n, f);
+    if (STATS) st.bytes_scalar += 96u * (unsigned)((n + 3) / 4 + 1);  // block boxes, four per fetch
 #ifdef MT_PROF
     const unsigned long long tg1 = __builtin_amdgcn_s_memtime();
     o.t_a += (unsigned)(tg1 - tg0);
@@ -1380,6 +1406,8 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
 #endif
   }
   o.mt_tests = st.v[ST_MT_TESTS];
+  o.bytes_v = st.v[ST_BYTES_VECTOR];
+  o.bytes_s = st.bytes_scalar;
   return o;
 }
 
@@ -1488,6 +1516,8 @@ __device__ __forceinline__ ScanOut scan_big_vec(const DevScene &S, int lane, int
   }
   if (pmask) flush_candidates<STATS>(S, r, pend, o.best, o.best_t, st);
   o.mt_tests = st.v[ST_MT_TESTS];
+  o.bytes_v = st.v[ST_BYTES_VECTOR];
+  o.bytes_s = st.bytes_scalar;
   return o;
 }
 
@@ -1501,6 +1531,8 @@ __device__ __attribute__((noinline)) ScanOut scan_exact_call(const double *b64, 
   ScanOut o{-1, 0.0, 0u};
   scan_node_prims<MODE, OCT, STATS>(S, r, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
   o.mt_tests = st.v[ST_MT_TESTS];
+  o.bytes_v = st.v[ST_BYTES_VECTOR];
+  o.bytes_s = st.bytes_scalar;
   return o;
 }
 
@@ -1518,6 +1550,8 @@ __device__ __attribute__((noinline)) ScanOut scan_transposed_call(const double *
   ScanOut o{-1, 0.0, 0u};
   scan_node_transposed<EX, STATS>(S, r, lane, inmask, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
   o.mt_tests = st.v[ST_MT_TESTS];
+  o.bytes_v = st.v[ST_BYTES_VECTOR];
+  o.bytes_s = st.bytes_scalar;
   return o;
 }
 
@@ -1540,6 +1574,8 @@ __device__ __attribute__((noinline)) ScanOut scan_transposed_blocks_call(const D
   scan_node_transposed_blocks<EX, STATS>(S, r, f, lane, inmask, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
 #endif
   o.mt_tests = st.v[ST_MT_TESTS];
+  o.bytes_v = st.v[ST_BYTES_VECTOR];
+  o.bytes_s = st.bytes_scalar;
   return o;
 }
 
@@ -1591,8 +1627,8 @@ struct TraceOut {
   int status;   // DEV_OK or DEV_ERR_*
   int prim;     // stream index of the closest hit, -1 none
   double t;
-  unsigned box_tests, node_visits, tri_tests, mt_tests;  // per lane
-  unsigned wave_node_steps, wave_tri_steps;              // wave-uniform
+  unsigned box_tests, node_visits, tri_tests, mt_tests, bytes_vector;  // per lane
+  unsigned wave_node_steps, wave_tri_steps, bytes_scalar;              // wave-uniform
 };
 
 // NOT inlined on purpose: as a function of its own the traversal gets its own
@@ -1643,6 +1679,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   const int pack_shift = stk.pack_shift;  // wave-uniform
   if (STATS) {
     cnt[0 * 64 + lane] = 0; cnt[1 * 64 + lane] = 0; cnt[2 * 64 + lane] = 0; cnt[3 * 64 + lane] = 0;
+    cnt[4 * 64 + lane] = 0;
   }
   RayRegs r;
   r.ox = ox; r.oy = oy; r.oz = oz;
@@ -1686,7 +1723,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   if (want) {
     // root box test, octtree.cc:35-37 (exact form; once per ray)
     const MT_CONST NodeRec *R = nodes;
-    if (STATS) cnt[0 * 64 + lane] = 1;
+    if (STATS) {
+      cnt[0 * 64 + lane] = 1;
+      st.bytes_scalar += 96u;  // the root record
+    }
     const double t1 = (R->lo[0] - ox) * r.ix, t2 = (R->hi[0] - ox) * r.ix;
     const double t3 = (R->lo[1] - oy) * r.iy, t4 = (R->hi[1] - oy) * r.iy;
     const double t5 = (R->lo[2] - oz) * r.iz, t6 = (R->hi[2] - oz) * r.iz;
@@ -1742,6 +1782,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         depth++;
         cur = child;
         load_record(child);
+        if (STATS) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         break;
       }
       if (depth == 0) {
@@ -1820,6 +1861,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)cur_pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           if (o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (o.bytes_v) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], o.bytes_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         unsigned ordw = 0;
         const int fc = cur_fc;
@@ -1830,6 +1872,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, S.force_mode != 9)
                              : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                               irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr);
+        }
+        if (STATS && fc != 0) {  // node planes + record (88 B) and the subtree boxes of the children entered
+          __hip_atomic_fetch_add(&cnt[4 * 64 + lane], 88u + 24u * (((ordw >> 24) & 15u) + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         finish_node(fc, ordw, o.best, o.best_t);
       }
@@ -1922,6 +1967,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           if (o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (o.bytes_v) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], o.bytes_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
       }
     }
@@ -1974,6 +2020,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)cur_pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
           if (o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (o.bytes_v) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], o.bytes_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         unsigned ordw = 0;
         const int fc = cur_fc;
@@ -1987,6 +2034,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, kSurvivorsFirst)
                              : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                               irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr);
+        }
+        if (STATS && fc != 0) {  // node planes + record (88 B) and the subtree boxes of the children entered
+          __hip_atomic_fetch_add(&cnt[4 * 64 + lane], 88u + 24u * (((ordw >> 24) & 15u) + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
         }
         finish_node(fc, ordw, o.best, o.best_t);
       }
@@ -2090,6 +2140,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       best = o.best;
       best_t = o.best_t;
       if (STATS && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (STATS && o.bytes_v) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], o.bytes_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       MT_PROF_END(PROF_SCAN_TRANSPOSED, prof_t1);
 #ifdef MT_PROF
       MT_PROF_COUNT(PROF_TA_T, __builtin_amdgcn_readfirstlane(o.t_a));
@@ -2141,6 +2192,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         best = o.best;
         best_t = o.best_t;
         if (STATS && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (STATS && o.bytes_v) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], o.bytes_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);  // wave-uniform
       }
 #ifdef MT_PROF
     }
@@ -2169,6 +2222,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
                                                        irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr)
                            : order_children_regular(Np, r, sub, f32, true, kSurvivorsFirst);
       }
+      if (STATS && fc != 0) st.bytes_scalar += 96u + 24u * 8u;  // node record + the children's subtree boxes, once for the wave
       finish_node(fc, ordw, best, best_t);
     }
     MT_PROF_END(PROF_CHILDREN_UNWIND, prof_t1);
@@ -2202,8 +2256,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   o.node_visits = STATS ? cnt[1 * 64 + lane] : 0u;
   o.tri_tests = STATS ? cnt[2 * 64 + lane] : 0u;
   o.mt_tests = STATS ? cnt[3 * 64 + lane] : 0u;
+  o.bytes_vector = STATS ? cnt[4 * 64 + lane] : 0u;
   o.wave_node_steps = st.wave_node_steps;
   o.wave_tri_steps = st.wave_tri_steps;
+  o.bytes_scalar = st.bytes_scalar;
   return o;
 }
 
@@ -2215,6 +2271,8 @@ __device__ __forceinline__ void add_trace_stats(LaneStats &st, const TraceOut &o
     st.v[ST_NODE_VISITS] += o.node_visits;
     st.v[ST_TRI_TESTS] += o.tri_tests;
     st.v[ST_MT_TESTS] += o.mt_tests;
+    st.v[ST_BYTES_VECTOR] += o.bytes_vector;
+    st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_scalar);
     st.wave_node_steps += (unsigned)__builtin_amdgcn_readfirstlane((int)o.wave_node_steps);
     st.wave_tri_steps += (unsigned)__builtin_amdgcn_readfirstlane((int)o.wave_tri_steps);
   }
