@@ -236,7 +236,10 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     P.pool_cap = (int)cap;
     P.prio_units = (unsigned)(s->n_cu * 4);  // one per SIMD
   } else {
-    const size_t fbytes = waves * (size_t)(max_depth > 0 ? max_depth : 1) * kFrameSlots * 64 * sizeof(double);
+    size_t fbytes = waves * (size_t)(max_depth > 0 ? max_depth : 1) * kFrameSlots * 64 * sizeof(double);
+#if MT_DUP == 7
+    fbytes += waves * 100 * 64 * sizeof(unsigned);  // the spill-traffic experiment's buffer, behind the frames
+#endif
     const size_t slots_px = (size_t)n_tiles * (size_t)tile_w * (size_t)tile_h;
     int rc = ensure_bytes((void **)&s->d_frames, &s->frames_bytes, fbytes);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_hit_prim, &s->hit_prim_bytes, slots_px * sizeof(int32_t));
@@ -303,7 +306,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       HIP_TRY(hipGetLastError());
     }
     // blocks above cut_share of an even split of the frame are handed out in pieces
-    SchedParams sp{0.8f, {1.0f, 0.35f, 0.12f}, {1.0f, 1.1f, 3.0f}, 3.0f};
+    SchedParams sp{1.0f, {1.0f, 0.35f, 0.12f}, {1.0f, 1.1f, 3.0f}, 3.0f};
     if (const char *e = getenv("MT_DEBUG_CUT_SHARE")) sp.cut_share = (float)atof(e);
     if (const char *e = getenv("MT_DEBUG_PIECE_TIME")) sscanf(e, "%f,%f", &sp.piece_time[1], &sp.piece_time[2]);
     if (const char *e = getenv("MT_DEBUG_PIECE_WORK")) sscanf(e, "%f,%f", &sp.piece_work[1], &sp.piece_work[2]);

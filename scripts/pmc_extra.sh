@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras"
 i=0
 for grp in "$@"; do
   i=$((i+1))

@@ -9,7 +9,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline"
+BENCH="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras"
 timeout -k 10 150 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$OUT/stats.log" 2>&1
 echo "stats done" >> "$OUT/progress.txt"
 i=0
@@ -20,7 +20,9 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" \
            "WRITE_SIZE" \
            "TCC_HIT_sum TCC_MISS_sum" \
-           "SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU"; do
+           "SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
+           "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES" \
+           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
   i=$((i+1))
   timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp -d "$OUT/pmc$i" --output-format csv -- $BENCH > "$OUT/pmc$i.log" 2>&1 || echo "pass $i ($grp) failed" >> "$OUT/failed.txt"
   echo "pass $i done" >> "$OUT/progress.txt"

@@ -1,11 +1,12 @@
 """Summarises gpurun_out/prof_<tag>/ (scripts/pmc_passes.sh) per kernel.
 
-bench.py --steps 4 --warmup 2 launches mt::render_kernel eight times: warm-up 1
-(no cost history yet: primary_kernel + render_kernel), warm-up 2 and the four
-timed steps (schedule_kernel + render_kernel), then two untimed counting frames
-(traversal mode 7; primary rays only).  Figures below are means over the four
-TIMED launches (dispatches 3..6 of render_kernel in launch order); the other
-launches are listed for reference.
+bench.py --steps 4 --warmup 2 --no-extras launches mt::render_kernel six times:
+warm-up 1 (no cost history yet: primary_kernel + render_kernel), warm-up 2 and
+the four timed steps (forecast_kernel + schedule_kernel + render_kernel).
+Figures below are means over the four TIMED launches (dispatches 3..6 of
+render_kernel in launch order); the other launches are listed for reference.
+With a second argument the derived figures are also written as JSON (the entry
+bench.py reads from profiles/hbm_traffic.json).
 
 Usage: python scripts/pmc_summary.py <tag> > profiles/<tag>_pmc_summary.txt"""
 import csv, glob, os, sys, collections
@@ -64,7 +65,41 @@ for k in cnt:
         print("  HBM_TRAFFIC_BYTES %d" % int(rd + wr))
     if "TCC_HIT_sum" in m:
         print("  L2 hit rate %.4f" % (m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])))
+    derived = {}
+    if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
+        derived["hbm_bytes_per_launch"] = int(m["FETCH_SIZE"] * 1024 * 2 + m["WRITE_SIZE"] * 1024)
     if "SQ_WAVE_CYCLES" in m:
         print("  share of wave time: VALU busy %.3f  waiting on s_waitcnt %.3f  issue-stalled %.3f" % (
             m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"], m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
             m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]))
+        derived["wave_time_share"] = {"valu_busy": m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"],
+                                      "s_waitcnt": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
+                                      "issue_stalled": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]}
+    t = dur.get(k)
+    if t and len(t) >= 6 and "SQ_ACTIVE_INST_VALU" in m:
+        ms = sum(t[TIMED]) / len(t[TIMED])
+        # SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles); 1024 SIMDs; the clock is
+        # GRBM_GUI_ACTIVE / 8 XCDs / duration (MI355X_MICROARCH.md, DVFS section)
+        clk = m.get("GRBM_GUI_ACTIVE", 0) / 8.0 / (ms * 1e-3) if m.get("GRBM_GUI_ACTIVE") else 2.4e9
+        frac = m["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * clk * ms * 1e-3)
+        print("  VALU issue: SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x %.2f GHz x %.3f ms) = %.3f of the chip's VALU issue cycles" % (clk / 1e9, ms, frac))
+        derived["name"] = "VALU issue"
+        derived["frac"] = frac
+        derived["formula"] = "SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x clock x kernel time), clock = GRBM_GUI_ACTIVE / 8 / kernel time"
+        derived["effective_clock_GHz"] = clk / 1e9
+        derived["kernel_ms_under_rocprof"] = ms
+    if "SQ_THREAD_CYCLES_VALU" in m and "SQ_ACTIVE_INST_VALU" in m:
+        lanes = m["SQ_THREAD_CYCLES_VALU"] / m["SQ_ACTIVE_INST_VALU"]
+        print("  active lanes per VALU instruction: %.1f of 64" % lanes)
+        derived["active_lanes_per_valu_instruction"] = lanes
+    if "TCC_HIT_sum" in m:
+        l2 = (m["TCC_HIT_sum"] + m["TCC_MISS_sum"]) * 128
+        print("  L2 requests x 128 B = %.1f GB per launch" % (l2 / 1e9))
+        derived["l2_bytes_per_launch"] = int(l2)
+        derived["l2_hit_rate"] = m["TCC_HIT_sum"] / (m["TCC_HIT_sum"] + m["TCC_MISS_sum"])
+    if "SQC_DCACHE_REQ" in m and m["SQC_DCACHE_REQ"]:
+        derived["scalar_cache_miss_rate"] = m["SQC_DCACHE_MISSES"] / m["SQC_DCACHE_REQ"]
+        print("  scalar data cache miss rate %.3f" % derived["scalar_cache_miss_rate"])
+    if len(sys.argv) > 2 and derived:
+        import json
+        json.dump(derived, open(sys.argv[2], "w"), indent=1, sort_keys=True)
