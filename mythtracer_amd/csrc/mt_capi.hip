@@ -236,7 +236,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     P.pool_cap = (int)cap;
     P.prio_units = (unsigned)(s->n_cu * 4);  // one per SIMD
   } else {
-    size_t fbytes = waves * (size_t)(max_depth > 0 ? max_depth : 1) * kFrameSlots * 64 * sizeof(double);
+    size_t fbytes = waves * ((size_t)(max_depth > 0 ? max_depth : 1) * kFrameSlots + kParkSlots) * 64 * sizeof(double);
 #if MT_DUP == 7
     fbytes += waves * 100 * 64 * sizeof(unsigned);  // the spill-traffic experiment's buffer, behind the frames
 #endif

@@ -436,6 +436,7 @@ __global__ __launch_bounds__(256, 3) void pool_kernel(DevScene S, RenderParams P
 #endif
       const int prim = to.prim;
       const double t = to.t;
+
       if (S.hb) {
         const unsigned long long ex = __builtin_amdgcn_read_exec();
         if (lane == 0) { S.hb[wave_id * 4 + 0] = 3 | ((unsigned long long)passes << 8); S.hb[wave_id * 4 + 3] = ex; }

@@ -25,9 +25,25 @@ enum { STAGE_REFL = 0, STAGE_REFR = 1 };
 // Recursion frames (one per level that has a child in flight) live in a
 // global scratch buffer, [wave][level][slot][lane] doubles: coalesced, and
 // touched only once per secondary ray.
+// Behind the frames of a wave: `kParkSlots` more slots per lane for the parts of
+// a lane's context that only a minority of passes needs -- the state of a shadow
+// loop that crosses glass (start point, light power), the three terms of a light
+// while a four-lane round waits for its slowest role, the ray direction of the
+// call being shaded (needed again after its lights, for the child rays).  Kept
+// in registers they would be spilled and reloaded around EVERY traversal call
+// (that traffic costs about a tenth of the frame).
+constexpr int kParkSlots = 18;
+enum { PARK_START = 0, PARK_LP = 3, PARK_ADD1 = 6, PARK_ADD2 = 9, PARK_ADD3 = 12, PARK_DIR = 15 };
 struct FrameIO {
   double *base;  // this wave's block
+  double *park;  // this wave's parked values, [slot][lane]
   int lane;
+  __device__ __forceinline__ void park3(int s, V3 v) const {
+    park[(s + 0) * 64 + lane] = v.x; park[(s + 1) * 64 + lane] = v.y; park[(s + 2) * 64 + lane] = v.z;
+  }
+  __device__ __forceinline__ V3 unpark3(int s) const {
+    return V3{park[(s + 0) * 64 + lane], park[(s + 1) * 64 + lane], park[(s + 2) * 64 + lane]};
+  }
   __device__ __forceinline__ double *slot(int level, int s) const {
     return base + ((size_t)level * kFrameSlots + s) * 64 + lane;
   }
@@ -382,6 +398,8 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
   stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
   FrameIO fio;
   fio.base = P.frames + (size_t)wave_id * (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64;
+  fio.park = P.frames + (size_t)gridDim.x * waves_per_block * (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64 +
+             (size_t)wave_id * kParkSlots * 64;
   fio.lane = lane;
 
   const MT_CONST mt_material *mtls = as_const(S.mtls);
@@ -457,10 +475,14 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
       const V3 d = s_start + (s_ds * (double)g.py) + (s_dp * (double)g.px);
       rd = normalized(d);
     }
-    V3 Pt = v3(0, 0, 0), Nn = Pt, surf = Pt, color = Pt, Rd = Pt, dir = Pt, L = Pt, start = Pt,
-       lp = Pt;
-    V3 add1 = Pt, add2 = Pt, add3 = Pt;  // this role's contributions to `color`, in the order they are added
-    bool has_light = false, has_add3 = false;
+    // (Not kept across passes, because every live value is spilled around the
+    // traversal call: the light direction -- it IS the shadow ray's direction rd --
+    // and the reflected direction, recomputed from dir and Nn when it is needed.)
+    // Parked instead (FrameIO::park): dir; start point and light power of a shadow
+    // loop once it has crossed glass (`crossed`); a role's three terms in a
+    // four-lane round.
+    V3 Pt = v3(0, 0, 0), Nn = Pt, surf = Pt, color = Pt;
+    bool has_light = false, has_add3 = false, crossed = false;
     double refl_dot = 0.0;
     int mtl = -1, li = 0, round_base = 0;
     bool traversing = false;
@@ -501,7 +523,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
         // traversal -- 100 more dwords per lane written before the call and read back
         // after it, coalesced like the compiler's own spills -- to see what that traffic costs.
         unsigned *dup_buf = (unsigned *)(P.frames + (size_t)gridDim.x * (blockDim.x >> 6) *
-                                         (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64) +
+                                         ((size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots + kParkSlots) * 64) +
                             (size_t)wave_id * 100 * 64 + lane;
         for (int q = 0; q < 100; q++) dup_buf[q * 64] = (unsigned)(q + lane) ^ (unsigned)passes;
 #endif
@@ -517,6 +539,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
         prim = to.prim;
         t = to.t;
         trc = to.status;
+
       }
       if (S.hb) {
         const unsigned long long ex = __builtin_amdgcn_read_exec();
@@ -531,6 +554,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
       // ---- stage 1 (per lane): consume the traversal result
       bool after_lights = false, do_return = false;
       V3 retval = v3(0, 0, 0);
+      V3 add1 = retval, add2 = retval, add3 = retval;  // this role's contributions to `color`, in the order they are added
       if (tracing) {
         if (mode == MODE_RADIANCE) {
           if (STATS) {  // with launch 1, level 0 was counted there
@@ -545,7 +569,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
               st.v[ST_BYTES_VECTOR] += 72u + 72u + 4u + 64u;  // vertices, normals, material index, material
             }
             Pt = ro + rd * t;  // primitive_triangle.cc:141
-            dir = rd;
+            const V3 dir = rd;
             const double *vtx = S.tri_vertex + (size_t)prim * 9;
             const Bary w = barycentric(vtx, Pt);
             Nn = interpolate(S.tri_normal + (size_t)prim * 9, w);  // :38
@@ -567,8 +591,9 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
                 const V3 uvw = interpolate(S.tri_uvw + (size_t)prim * 9, w);
                 surf = surf * texture_color_at(S.texs[m->tex], uvw.x, uvw.y);
               }
-              Rd = dir - Nn * (2 * dot(dir, Nn));  // :68-69
+              const V3 Rd = dir - Nn * (2 * dot(dir, Nn));  // :68-69
               refl_dot = dot(Rd, towards_camera);  // :170, the same for every light
+              fio.park3(PARK_DIR, dir);
               color = v3(0, 0, 0);
               round_base = 0;
               if (S.n_lights > 0) want_round = true;
@@ -584,6 +609,11 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
           const MT_CONST mt_light *lt = lights + li;
           const V3 lpos = v3(lt->position[0], lt->position[1], lt->position[2]);
           bool light_done = false, in_shadow = false;
+          V3 start = Pt, lp = v3(1.0, 1.0, 1.0);  // :90, :94 -- until the loop has crossed glass
+          if (crossed) {
+            start = fio.unpark3(PARK_START);
+            lp = fio.unpark3(PARK_LP);
+          }
           if (prim < 0) {
             light_done = true;  // :109-112
           } else {
@@ -608,7 +638,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
                 }
                 traversing = !traversing;
                 const V3 sp = ro + rd * t;
-                start = sp + (L * 0.0000001);  // :137
+                start = sp + (rd * 0.0000001);  // :137 (rd is light_direction)
                 if (sqr_distance(Pt, start) > sqr_distance(Pt, lpos)) {
                   light_done = true;  // :141-145
                 } else if (lp.x <= 0.001 && lp.y <= 0.001 && lp.z <= 0.001) {
@@ -616,8 +646,10 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
                   in_shadow = true;
                   light_done = true;
                 } else {
-                  ro = start + (L * 0.00001);  // next iteration, :95-99
-                  rd = L;
+                  ro = start + (rd * 0.00001);  // next iteration, :95-99; rd stays light_direction
+                  fio.park3(PARK_START, start);
+                  fio.park3(PARK_LP, lp);
+                  crossed = true;
                 }
               }
             }
@@ -634,13 +666,18 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
             lp.z = std_max(lp.z, amb.z);
             const V3 kd = v3(m->diffuse[0], m->diffuse[1], m->diffuse[2]);
             const V3 ld = v3(lt->diffuse[0], lt->diffuse[1], lt->diffuse[2]);
-            add2 = kd * surf * dot(L, Nn) * ld * lp;
+            add2 = kd * surf * dot(rd, Nn) * ld * lp;
             has_add3 = false;
             if (!in_shadow && refl_dot > 0) {
               const V3 ks = v3(m->specular[0], m->specular[1], m->specular[2]);
               const V3 ls = v3(lt->specular[0], lt->specular[1], lt->specular[2]);
               add3 = ks * surf * ::pow(refl_dot, m->specular_exp) * ls;
               has_add3 = true;
+            }
+            if (quad) {  // the round may have to wait for a slower role
+              fio.park3(PARK_ADD1, add1);
+              fio.park3(PARK_ADD2, add2);
+              fio.park3(PARK_ADD3, add3);
             }
             mode = MODE_IDLE;
           }
@@ -654,6 +691,11 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
         const unsigned long long busy = __ballot(alive && mode == MODE_SHADOW);
         const bool round_done = owner && waiting_round && ((busy & my_group) == 0ull);
         const int hl0 = has_light ? 1 : 0, h30 = has_add3 ? 1 : 0;
+        if (quad && has_light) {  // possibly computed in an earlier pass
+          add1 = fio.unpark3(PARK_ADD1);
+          add2 = fio.unpark3(PARK_ADD2);
+          add3 = fio.unpark3(PARK_ADD3);
+        }
         // role 0 is the owner itself
         if (round_done && has_light) {
           color = color + add1;
@@ -704,12 +746,10 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
           if (has_light) {
             const MT_CONST mt_light *lt = lights + li;
             const V3 lpos = v3(lt->position[0], lt->position[1], lt->position[2]);
-            L = normalized(lpos - Pt);
-            lp = v3(1.0, 1.0, 1.0);
+            rd = normalized(lpos - Pt);  // light_direction, :79-80
             traversing = false;
-            start = Pt;
-            ro = start + (L * 0.00001);
-            rd = L;
+            crossed = false;
+            ro = Pt + (rd * 0.00001);  // start_point = intersection_point, :94-97
             mode = MODE_SHADOW;
           } else {
             mode = MODE_IDLE;
@@ -726,6 +766,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
         if (after_lights) {
           const MT_CONST mt_material *m = mtls + mtl;
           const double refl = m->reflectance, tr = m->transparency;
+          const V3 dir = fio.unpark3(PARK_DIR);
           if (level < P.max_depth && refl > 0.0 && coef > 0.01 && !in_object) {  // :181-189
             if (STATS) st.v[ST_BYTES_VECTOR] += 2u * 88u;  // recursion frame, written now and read at the return
             fio.put3(level, 0, color);
@@ -734,6 +775,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
             *fio.slot(level, 9) = coef;
             *(long long *)fio.slot(level, 10) =
                 (long long)mtl | ((long long)(in_object ? 1 : 0) << 32) | ((long long)STAGE_REFL << 33);
+            const V3 Rd = dir - Nn * (2 * dot(dir, Nn));  // :68-69 again: same operands, same value
             ro = Pt + (Rd * 0.0001);  // :70-74
             rd = Rd;
             coef = coef * refl;
@@ -777,7 +819,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
             const double tr = m->transparency;
             if (tr > 0.0) {  // level < max_depth holds: this frame pushed a child
               Pt = fio.get3(level, 3);
-              dir = fio.get3(level, 6);
+              const V3 dir = fio.get3(level, 6);
               coef = *fio.slot(level, 9);
               fio.put3(level, 0, color);
               *(long long *)fio.slot(level, 10) =

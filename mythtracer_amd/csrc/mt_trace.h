@@ -858,6 +858,11 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
 }
 
 
+#ifdef MT_SORT_ALL_PAIRS
+constexpr bool kSortAnyOnly = false;
+#else
+constexpr bool kSortAnyOnly = true;
+#endif
 // Child slab tests + ordering of the hit children, octtree.cc:204-216.
 // Returns ord (3 bits per entry) | count << 24.
 // keep: bit c clear = child c's subtree provably holds no triangle this ray's
@@ -937,13 +942,17 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
       return v0 ? (c0 | (1u << 24)) : 0u;
     }
     // No NaN keys: the stable sort by tmin is the order by (tmin, index).
+    // Only the children that are left for SOME lane of the wave (`any`, 2..4 of
+    // them for coherent rays) take part in the pair comparisons.
     unsigned rank[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) rank[c] = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
+      if (kSortAnyOnly && ((any >> i) & 1u) == 0u) continue;  // wave-uniform
 #pragma unroll
       for (int j = i + 1; j < 8; j++) {
+        if (kSortAnyOnly && ((any >> j) & 1u) == 0u) continue;  // wave-uniform
         const bool both = valid[i] && valid[j];
         const bool j_first = tm[j] < tm[i];
         rank[i] += (both && j_first) ? 1u : 0u;
@@ -952,6 +961,7 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
     }
 #pragma unroll
     for (int c = 0; c < 8; c++) {
+      if (kSortAnyOnly && ((any >> c) & 1u) == 0u) continue;  // wave-uniform
       if (valid[c]) {
         ord |= (unsigned)c << (3 * rank[c]);
         cnt++;
@@ -1629,6 +1639,7 @@ struct TraceOut {
   double t;
   unsigned box_tests, node_visits, tri_tests, mt_tests, bytes_vector;  // per lane
   unsigned wave_node_steps, wave_tri_steps, bytes_scalar;              // wave-uniform
+
 };
 
 // NOT inlined on purpose: as a function of its own the traversal gets its own
@@ -2260,6 +2271,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   o.wave_node_steps = st.wave_node_steps;
   o.wave_tri_steps = st.wave_tri_steps;
   o.bytes_scalar = st.bytes_scalar;
+
   return o;
 }
 
