@@ -188,6 +188,23 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   P.counters = s->d_counters;
   P.work_counter = s->d_work;
   const size_t waves = (size_t)s->grid_blocks * s->waves_per_block;
+  // The block costs of the previous launch are a valid forecast when that
+  // launch had the same geometry (an animation frame, main_local.cc:79-110, or a
+  // repeated benchmark step) -- whichever engine measured them.  Then the blocks
+  // are handed out longest first, the longest in pieces.  Otherwise: the ray
+  // pool forecasts from 1/16 of the primary rays (probe_kernel); the state
+  // machine classifies the blocks by material in a launch of its own
+  // (primary_kernel).
+  unsigned long long sig = 1469598103934665603ull;
+  {
+    const long long key[] = {image_w, image_h, rx, ry, rw, rh, tile_w, tile_h, first_tile, tile_stride,
+                             n_tiles, max_depth, s->dev.n_lights};
+    for (long long v : key) {
+      sig = (sig ^ (unsigned long long)v) * 1099511628211ull;
+    }
+    if (sig == 0) sig = 1;
+  }
+  const bool have_costs = s->use_history && s->cost_signature == sig;
   // ---- which engine?  Both compute every pixel with the same operations in the
   // same order (tests render through both).  The state machine (one lane per
   // pixel, its context in registers) has the lower cost per ray and is the
@@ -200,9 +217,14 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   if (engine != 1 && engine != 2) {
     float per_wave = 6.0f;  // blocks per wave below which a launch is taken to be tail-bound
     if (const char *e = getenv("MT_DEBUG_POOL_BELOW")) per_wave = (float)atof(e);
-    engine = ((float)P.n_items < per_wave * (float)waves) ? 2 : 1;
+    // ... and the first frame of a geometry: without measured costs the order
+    // of the work is a guess, and the pool's short pixel chains forgive a bad
+    // guess (13 ms against the state machine's 15.5 on the 1080p frame)
+    engine = (!have_costs || (float)P.n_items < per_wave * (float)waves) ? 2 : 1;
   }
   const bool pool_engine = engine == 2;
+  const bool history = have_costs && (pool_engine || d_debug == nullptr);
+  P.from_primary = history ? 0 : 1;
   {
     int rc = ensure_bytes((void **)&s->d_item_cost, &s->item_cost_bytes, (size_t)P.n_items * 4);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_item_forecast, &s->item_forecast_bytes, (size_t)P.n_items * 4);
@@ -255,24 +277,6 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     P.class_list = s->d_class_list;
     P.class_count = s->d_work + 4;  // d_work: [0..1] work counters, [4..6] class counts
   }
-  // The block costs of the previous launch are a valid forecast when that
-  // launch had the same geometry and engine (an animation frame,
-  // main_local.cc:79-110, or a repeated benchmark step).  Then the blocks are
-  // handed out longest first, the longest in pieces.  Otherwise: the state
-  // machine classifies the blocks by material in a launch of its own
-  // (primary_kernel); the ray pool forecasts from 1/64 of the primary rays
-  // (probe_kernel).
-  unsigned long long sig = 1469598103934665603ull;
-  {
-    const long long key[] = {image_w, image_h, rx, ry, rw, rh, tile_w, tile_h, first_tile, tile_stride,
-                             n_tiles, max_depth, (long long)(size_t)s->d_item_cost, s->dev.n_lights, engine};
-    for (long long v : key) {
-      sig = (sig ^ (unsigned long long)v) * 1099511628211ull;
-    }
-    if (sig == 0) sig = 1;
-  }
-  const bool history = s->use_history && s->cost_signature == sig && (pool_engine || d_debug == nullptr);
-  P.from_primary = history ? 0 : 1;
   P.item_cycles = nullptr;
   unsigned long long *d_item = nullptr;
   const char *item_dump = getenv("MT_DEBUG_ITEM_CYCLES");
@@ -301,18 +305,20 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   }
   if (pool_engine) {
     if (!history) {
-      hipLaunchKernelGGL(probe_kernel, dim3((P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream,
+      hipLaunchKernelGGL(probe_kernel, dim3((4 * P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream,
                          s->dev, P);
       HIP_TRY(hipGetLastError());
     }
     // blocks above cut_share of an even split of the frame are handed out in pieces
-    SchedParams sp{1.0f, {1.0f, 0.35f, 0.12f}, {1.0f, 1.1f, 3.0f}, 3.0f};
+    SchedParams sp{history ? 1.0f : 0.3f, {1.0f, 0.35f, 0.12f}, {1.0f, 1.1f, 3.0f}, 3.0f,
+                   (!history || s->last_engine == 2) ? 1 : 0};  // a forecast is cut more eagerly
     if (const char *e = getenv("MT_DEBUG_CUT_SHARE")) sp.cut_share = (float)atof(e);
     if (const char *e = getenv("MT_DEBUG_PIECE_TIME")) sscanf(e, "%f,%f", &sp.piece_time[1], &sp.piece_time[2]);
     if (const char *e = getenv("MT_DEBUG_PIECE_WORK")) sscanf(e, "%f,%f", &sp.piece_work[1], &sp.piece_work[2]);
     if (const char *e = getenv("MT_DEBUG_CELL_FACTOR")) sp.cell_factor = (float)atof(e);
     hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
-                       reproject, radius, 1, sp.piece_work[1], sp.piece_work[2], 16000u);
+                       reproject, radius, (history && s->last_engine == 1) ? 0 : 1,
+                       (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u);
     hipLaunchKernelGGL(pool_schedule_kernel, dim3(1), dim3(kPoolSchedThreads), 0, stream, P,
                        s->grid_blocks * s->waves_per_block, sp);
     HIP_TRY(hipGetLastError());
@@ -327,7 +333,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       float quad_share = 0.8f;  // blocks above this share of an even split are cut into quarters
       if (const char *e = getenv("MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
       hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
-                         reproject, radius, 0, 1.7f, 1.0f, 16000u);
+                         reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : 1.7f, 3.0f, 16000u);
       hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
                          s->grid_blocks * s->waves_per_block, quad_share);
     } else if (s->stats_enabled) {

@@ -136,20 +136,26 @@ __device__ __forceinline__ void pool_flush_item_stats(LaneStats &st, unsigned lo
 
 // ---------------------------------------------------------------------------
 // Cost forecast for a launch without history (first frame of a geometry): the
-// primary ray of ONE pixel per 8x8 block is traced (1/64 of the primary rays)
-// and the block is weighted by the material it sees -- reflective and
+// primary rays of FOUR pixels per 8x8 block are traced (1/16 of the primary
+// rays; a lane per sample, so a wave probes 16 blocks) and the block is
+// weighted by the most expensive material they see -- reflective and
 // transparent surfaces start recursions -- so that pool_schedule_kernel can hand
-// out the blocks that are probably long first.  The forecast only orders the
-// work; nothing computed for a pixel depends on it.
+// out the blocks that are probably long first and in pieces.  (One sample per
+// block misses the rims of the glass spheres: those blocks then run late and
+// whole, and the first frame took 21 ms instead of 14.)  The forecast only
+// orders the work; nothing computed for a pixel depends on it.
 __global__ __launch_bounds__(256, 3) void probe_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
   stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
-  const unsigned item = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned sample = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned item = sample >> 2;
+  const int which = (int)(sample & 3u);
   const bool have = item < P.n_items;
-  PoolGeom g = pool_geometry(P, have ? item : 0u, -1, 27);  // pixel (3, 3) of the block
+  // pixels (1,1), (5,1), (1,5), (5,5) of the block; (0,0) where those fall off a clipped tile
+  PoolGeom g = pool_geometry(P, have ? item : 0u, -1, (1 + 4 * (which & 1)) + 8 * (1 + 4 * (which >> 1)));
   if (!g.inside) g = pool_geometry(P, have ? item : 0u, -1, 0);
   const bool want = have && g.inside;
   const V3 cam_origin = v3_load(P.sensor.origin);
@@ -162,24 +168,28 @@ __global__ __launch_bounds__(256, 3) void probe_kernel(DevScene S, RenderParams 
   const TraceOut to = trace_wave<false>(S.self, stk.base, lane, want, cam_origin.x, cam_origin.y, cam_origin.z,
                                         rd.x, rd.y, rd.z);
   if (to.status != DEV_OK && lane == 0) atomicMax(P.counters + ST_STATUS, (unsigned long long)to.status);
-  if (have) {
-    // Forecast in the unit of the measured costs (64 s_memtime ticks): passes
-    // the block will need x what such a pass costs on this kind of surface
-    // (coherent shadow rays ~0.25 M ticks a pass; rays mirrored or refracted by
-    // curved surfaces are incoherent, ~0.4 M and ~0.8 M).
-    unsigned cost = 4000u;  // one pass: the primary rays
-    if (want && to.prim >= 0) {
+  // Forecast in the unit of the measured costs (64 s_memtime ticks): passes
+  // the block will need x what such a pass costs on this kind of surface
+  // (coherent shadow rays ~0.25 M ticks a pass; rays mirrored or refracted by
+  // curved surfaces are incoherent, ~0.4 M and ~0.8 M).
+  unsigned cost = 0u;
+  if (want) {
+    cost = 4000u;  // one pass: the primary rays
+    if (to.prim >= 0) {
       const int m = S.tri_mtl[to.prim];
       if (m >= 0) {
         const mt_material *mm = S.mtls + m;
         const unsigned per_level = 1u + (unsigned)S.n_lights;
-        if (mm->transparency > 0.0) cost = 12500u * per_level * (unsigned)(P.max_depth + 1) * 2u;
-        else if (mm->reflectance > 0.0) cost = 6250u * per_level * (unsigned)(P.max_depth + 1);
+        if (mm->transparency > 0.0) cost = 25000u * per_level * (unsigned)(P.max_depth + 1) * 2u;
+        else if (mm->reflectance > 0.0) cost = 25000u * per_level * (unsigned)(P.max_depth + 1);
         else cost = 4000u * per_level;
       }
     }
-    P.item_cost[item] = want ? cost : 0u;
   }
+  // the block's forecast = the largest of its four samples (they sit in four adjacent lanes)
+  cost = max(cost, (unsigned)__builtin_amdgcn_update_dpp(0, (int)cost, 0xb1, 0xf, 0xf, false));  // quad_perm 1,0,3,2
+  cost = max(cost, (unsigned)__builtin_amdgcn_update_dpp(0, (int)cost, 0x4e, 0xf, 0xf, false));  // quad_perm 2,3,0,1
+  if (have && which == 0) P.item_cost[item] = cost;
 }
 
 // ---------------------------------------------------------------------------
@@ -211,10 +221,11 @@ struct SchedParams {
   float piece_time[3];  // expected time of ONE unit relative to the whole block, per granularity
   float piece_work[3];  // measured cost of all pieces of a block relative to the whole block
   float cell_factor;    // quarters above cell_factor x the threshold are cut again
+  int own_costs;        // 1: the cost words were written by this engine (granularity in bits 30-31)
 };
 __device__ __forceinline__ void sched_decide(unsigned word, unsigned forecast, float cut_above, const SchedParams &sp,
                                              int &level, unsigned &unit_cost) {
-  const int was = (int)(word >> 30);
+  const int was = sp.own_costs ? (int)(word >> 30) : 0;
   const float c = (float)forecast;  // as a whole block (forecast_kernel)
   const float thr = was > 0 ? 0.7f * cut_above : cut_above;
   // 2x2 cells (level 2) only for blocks whose QUARTERS would each exceed the
