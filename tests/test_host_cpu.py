@@ -362,6 +362,85 @@ def test_texture_loaders(tmp_path):
         assert M.MythTracer().load_obj(str(tmp_path / "m.obj")) == ok, name
 
 
+def _png(w, h, ctype, pixels, filters, level, palette=None, idat_split=None):
+    """A PNG written by hand: per-row filter types as given, zlib level as given
+    (0 = stored blocks, 1 = fixed Huffman for small inputs, 9 = dynamic)."""
+    import struct, zlib
+    channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    rows = pixels.reshape(h, w * channels).astype(np.int32)
+    raw = bytearray()
+    prev = np.zeros(w * channels, dtype=np.int32)
+    for y in range(h):
+        cur = rows[y]
+        ft = filters[y % len(filters)]
+        left = np.concatenate([np.zeros(channels, dtype=np.int32), cur[:-channels]])
+        upleft = np.concatenate([np.zeros(channels, dtype=np.int32), prev[:-channels]])
+        if ft == 0: pred = 0
+        elif ft == 1: pred = left
+        elif ft == 2: pred = prev
+        elif ft == 3: pred = (left + prev) >> 1
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        raw.append(ft)
+        raw += bytes(((cur - pred) & 255).astype(np.uint8))
+        prev = cur
+    z = zlib.compress(bytes(raw), level)
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(palette.astype(np.uint8).reshape(-1)))
+    parts = [z] if not idat_split else [z[:idat_split], z[idat_split:]]
+    for part in parts:
+        out += chunk(b"IDAT", part)
+    return out + chunk(b"IEND", b"")
+
+
+def test_png_textures(tmp_path):
+    """PNG decoding (own inflate + unfilter): every supported colour type, all
+    five scanline filters, stored / fixed / dynamic deflate blocks, IDAT split
+    over two chunks; texels = byte / 255.0 of the RGB(A) image, alpha dropped,
+    grey replicated, palette looked up -- what SDL's RGBA32 conversion gives
+    (texture.cc:88-104).  Damaged files are refused."""
+    rnd = np.random.RandomState(7)
+    w, h = 13, 9
+    pal = rnd.randint(0, 256, size=(17, 3))
+    cases = []
+    for ctype, ch in ((2, 3), (6, 4), (0, 1), (4, 2), (3, 1)):
+        px = rnd.randint(0, 17 if ctype == 3 else 256, size=(h, w, ch))
+        # smooth images too: long matches and dynamic Huffman trees
+        smooth = ((np.add.outer(np.arange(h), np.arange(w))[:, :, None] * 3 + np.arange(ch)) % (17 if ctype == 3 else 256))
+        for name, img, filters, level, split in ((f"t{ctype}_noise_f0", px, [0], 0, None),
+                                                 (f"t{ctype}_noise_all", px, [0, 1, 2, 3, 4], 9, 40),
+                                                 (f"t{ctype}_smooth_all", smooth, [4, 3, 2, 1, 0], 9, None),
+                                                 (f"t{ctype}_smooth_f1", smooth, [1], 1, None)):
+            blob = _png(w, h, ctype, img, filters, level, palette=pal if ctype == 3 else None, idat_split=split)
+            if ctype in (2, 6):
+                rgb = img[:, :, :3]
+            elif ctype == 3:
+                rgb = pal[img[:, :, 0]]
+            else:
+                rgb = np.repeat(img[:, :, :1], 3, axis=2)
+            cases.append((name + ".png", blob, rgb.astype(np.uint8)))
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nusemtl a\nf 1/1 2/1 3/1 \n")
+    for name, blob, rgb in cases:
+        (tmp_path / name).write_bytes(blob)
+        (tmp_path / "m.mtl").write_text("newmtl a\nKa 1 1 1\nmap_Ka %s\n" % name)
+        m = M.MythTracer(str(tmp_path / "m.obj"))
+        tex = m.flatten()["textures"][0]["texels"]
+        assert tex.dtype == np.uint8 and np.array_equal(tex, rgb), name
+    good = cases[1][1]
+    bad = {"truncated.png": good[:len(good) // 2], "bad_adler.png": good.replace(good[-20:-16], b"\0\0\0\0", 1),
+           "interlaced.png": good[:28] + b"\x01" + good[29:], "depth16.png": good[:24] + b"\x10" + good[25:]}
+    for name, blob in bad.items():
+        (tmp_path / name).write_bytes(blob)
+        (tmp_path / "m.mtl").write_text("newmtl a\nKa 1 1 1\nmap_Ka %s\n" % name)
+        assert not M.MythTracer().load_obj(str(tmp_path / "m.obj")), name
+
+
 def test_wire_formats():
     """WorkChunk / Camera (de)serialisation, mythtracer.cc:314-429, camera.cc:71-96."""
     L = M.host_lib()
