@@ -203,16 +203,35 @@ def main():
         step()
     fence()
     abi.read_stats(h)              # drop warm-up counts
-    abi.kernel_times(h)            # ... and warm-up kernel durations
+    # One untimed frame WITH the work counters gives the frame's ray counts and
+    # requested bytes (they are the same for every step: the frame is the same);
+    # the timed steps then run the kernels built without the counters
+    # (mt_scene_set_stats: about 7 % of a frame goes into counting).
+    step()
+    fence()
+    counters = abi.read_stats(h)   # this rank, one frame
+    abi.set_stats(h, False)
+    step()                         # first launch of the counter-free kernels
+    fence()
+    abi.kernel_times(h)            # drop the durations so far
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
-    counters = abi.read_stats(h)   # this rank, all timed steps
     # per-kernel device durations of the timed steps: HIP events the library
     # records on the launch stream around each of its kernels (at most the last 64)
     k_order, k_frame = abi.kernel_times(h, 64)
+    abi.set_stats(h, True)
+    # the same, counters on, for comparison (16 steps)
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(16):
+        step()
+    fence()
+    elapsed_counting = (time.perf_counter() - t1) / 16.0
+    abi.read_stats(h)
+    abi.kernel_times(h)
 
     keys = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests", "node_visits",
             "tri_tests", "mt_tests", "shaded_hits", "wave_node_steps", "wave_tri_steps",
@@ -230,8 +249,8 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-    tot = {k: int(v) for k, v in zip(keys, vec.tolist())}
-    per_frame = {k: v // max(args.steps, 1) for k, v in tot.items()}
+    per_frame = {k: int(v) for k, v in zip(keys, vec.tolist())}   # all ranks, one frame
+    tot = {k: v * args.steps for k, v in per_frame.items()}
     rays = tot["rays_primary"] + tot["rays_secondary"] + tot["rays_shadow"]
     mismatch = False
 
@@ -316,6 +335,9 @@ def main():
                                  "the other regimes)",
                        "scene_sha256": info["sha256"]},
             "frame_ms_wall": elapsed / max(args.steps, 1) * 1e3,
+            "frame_ms_wall_with_work_counters": elapsed_counting * 1e3,
+            "work_counters": "off in the timed steps (mt_scene_set_stats(scene, 0)); ray counts and requested bytes "
+                             "are those of one untimed frame of the same workload rendered with the counters on",
             "render_ms_device": k_step_ms,
             "rays_per_frame": {k: per_frame[k] for k in RAY_KEYS},
             "Mray_s_primary_plus_shadow": (tot["rays_primary"] + tot["rays_shadow"]) / elapsed / 1e6,

@@ -197,6 +197,13 @@ int mt_blit_tiles_device(mt_scene *scene, int image_w, int image_h,
 /* Fetches and clears the accumulated counters (kernel_ms/total_ms = 0). */
 int mt_scene_read_stats(mt_scene *scene, mt_stats *stats);
 
+/* Work counters of the *_device calls: 1 (default) = the kernels count rays,
+ * node visits, box tests, requested bytes ... as they go (about 7 % of a
+ * frame's time: one LDS atomic per counter and node visit); 0 = kernels built
+ * without the counters (mt_scene_read_stats then returns zeros).  The image is
+ * the same either way.  mt_render_chunk with a stats pointer always counts. */
+int mt_scene_set_stats(mt_scene *scene, int enabled);
+
 /* Work scheduling.  use_cost_history = 1 (default): a launch with the same
  * geometry as the previous one (image, region, tiling, recursion depth, light
  * count) hands out its 8x8-pixel blocks in the order of the costs measured in

@@ -21,6 +21,7 @@ HIP_SYMBOLS = [
     "mt_render_chunk_device", "mt_render_tiles_device", "mt_blit_tiles_device",
     "mt_scene_read_stats", "mt_intersect_rays", "mt_scene_set_traversal_mode",
     "mt_scene_kernel_times", "mt_scene_set_scheduling", "mt_scene_set_engine",
+    "mt_scene_set_stats",
 ]
 
 STAT_NAMES = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests",
@@ -126,6 +127,7 @@ class HipAbi:
         L.mt_scene_set_scheduling.argtypes = [vp, ci]
         if hasattr(L, "mt_scene_set_engine"):  # absent from older builds loaded by the A/B scripts
             L.mt_scene_set_engine.argtypes = [vp, ci]
+            L.mt_scene_set_stats.argtypes = [vp, ci]
 
     def last_error(self) -> str:
         return self.lib.mt_last_error().decode(errors="replace")
@@ -251,6 +253,10 @@ class HipAbi:
         st = mt_stats()
         self.check(self.lib.mt_scene_read_stats(h, C.byref(st)))
         return st.as_dict()
+
+    def set_stats(self, h, enabled: bool):
+        """Work counters of the *_device calls on (default) or off."""
+        self.check(self.lib.mt_scene_set_stats(h, 1 if enabled else 0))
 
     def set_engine(self, h, engine: int):
         """0 = automatic, 1 = throughput engine (state machine), 2 = latency engine (ray pool)."""

@@ -754,6 +754,12 @@ int mt_scene_set_scheduling(mt_scene *s, int use_cost_history) {
   return MT_OK;
 }
 
+int mt_scene_set_stats(mt_scene *s, int enabled) {
+  if (!s || (enabled != 0 && enabled != 1)) return fail(MT_ERR_ARG, "bad stats argument");
+  s->stats_enabled = enabled != 0;
+  return MT_OK;
+}
+
 int mt_scene_set_engine(mt_scene *s, int engine) {
   if (!s || engine < 0 || engine > 2) return fail(MT_ERR_ARG, "engine must be 0 (automatic), 1 or 2");
   s->engine = engine;
@@ -888,8 +894,11 @@ int mt_render_chunk(mt_scene *s, const mt_sensor *sensor, int image_w, int image
   }
   HIP_TRY(hipMemset(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long)));
   HIP_TRY(hipEventRecord(s->ev0, nullptr));
+  const bool counters_were = s->stats_enabled;
+  if (stats) s->stats_enabled = true;  // the caller asked for them
   rc = mt_render_chunk_device(s, sensor, image_w, image_h, chunk_x, chunk_y, chunk_w, chunk_h,
                               max_depth, s->d_rgb, out_debug ? s->d_debug : nullptr, nullptr);
+  s->stats_enabled = counters_were;
   if (rc != MT_OK) return rc;
   HIP_TRY(hipEventRecord(s->ev1, nullptr));
   HIP_TRY(hipMemcpy(out_rgb, s->d_rgb, npx * 3, hipMemcpyDeviceToHost));

@@ -1,10 +1,12 @@
 """Summarises gpurun_out/prof_<tag>/ (scripts/pmc_passes.sh) per kernel.
 
-bench.py --steps 4 --warmup 2 --no-extras launches mt::render_kernel six times:
-warm-up 1 (no cost history yet: primary_kernel + render_kernel), warm-up 2 and
-the four timed steps (forecast_kernel + schedule_kernel + render_kernel).
-Figures below are means over the four TIMED launches (dispatches 3..6 of
-render_kernel in launch order); the other launches are listed for reference.
+bench.py --steps 4 --warmup 2 --no-extras launches, in this order: warm-up 1 (no
+cost history: probe + pool_kernel<true>), warm-up 2 and the counting frame
+(render_kernel<true>), then the kernels built WITHOUT the work counters: one
+first launch and the four timed steps (render_kernel<false>), then 16 more frames
+with the counters.  Figures below are means over the four TIMED launches =
+launches 2..5 of render_kernel<false>; the other launches are listed for
+reference.
 With a second argument the derived figures are also written as JSON (the entry
 bench.py reads from profiles/hbm_traffic.json).
 
@@ -13,7 +15,8 @@ import csv, glob, os, sys, collections
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-TIMED = slice(2, 6)
+TIMED = slice(1, 5)   # of render_kernel<false>
+FRAME_KERNEL = "render_kernel<false>"
 
 
 def by_kernel(rows, value):
@@ -38,9 +41,9 @@ for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         continue
     print("  %s" % k[:70])
     print("     all launches: %s" % " ".join("%.3f" % x for x in v))
-    if "render_kernel" in k and len(v) >= 6:
+    if FRAME_KERNEL in k and len(v) >= 5:
         t = v[TIMED]
-        print("     timed launches (3..6): mean %.3f  min %.3f  max %.3f" % (sum(t) / len(t), min(t), max(t)))
+        print("     timed launches (2..5): mean %.3f  min %.3f  max %.3f" % (sum(t) / len(t), min(t), max(t)))
 cnt = collections.defaultdict(dict)
 for f in sorted(glob.glob(os.path.join(base, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
     rows = list(csv.DictReader(open(f)))
@@ -49,12 +52,12 @@ for f in sorted(glob.glob(os.path.join(base, "pmc*", "**", "*counter_collection.
         for k, v in per.items():
             cnt[k][c] = v
 for k in cnt:
-    if "render_kernel" not in k:
+    if FRAME_KERNEL not in k:
         continue
-    print("\ncounters of %s, mean over the timed launches (3..6)" % k[:60])
+    print("\ncounters of %s, mean over the timed launches (2..5)" % k[:60])
     m = {}
     for c, v in sorted(cnt[k].items()):
-        t = v[TIMED] if len(v) >= 6 else v
+        t = v[TIMED] if len(v) >= 5 else v
         m[c] = sum(t) / len(t)
         print("  %-26s %.6g" % (c, m[c]))
     if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
@@ -76,7 +79,7 @@ for k in cnt:
                                       "s_waitcnt": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
                                       "issue_stalled": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"]}
     t = dur.get(k)
-    if t and len(t) >= 6 and "SQ_ACTIVE_INST_VALU" in m:
+    if t and len(t) >= 5 and "SQ_ACTIVE_INST_VALU" in m:
         ms = sum(t[TIMED]) / len(t[TIMED])
         # SQ_ACTIVE_INST_VALU counts quad-cycles (4 shader cycles); 1024 SIMDs; the clock is
         # GRBM_GUI_ACTIVE / 8 XCDs / duration (MI355X_MICROARCH.md, DVFS section)
