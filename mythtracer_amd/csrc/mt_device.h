@@ -148,7 +148,11 @@ struct RenderParams {
 // ones when a node index and a triangle index fit one word together
 // (DevScene::pack_shift != 0), plus five per-lane work counters.
 __host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
-  return (size_t)depth * 64 * (packed ? 16 : 20) + 5 * 64 * 4;
+  size_t n = (size_t)depth * 64 * (packed ? 16 : 20) + 5 * 64 * 4;
+#ifdef MT_VEC_SCAN
+  n += 64 * 32;  // staging area of the vector-load scan: 64 boxes of 8 floats
+#endif
+  return n;
 }
 
 constexpr int kFrameSlots = 11;  // throughput engine: 10 doubles + 1 packed meta word per recursion frame

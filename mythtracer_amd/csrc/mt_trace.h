@@ -877,8 +877,19 @@ template <int MODE>
 // for the children some lane enters.
 __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, const RayRegs &r,
                                                    unsigned keep = 0xffu, unsigned um = 0xffu,
-                                                   const float *sub = nullptr, const Filter32 *f = nullptr) {
+                                                   const float *sub = nullptr, const Filter32 *f = nullptr,
+                                                   bool preload = false) {
   constexpr bool EX = (MODE == 0);
+  // preload (wave-uniform node, MT_PRELOAD_SUB): the eight subtree boxes are
+  // fetched together up front -- one round trip instead of one per entered child
+  float sbox[48];
+  if constexpr (!EX) {
+    if (preload && sub != nullptr) {
+      const MT_CONST float *sp = as_const(sub);
+#pragma unroll
+      for (int i = 0; i < 48; i++) sbox[i] = sp[i];
+    }
+  }
   double xmin[2], xmax[2], ymin[2], ymax[2], zmin[2], zmax[2];
   {
     const double t0 = (N->lo[0] - r.ox) * r.ix, tc = (N->c[0] - r.ox) * r.ix,
@@ -918,7 +929,7 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
     if constexpr (!EX) {
       if (sub != nullptr) {
         if (__ballot(valid[c]) != 0ull) {
-          valid[c] = valid[c] && subtree_may_hit(sub + c * 6, *f, __builtin_signbit(r.ix),
+          valid[c] = valid[c] && subtree_may_hit(preload ? sbox + c * 6 : sub + c * 6, *f, __builtin_signbit(r.ix),
                                                  __builtin_signbit(r.iy), __builtin_signbit(r.iz));
         }
       }
@@ -1228,6 +1239,11 @@ __device__ __forceinline__ unsigned order_children_regular(const NodeRec *N, con
       }
     }
   }
+#ifdef MT_PRELOAD_SUB
+  if (uniform_node) {
+    return order_children<1>(as_const(uniform_ptr(N)), r, keep, um, sub == nullptr ? nullptr : uniform_ptr(sub), &f, true);
+  }
+#endif
   return order_children<1>(as_const(uniform_node ? uniform_ptr(N) : N), r, keep, um,
                            sub == nullptr ? nullptr : (uniform_node ? uniform_ptr(sub) : sub), &f);
 }
@@ -1442,9 +1458,14 @@ constexpr bool kVecScan = false;  // experimental: slower than t
 // test, Möller–Trumbore for the survivors in stream order.
 // Must be called by ALL 64 lanes (`in` = lanes that want this node).
 template <bool STATS>
-__device__ __forceinline__ ScanOut scan_big_vec(const DevScene &S, int lane, int pb, int pc, bool in,
+__device__ __forceinline__ ScanOut scan_big_vec(const DevScene &S, unsigned stage_off, int lane, int pb, int pc, bool in,
                                                 const RayRegs &r, const Filter32 &f, bool one_octant,
                                                 int sx, int sy, int sz) {
+  // The 64 boxes a step works on are STAGED IN LDS (8 floats per box) and read
+  // back with two wave-uniform ds_read_b128 per box: every lane gets the same
+  // box as vector operands -- no v_readlane, no scalar registers.
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  MT_LDS f4v *const stage = (MT_LDS f4v *)(uintptr_t)stage_off;
   ScanOut o{-1, 0.0, 0u};
   LaneStats st;
   st.clear();
@@ -1456,9 +1477,13 @@ __device__ __forceinline__ ScanOut scan_big_vec(const DevScene &S, int lane, int
   const float *gp = S.grp_aabb32 + (size_t)b0 * 6;
   // fp32 verdict of all rays for the box held by lane j of (n0..f2): planes as
   // (near xyz, far xyz) when one_octant, else (min xyz, max xyz)
-  auto verdict = [&](float n0, float n1, float n2, float f0, float f1, float f2, int j) -> unsigned long long {
-    const float b[6] = {readlane_f32(n0, j), readlane_f32(n1, j), readlane_f32(n2, j),
-                        readlane_f32(f0, j), readlane_f32(f1, j), readlane_f32(f2, j)};
+  auto put = [&](float n0, float n1, float n2, float f0, float f1, float f2) {
+    stage[lane * 2 + 0] = f4v{n0, n1, n2, f0};
+    stage[lane * 2 + 1] = f4v{f1, f2, 0.0f, 0.0f};
+  };
+  auto verdict = [&](int j) -> unsigned long long {
+    const f4v a = stage[j * 2 + 0], c = stage[j * 2 + 1];
+    const float b[6] = {a.x, a.y, a.z, a.w, c.x, c.y};
     return (one_octant ? filter32_pass<0>(b, f) : filter32_pass<8>(b, f)) & inmask;
   };
   for (int g0 = 0; g0 < nb; g0 += 64) {
@@ -1470,8 +1495,9 @@ __device__ __forceinline__ ScanOut scan_big_vec(const DevScene &S, int lane, int
       const float n0 = (one_octant && sx) ? x1 : x0, f0 = (one_octant && sx) ? x0 : x1;
       const float n1 = (one_octant && sy) ? y1 : y0, f1 = (one_octant && sy) ? y0 : y1;
       const float n2 = (one_octant && sz) ? z1 : z0, f2 = (one_octant && sz) ? z0 : z1;
+      put(n0, n1, n2, f0, f1, f2);
       for (int j = 0; j < n; j++) {
-        if (verdict(n0, n1, n2, f0, f1, f2, j) != 0ull) live |= 1ull << j;
+        if (verdict(j) != 0ull) live |= 1ull << j;
       }
     }
 #ifdef MT_PROF
@@ -1499,6 +1525,7 @@ __device__ __forceinline__ ScanOut scan_big_vec(const DevScene &S, int lane, int
       const float n0 = (one_octant && sx) ? x1 : x0, f0 = (one_octant && sx) ? x0 : x1;
       const float n1 = (one_octant && sy) ? y1 : y0, f1 = (one_octant && sy) ? y0 : y1;
       const float n2 = (one_octant && sz) ? z1 : z0, f2 = (one_octant && sz) ? z0 : z1;
+      put(n0, n1, n2, f0, f1, f2);
       unsigned long long todo = __builtin_amdgcn_ballot_w64(ok);  // ascending lane = ascending stream position
 #ifdef MT_PROF
       o.n_ranges++;
@@ -1507,7 +1534,7 @@ __device__ __forceinline__ ScanOut scan_big_vec(const DevScene &S, int lane, int
       while (todo != 0ull) {
         const int j = __builtin_ctzll(todo);
         todo &= todo - 1;
-        const unsigned long long m = verdict(n0, n1, n2, f0, f1, f2, j);
+        const unsigned long long m = verdict(j);
         if (m == 0ull) continue;
         // exact fp64 test (primitive_triangle.cc:83-108) for the rays the filter let through
         const int tj = __builtin_amdgcn_readlane(tri_c, j);
@@ -1688,6 +1715,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   // not in registers: four ds_add per node step instead of four live VGPRs
   MT_LDS unsigned *const cnt = (MT_LDS unsigned *)(uintptr_t)(stk.base + (unsigned)stk.depth * 64u * stk.frame_bytes());
   const int pack_shift = stk.pack_shift;  // wave-uniform
+  const unsigned stage_off = stk.base + (unsigned)stk.depth * 64u * stk.frame_bytes() + 5u * 64u * 4u;  // MT_VEC_SCAN only
+  (void)stage_off;
   if (STATS) {
     cnt[0 * 64 + lane] = 0; cnt[1 * 64 + lane] = 0; cnt[2 * 64 + lane] = 0; cnt[3 * 64 + lane] = 0;
     cnt[4 * 64 + lane] = 0;
@@ -1949,7 +1978,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
 #endif
       ScanOut o{-1, 0.0, 0u};
       if constexpr (kVecScan) {
-        if (vec_scan) o = scan_big_vec<STATS>(S, lane, pb, pc, in, r, f32, mode == 2, sx, sy, sz);
+        if (vec_scan) o = scan_big_vec<STATS>(S, stage_off, lane, pb, pc, in, r, f32, mode == 2, sx, sy, sz);
       }
       if (vec_scan) {
       } else if (transposed) {
@@ -2120,7 +2149,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     if (vec_scan) diag_vec++;
 #endif
     if constexpr (kVecScan) if (vec_scan) {
-      const ScanOut o = scan_big_vec<STATS>(S, lane, pb, pc, in, r, f32, mode == 2, sx, sy, sz);
+      const ScanOut o = scan_big_vec<STATS>(S, stage_off, lane, pb, pc, in, r, f32, mode == 2, sx, sy, sz);
       best = o.best;
       best_t = o.best_t;
       if (STATS && in && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
