@@ -247,6 +247,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     const long long all = 64ll * ((2ll << max_depth) - 1);
     const long long floor_cap = 64 + 128 + 4ll * (max_depth + 1) + 64;
     long long cap = all < kPoolCapMax ? all : kPoolCapMax;
+    if (const char *e = getenv("MT_DEBUG_POOL_CAP")) cap = atoll(e);  // tests: force the depth-first throttle
     if (cap < floor_cap) cap = floor_cap;
     const size_t rec_bytes = (size_t)(kRecFixed + kLightSlot * n_l) * sizeof(double);
     size_t stride = (size_t)cap * rec_bytes + (size_t)cap * (size_t)(n_l > 0 ? n_l : 1) * 4 + (size_t)cap * 4;

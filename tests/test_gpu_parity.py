@@ -725,3 +725,98 @@ def test_seam_driver_like_main_local(scenes, tmp_path):
     img, _ = run(scenes["room"], W, H, view["cam"], view["lights"])
     assert_rgb_close(img, view["rgb"], "seam driver, room_view_back")
     assert np.array_equal(img, view["rgb"])
+
+
+@pytest.mark.parametrize("pool_cap", [None, 1])
+def test_binary_recursion_trees_fill_the_ray_pool(pool_cap, monkeypatch):
+    """A material that is reflective AND transparent makes every hit spawn two
+    child calls (mythtracer.cc:181-189 and :192-225): at depth 7 a pixel's
+    recursion tree has up to 255 calls, a block's 16 320 -- far beyond the ray
+    pool's 1 024 records per wave, so its depth-first throttle has to work; the
+    state machine walks the same trees with its frame stack.  Pixels, debug
+    buffer and every ray count must equal the oracle's.  pool_cap = 1: the pool
+    is cut down to its minimum (MT_DEBUG_POOL_CAP), so that it throttles all
+    the time."""
+    if pool_cap is not None:
+        monkeypatch.setenv("MT_DEBUG_POOL_CAP", str(pool_cap))
+    m, o = _both()
+    for s in (m, o):
+        s.add_material("both", (.1, .1, .1), (.3, .3, .3), (.4, .4, .4), ns=20, refl=0.8, tr=0.7, tf=(.9, .8, .7), ni=1.3)
+        s.add_material("wall", (.6, .5, .4), (.6, .5, .4), (.1, .1, .1), ns=4)
+        k = 0
+        for i, z in enumerate([10, 14, 18, 22, 26, 30]):  # panes facing the camera, normals towards it
+            n = [[0, 0, -1]] * 3
+            w = 12 - i
+            s.add_triangle([[-w, -w, z], [w, -w, z], [-w, w, z]], n, mtl=0, line_no=k); k += 1
+            s.add_triangle([[w, w, z], [-w, w, z], [w, -w, z]], n, mtl=0, line_no=k); k += 1
+        n = [[0, 0, -1]] * 3
+        s.add_triangle([[-40, -40, 40], [40, -40, 40], [-40, 40, 40]], n, mtl=1, line_no=k); k += 1
+        s.add_triangle([[40, 40, 40], [-40, 40, 40], [40, -40, 40]], n, mtl=1, line_no=k); k += 1
+        n = [[0, 0, 1]] * 3  # a wall behind the camera catches the mirrored rays
+        s.add_triangle([[-40, -40, -20], [40, -40, -20], [-40, 40, -20]], n, mtl=1, line_no=k); k += 1
+        s.add_triangle([[40, 40, -20], [-40, 40, -20], [40, -40, -20]], n, mtl=1, line_no=k); k += 1
+    lights = [(0, 30, -10, .1, .1, .1, .9, .9, .9, .5, .5, .5), (-20, -5, 5, 0, 0, 0, .4, .4, .4, .2, .2, .2)]
+    for depth in (5, 7):
+        m.set_max_level(depth)
+        m.set_lights(lights)
+        o.set_lights(lights)
+        g = m.render((0, 0, -5, 0, 0, 0, 70), 64, 48, debug=True)
+        r = o.render((0, 0, -5, 0, 0, 0, 70), 64, 48, max_level=depth, debug=True)
+        counters_match(g["counters"], r["counters"])
+        assert np.array_equal(g["line"], r["line"])
+        assert_rgb_close(g["rgb"], r["rgb"], "binary recursion, depth %d" % depth)
+        assert g["counters"]["rays_secondary"] > 20 * 64 * 48 * 0.2  # the trees really branch
+
+
+def test_moving_camera_uses_reprojected_costs(scenes):
+    """The animation regime (main_local.cc:51-76: yaw += 2 degrees per frame):
+    from the second frame on the work order comes from the previous frame's
+    costs, re-projected through the camera change (forecast_kernel) -- also with
+    a translation and a roll.  The order must not change a pixel: every frame
+    equals the oracle's."""
+    m = M.MythTracer(scenes["room"])
+    o = orclib.OracleScene(scenes["room"])
+    m.set_lights(scenegen.ROOM_LIGHTS)
+    o.set_lights(scenegen.ROOM_LIGHTS)
+    W, H = 320, 180
+    cam = list(scenegen.ROOM_CAMERA)
+    for f in range(5):
+        g = m.render(cam, W, H, debug=True)
+        r = o.render(cam, W, H, debug=True)
+        assert np.array_equal(g["line"], r["line"]), f
+        assert_rgb_close(g["rgb"], r["rgb"], "moving camera, frame %d" % f)
+        counters_match(g["counters"], r["counters"])
+        cam[4] += 2.0           # yaw
+        if f >= 2:
+            cam[0] += 7.0       # then the camera also walks and rolls
+            cam[5] += 3.0
+
+
+def test_work_counters_can_be_switched_off(scenes):
+    """mt_scene_set_stats(scene, 0): the *_device calls run the kernels built
+    without the work counters; same frame, counters stay zero."""
+    import torch
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["mini"])
+    h = abi.scene_create(m.flatten())
+    try:
+        abi.set_lights(h, scenegen.ROOM_LIGHTS)
+        sens = binding.sensor(scenegen.ROOM_CAMERA, 200, 112)
+        want = abi.render_chunk(h, sens, 200, 112)
+        buf = torch.zeros((112, 200, 3), dtype=torch.uint8, device="cuda")
+        abi.read_stats(h)
+        for enabled in (False, True):
+            abi.set_stats(h, enabled)
+            buf.zero_()
+            abi.render_chunk_device(h, sens, 200, 112, (0, 0, 200, 112), 5, ctypes.c_void_p(buf.data_ptr()))
+            torch.cuda.synchronize()
+            st = abi.read_stats(h)
+            assert np.array_equal(buf.cpu().numpy(), want["rgb"]), enabled
+            rays = sum(st[k] for k in RAY_KEYS)
+            assert rays == (sum(want["stats"][k] for k in RAY_KEYS) if enabled else 0), enabled
+        # a host call that asks for statistics counts whatever the switch says
+        abi.set_stats(h, False)
+        again = abi.render_chunk(h, sens, 200, 112)
+        assert {k: again["stats"][k] for k in ALL_KEYS} == {k: want["stats"][k] for k in ALL_KEYS}
+    finally:
+        abi.scene_destroy(h)
