@@ -5,6 +5,13 @@
 #include <stdint.h>
 #include "mythtracer_hip.h"
 
+// Waves per SIMD the frame kernels are compiled for (register budget 512 / n per
+// lane: 3 -> 168 VGPRs).  Swept: 2 (256 VGPRs, no spills) and 4 (128) are both
+// slower than 3.
+#ifndef MT_WAVES_PER_SIMD
+#define MT_WAVES_PER_SIMD 3
+#endif
+
 namespace mt {
 
 // One octree node, 96 bytes so that a wave fetches it with two scalar loads

@@ -144,7 +144,7 @@ __device__ __forceinline__ void pool_flush_item_stats(LaneStats &st, unsigned lo
 // block misses the rims of the glass spheres: those blocks then run late and
 // whole, and the first frame took 21 ms instead of 14.)  The forecast only
 // orders the work; nothing computed for a pixel depends on it.
-__global__ __launch_bounds__(256, 3) void probe_kernel(DevScene S, RenderParams P) {
+__global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void probe_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
 // the pixel store.  Persistent waves pull work units in pool_schedule_kernel's
 // order; the first ones (the longest) run at raised wave priority.
 template <bool STATS>
-__global__ __launch_bounds__(256, 3) void pool_kernel(DevScene S, RenderParams P) {
+__global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void pool_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;

@@ -147,7 +147,7 @@ __device__ __forceinline__ void flush_item_stats(LaneStats &st, unsigned long lo
 //   class 2: some pixel hit a transparent material (deep refraction trees),
 //   class 1: some pixel hit a reflective one, class 0: everything else.
 template <bool STATS>
-__global__ __launch_bounds__(256, 3) void primary_kernel(DevScene S, RenderParams P) {
+__global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
 // costs about 80 % of a pass over 64; quarters pay off only with four lanes per
 // pixel, i.e. with the pixel's shadow loops running side by side.)
 template <bool STATS>
-__global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams P) {
+__global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256, 3) void render_kernel(DevScene S, RenderParams
 
 // OctTree::IntersectRay for a batch of arbitrary rays: lane i of the grid
 // traces ray i.
-__global__ __launch_bounds__(256, 3) void intersect_kernel(DevScene S, int n, const double *rays,
+__global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void intersect_kernel(DevScene S, int n, const double *rays,
                                                         int *out_tri, int *out_line,
                                                         double *out_t, double *out_point,
                                                         unsigned long long *counters) {
