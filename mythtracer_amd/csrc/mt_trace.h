@@ -1786,8 +1786,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     cur_fc = q[0];
     cur_pb = q[1];
     cur_pc = q[2];
-    cur_level = q[4];
+    cur_level = q[4];  // used by the -DMT_LEVEL_LOOP variant only
   };
+  (void)cur_level;
   if (cur >= 0) load_record(cur);
 
   // The tail of PrimitiveIntersectRay for one node (octtree.cc:199-256): order
