@@ -1,12 +1,13 @@
 // texture.cc — texture files -> texels (reference: VerStarting/texture.cc:60-109).
 //
 // The reference decodes through SDL2_image; this build has no third-party
-// decoder, so four self-contained formats are read directly: PNG (8-bit
+// decoder, so five self-contained formats are read directly: PNG (8-bit
 // grey / grey+alpha / RGB / RGBA / palette, non-interlaced; own inflate),
-// binary PPM (P6, maxval 255), uncompressed 24/32-bit BMP, uncompressed
-// true-colour TGA.  The texel conversion is the reference's: the image is taken
+// baseline JPEG (libjpeg's integer arithmetic restated, see DecodeJPEG), binary
+// PPM (P6, maxval 255), uncompressed 24/32-bit BMP, uncompressed true-colour
+// TGA.  The texel conversion is the reference's: the image is taken
 // as RGBA32 and colour = byte / 255.0 (texture.cc:88-104), rows stored top to
-// bottom, alpha dropped.  (JPEG stays out: its decoders do not agree bit for bit.)
+// bottom, alpha dropped.
 #include "texture.h"
 
 #include <cstdint>
@@ -315,6 +316,388 @@ Texture* DecodePNG(const std::vector<uint8_t>& d) {
   return FromRgbRows((size_t)w, (size_t)h, rgb);
 }
 
+// ---- JPEG (baseline) --------------------------------------------------------
+// Sequential DCT, Huffman, 8 bit, grey or YCbCr with 1x1 / 2x1 / 2x2 chroma
+// sampling, restart intervals.  The reference decodes JPEG through SDL2_image,
+// i.e. libjpeg with its defaults; decoders differ in the last bit unless they
+// use the same integer arithmetic, so this one restates libjpeg's: the
+// "islow" inverse DCT (jidctint.c: 13-bit constants, two passes), "fancy"
+// (triangle-filter) chroma upsampling with replicated edge rows (jdsample.c)
+// and the fixed-point YCbCr -> RGB tables (jdcolor.c).  tests/test_host_cpu.py
+// pins it to libjpeg-turbo's output (through PIL).
+struct JpegBits {
+  const uint8_t* p;
+  size_t n, pos;
+  uint32_t buf = 0;
+  int cnt = 0;
+  bool marker_hit = false;
+  int Bit() {
+    if (cnt == 0) {
+      int c = 0;
+      if (!marker_hit && pos < n) {
+        c = p[pos++];
+        if (c == 0xff) {
+          const int c2 = pos < n ? p[pos] : 0xd9;
+          if (c2 == 0) pos++;                     // stuffed zero
+          else { marker_hit = true; pos--; c = 0; }  // a marker: feed zeros (libjpeg does the same)
+        }
+      }
+      buf = (uint32_t)c;
+      cnt = 8;
+    }
+    cnt--;
+    return (int)((buf >> cnt) & 1u);
+  }
+  int Bits(int k) {
+    int v = 0;
+    while (k--) v = (v << 1) | Bit();
+    return v;
+  }
+  void Reset() { cnt = 0; marker_hit = false; }
+};
+struct JpegHuff {
+  int mincode[17], maxcode[18], valptr[17];
+  uint8_t vals[256];
+  bool present = false;
+  void Build(const uint8_t counts[16], const uint8_t* symbols, int nsym) {
+    memcpy(vals, symbols, (size_t)nsym);
+    int code = 0, k = 0;
+    for (int len = 1; len <= 16; len++) {
+      valptr[len] = k;
+      mincode[len] = code;
+      code += counts[len - 1];
+      k += counts[len - 1];
+      maxcode[len] = counts[len - 1] ? code - 1 : -1;
+      code <<= 1;
+    }
+    maxcode[17] = 0x7fffffff;
+    present = true;
+  }
+  int Decode(JpegBits& br) const {
+    int code = 0;
+    for (int len = 1; len <= 16; len++) {
+      code = (code << 1) | br.Bit();
+      if (maxcode[len] >= 0 && code <= maxcode[len] && code >= mincode[len]) return vals[valptr[len] + code - mincode[len]];
+    }
+    return -1;
+  }
+};
+inline int JpegExtend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
+
+// jidctint.c jpeg_idct_islow: dequantized coefficients (natural order) -> 64 samples
+void JpegIdctIslow(const int* in, uint8_t* out, int stride) {
+  constexpr int CB = 13, P1 = 2;
+  constexpr long F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633,
+                 F1501 = 12299, F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172;
+  auto descale = [](long x, int n) { return (x + (1L << (n - 1))) >> n; };
+  long ws[64];
+  for (int c = 0; c < 8; c++) {  // pass 1: columns
+    long z2 = in[16 + c], z3 = in[48 + c];
+    long z1 = (z2 + z3) * F0541;
+    long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+    z2 = in[c];
+    z3 = in[32 + c];
+    long tmp0 = (z2 + z3) * (1L << CB), tmp1 = (z2 - z3) * (1L << CB);
+    const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = in[56 + c]; tmp1 = in[40 + c]; tmp2 = in[24 + c]; tmp3 = in[8 + c];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    long z4 = tmp1 + tmp3;
+    const long z5 = (z3 + z4) * F1175;
+    tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+    z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    ws[c] = descale(tmp10 + tmp3, CB - P1);      ws[56 + c] = descale(tmp10 - tmp3, CB - P1);
+    ws[8 + c] = descale(tmp11 + tmp2, CB - P1);  ws[48 + c] = descale(tmp11 - tmp2, CB - P1);
+    ws[16 + c] = descale(tmp12 + tmp1, CB - P1); ws[40 + c] = descale(tmp12 - tmp1, CB - P1);
+    ws[24 + c] = descale(tmp13 + tmp0, CB - P1); ws[32 + c] = descale(tmp13 - tmp0, CB - P1);
+  }
+  auto clamp = [](long v) { v += 128; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+  for (int r = 0; r < 8; r++) {  // pass 2: rows
+    const long* w = ws + r * 8;
+    long z2 = w[2], z3 = w[6];
+    long z1 = (z2 + z3) * F0541;
+    long tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+    long tmp0 = (w[0] + w[4]) * (1L << CB), tmp1 = (w[0] - w[4]) * (1L << CB);
+    const long tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+    tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
+    z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+    long z4 = tmp1 + tmp3;
+    const long z5 = (z3 + z4) * F1175;
+    tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
+    z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
+    z3 += z5; z4 += z5;
+    tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+    uint8_t* o = out + r * stride;
+    constexpr int S = CB + P1 + 3;
+    o[0] = clamp(descale(tmp10 + tmp3, S)); o[7] = clamp(descale(tmp10 - tmp3, S));
+    o[1] = clamp(descale(tmp11 + tmp2, S)); o[6] = clamp(descale(tmp11 - tmp2, S));
+    o[2] = clamp(descale(tmp12 + tmp1, S)); o[5] = clamp(descale(tmp12 - tmp1, S));
+    o[3] = clamp(descale(tmp13 + tmp0, S)); o[4] = clamp(descale(tmp13 - tmp0, S));
+  }
+}
+
+Texture* DecodeJPEG(const std::vector<uint8_t>& d) {
+  static const uint8_t kZigzag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48,
+                                      41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
+                                      15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55,
+                                      62, 63};
+  struct Comp { int id, h, v, tq, td, ta, bw, bh, dc_pred; std::vector<uint8_t> plane; int pw, ph; };
+  int qt[4][64];
+  bool qt_ok[4] = {false, false, false, false};
+  JpegHuff hdc[4], hac[4];
+  std::vector<Comp> comps;
+  long W = 0, H = 0;
+  int restart = 0, adobe_transform = -1;
+  bool sof = false;
+  size_t pos = 2;
+  if (d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) return nullptr;
+  size_t scan_at = 0;
+  while (pos + 4 <= d.size()) {
+    if (d[pos] != 0xff) return nullptr;
+    const int m = d[pos + 1];
+    pos += 2;
+    if (m == 0xff) { pos--; continue; }  // fill byte
+    if (m == 0xd8 || (m >= 0xd0 && m <= 0xd7) || m == 0x01) continue;
+    if (m == 0xd9) break;
+    if (pos + 2 > d.size()) return nullptr;
+    const size_t len = ((size_t)d[pos] << 8) | d[pos + 1];
+    if (len < 2 || pos + len > d.size()) return nullptr;
+    const uint8_t* b = &d[pos + 2];
+    const size_t bl = len - 2;
+    if (m == 0xdb) {  // DQT
+      for (size_t i = 0; i < bl;) {
+        const int pq = b[i] >> 4, tq = b[i] & 15;
+        i++;
+        if (tq > 3 || i + (pq ? 128 : 64) > bl) return nullptr;
+        for (int k = 0; k < 64; k++) {
+          qt[tq][kZigzag[k]] = pq ? ((b[i] << 8) | b[i + 1]) : b[i];
+          i += pq ? 2 : 1;
+        }
+        qt_ok[tq] = true;
+      }
+    } else if (m == 0xc0 || m == 0xc1) {  // SOF0 / SOF1 (Huffman, sequential)
+      if (bl < 6 || b[0] != 8) return nullptr;
+      H = (b[1] << 8) | b[2];
+      W = (b[3] << 8) | b[4];
+      const int nc = b[5];
+      if ((nc != 1 && nc != 3) || bl < 6 + 3 * (size_t)nc) return nullptr;
+      comps.clear();
+      for (int i = 0; i < nc; i++) {
+        Comp c{};
+        c.id = b[6 + 3 * i];
+        c.h = b[7 + 3 * i] >> 4;
+        c.v = b[7 + 3 * i] & 15;
+        c.tq = b[8 + 3 * i];
+        if (c.tq > 3) return nullptr;
+        comps.push_back(c);
+      }
+      sof = true;
+    } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
+      return nullptr;  // progressive, lossless, arithmetic: not supported
+    } else if (m == 0xc4) {  // DHT
+      for (size_t i = 0; i < bl;) {
+        if (i + 17 > bl) return nullptr;
+        const int tc = b[i] >> 4, th = b[i] & 15;
+        int total = 0;
+        for (int k = 0; k < 16; k++) total += b[i + 1 + k];
+        if (th > 3 || tc > 1 || total > 256 || i + 17 + (size_t)total > bl) return nullptr;
+        (tc ? hac[th] : hdc[th]).Build(&b[i + 1], &b[i + 17], total);
+        i += 17 + (size_t)total;
+      }
+    } else if (m == 0xdd) {  // DRI
+      if (bl < 2) return nullptr;
+      restart = (b[0] << 8) | b[1];
+    } else if (m == 0xee) {  // Adobe APP14
+      if (bl >= 12 && !memcmp(b, "Adobe", 5)) adobe_transform = b[11];
+    } else if (m == 0xda) {  // SOS
+      if (!sof || bl < 1 || b[0] != (int)comps.size() || bl < 1 + 2 * comps.size() + 3) return nullptr;
+      for (size_t i = 0; i < comps.size(); i++) {
+        bool found = false;
+        for (Comp& c : comps) {
+          if (c.id == b[1 + 2 * i]) {
+            c.td = b[2 + 2 * i] >> 4;
+            c.ta = b[2 + 2 * i] & 15;
+            found = c.td < 4 && c.ta < 4;
+          }
+        }
+        if (!found) return nullptr;
+      }
+      scan_at = pos + len;
+      break;
+    }
+    pos += len;
+  }
+  if (!sof || scan_at == 0 || !SaneSize(W, H)) return nullptr;
+  int hmax = 1, vmax = 1;
+  for (const Comp& c : comps) {
+    if (c.h < 1 || c.v < 1 || c.h > 2 || c.v > 2 || !qt_ok[c.tq] || !hdc[c.td].present || !hac[c.ta].present) return nullptr;
+    hmax = c.h > hmax ? c.h : hmax;
+    vmax = c.v > vmax ? c.v : vmax;
+  }
+  if (comps.size() == 3) {
+    // luminance at full resolution, both chroma planes sampled alike: 1x1, 2x1 (h2v1) or 2x2 (h2v2)
+    if (comps[0].h != hmax || comps[0].v != vmax || comps[1].h != 1 || comps[1].v != 1 || comps[2].h != 1 ||
+        comps[2].v != 1 || (hmax == 1 && vmax == 2)) {
+      return nullptr;
+    }
+  } else {
+    hmax = vmax = 1;  // a single component is never interleaved: one block per MCU
+    comps[0].h = comps[0].v = 1;
+  }
+  const long mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+  {
+    // every block costs at least two bits (a DC code and an end-of-block code): a header
+    // that promises more blocks than the file can hold is refused before anything is allocated
+    long blocks_per_mcu = 0;
+    for (const Comp& c : comps) blocks_per_mcu += c.h * c.v;
+    if ((d.size() - scan_at) * 8 < (size_t)(mcux * mcuy * blocks_per_mcu) * 2) return nullptr;
+  }
+  for (Comp& c : comps) {
+    c.bw = (int)(mcux * c.h);
+    c.bh = (int)(mcuy * c.v);
+    c.pw = c.bw * 8;
+    c.ph = c.bh * 8;
+    c.plane.assign((size_t)c.pw * c.ph, 0);
+    c.dc_pred = 0;
+  }
+  // ---- entropy-coded segment
+  JpegBits br{d.data(), d.size(), scan_at};
+  int until_restart = restart;
+  for (long my = 0; my < mcuy; my++) {
+    for (long mx = 0; mx < mcux; mx++) {
+      if (restart && until_restart == 0) {
+        br.Reset();
+        // skip to the RSTn marker
+        while (br.pos + 1 < d.size() && !(d[br.pos] == 0xff && d[br.pos + 1] >= 0xd0 && d[br.pos + 1] <= 0xd7)) br.pos++;
+        br.pos += 2;
+        for (Comp& c : comps) c.dc_pred = 0;
+        until_restart = restart;
+      }
+      for (Comp& c : comps) {
+        for (int by = 0; by < c.v; by++) {
+          for (int bx = 0; bx < c.h; bx++) {
+            int coef[64] = {0};
+            const int t = hdc[c.td].Decode(br);
+            if (t < 0 || t > 11) return nullptr;
+            const int diff = t ? JpegExtend(br.Bits(t), t) : 0;
+            c.dc_pred += diff;
+            if (c.dc_pred < -32768 || c.dc_pred > 32767) return nullptr;  // beyond any 8-bit image (libjpeg keeps it in a short)
+            coef[0] = c.dc_pred * qt[c.tq][0];
+            for (int k = 1; k < 64;) {
+              const int rs = hac[c.ta].Decode(br);
+              if (rs < 0) return nullptr;
+              const int r = rs >> 4, sz = rs & 15;
+              if (sz == 0) {
+                if (r != 15) break;  // end of block
+                k += 16;
+                continue;
+              }
+              k += r;
+              if (k > 63) return nullptr;
+              coef[kZigzag[k]] = JpegExtend(br.Bits(sz), sz) * qt[c.tq][kZigzag[k]];
+              k++;
+            }
+            const size_t ox = (size_t)(mx * c.h + bx) * 8, oy = (size_t)(my * c.v + by) * 8;
+            JpegIdctIslow(coef, &c.plane[oy * c.pw + ox], c.pw);
+          }
+        }
+      }
+      if (restart) until_restart--;
+    }
+  }
+  // ---- upsampling (jdsample.c, do_fancy_upsampling) and colour conversion (jdcolor.c)
+  std::vector<uint8_t> rgb((size_t)W * H * 3);
+  if (comps.size() == 1) {
+    for (long y = 0; y < H; y++) {
+      for (long x = 0; x < W; x++) {
+        const uint8_t g = comps[0].plane[(size_t)y * comps[0].pw + x];
+        uint8_t* o = &rgb[((size_t)y * W + x) * 3];
+        o[0] = o[1] = o[2] = g;
+      }
+    }
+    return FromRgbRows((size_t)W, (size_t)H, rgb);
+  }
+  const long cw = (W + hmax - 1) / hmax, chh = (H + vmax - 1) / vmax;  // downsampled_width / height of the chroma planes
+  std::vector<uint8_t> up[2];
+  for (int ci = 0; ci < 2; ci++) {
+    const Comp& c = comps[1 + ci];
+    std::vector<uint8_t>& u = up[ci];
+    u.assign((size_t)W * H + (size_t)2 * W + 16, 0);
+    auto in = [&](long row, long col) -> int {  // edge rows replicated (jdmainct.c context rows)
+      row = row < 0 ? 0 : (row >= chh ? chh - 1 : row);
+      return c.plane[(size_t)row * c.pw + col];
+    };
+    if (hmax == 1 && vmax == 1) {
+      for (long y = 0; y < H; y++) memcpy(&u[(size_t)y * W], &c.plane[(size_t)y * c.pw], (size_t)W);
+    } else if (cw <= 2) {  // jinit_upsampler: planes this narrow get plain replication (h2v1_upsample / h2v2_upsample)
+      for (long y = 0; y < H; y++) {
+        for (long x = 0; x < W; x++) u[(size_t)y * W + x] = (uint8_t)in(y / vmax, x / 2);
+      }
+    } else if (hmax == 2 && vmax == 1) {  // h2v1_fancy_upsample
+      for (long y = 0; y < H; y++) {
+        std::vector<int> o((size_t)cw * 2);
+        {
+          o[0] = in(y, 0);
+          o[1] = (in(y, 0) * 3 + in(y, 1) + 2) >> 2;
+          for (long i = 1; i < cw - 1; i++) {
+            const int v = in(y, i) * 3;
+            o[2 * i] = (v + in(y, i - 1) + 1) >> 2;
+            o[2 * i + 1] = (v + in(y, i + 1) + 2) >> 2;
+          }
+          o[2 * cw - 2] = (in(y, cw - 1) * 3 + in(y, cw - 2) + 1) >> 2;
+          o[2 * cw - 1] = in(y, cw - 1);
+        }
+        for (long x = 0; x < W; x++) u[(size_t)y * W + x] = (uint8_t)o[x];
+      }
+    } else {  // h2v2_fancy_upsample
+      for (long y = 0; y < H; y++) {
+        const long r0 = y / 2, r1 = (y & 1) ? r0 + 1 : r0 - 1;  // nearer / farther input row
+        std::vector<int> o((size_t)cw * 2);
+        auto colsum = [&](long i) { return in(r0, i) * 3 + in(r1, i); };
+        {
+          int thiscs = colsum(0), nextcs = colsum(1), lastcs;
+          o[0] = (thiscs * 4 + 8) >> 4;
+          o[1] = (thiscs * 3 + nextcs + 7) >> 4;
+          lastcs = thiscs;
+          thiscs = nextcs;
+          for (long i = 1; i < cw - 1; i++) {
+            nextcs = colsum(i + 1);
+            o[2 * i] = (thiscs * 3 + lastcs + 8) >> 4;
+            o[2 * i + 1] = (thiscs * 3 + nextcs + 7) >> 4;
+            lastcs = thiscs;
+            thiscs = nextcs;
+          }
+          o[2 * cw - 2] = (thiscs * 3 + lastcs + 8) >> 4;
+          o[2 * cw - 1] = (thiscs * 4 + 7) >> 4;
+        }
+        for (long x = 0; x < W; x++) u[(size_t)y * W + x] = (uint8_t)o[x];
+      }
+    }
+  }
+  const bool is_rgb = adobe_transform == 0 || (comps[0].id == 'R' && comps[1].id == 'G' && comps[2].id == 'B');
+  auto clamp8 = [](int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+  for (long y = 0; y < H; y++) {
+    for (long x = 0; x < W; x++) {
+      const int Y = comps[0].plane[(size_t)y * comps[0].pw + x];
+      const int cb = up[0][(size_t)y * W + x], cr = up[1][(size_t)y * W + x];
+      uint8_t* o = &rgb[((size_t)y * W + x) * 3];
+      if (is_rgb) {
+        o[0] = (uint8_t)Y; o[1] = (uint8_t)cb; o[2] = (uint8_t)cr;
+      } else {  // ycc_rgb_convert: SCALEBITS 16, ONE_HALF 32768
+        const int xb = cb - 128, xr = cr - 128;
+        const int r = (int)((91881L * xr + 32768) >> 16);
+        const int bb = (int)((116130L * xb + 32768) >> 16);
+        const int g = (int)(((-22554L * xb + 32768) + (-46802L * xr)) >> 16);
+        o[0] = clamp8(Y + r);
+        o[1] = clamp8(Y + g);
+        o[2] = clamp8(Y + bb);
+      }
+    }
+  }
+  return FromRgbRows((size_t)W, (size_t)H, rgb);
+}
+
 uint32_t Le32(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
 uint16_t Le16(const uint8_t* p) { return (uint16_t)(p[0] | (p[1] << 8)); }
 
@@ -383,6 +766,7 @@ Texture* Texture::LoadFromFile(const char* fname) {
   if (!ReadAll(fname, &d) || d.size() < 4) return nullptr;
   Texture* t = nullptr;
   if (d[0] == 0x89 && d[1] == 'P') t = DecodePNG(d);
+  else if (d[0] == 0xff && d[1] == 0xd8) t = DecodeJPEG(d);
   else if (d[0] == 'P' && d[1] == '6') t = DecodePPM(d);
   else if (d[0] == 'B' && d[1] == 'M') t = DecodeBMP(d);
   else t = DecodeTGA(d);

@@ -440,6 +440,51 @@ def test_png_textures(tmp_path):
         (tmp_path / "m.mtl").write_text("newmtl a\nKa 1 1 1\nmap_Ka %s\n" % name)
         assert not M.MythTracer().load_obj(str(tmp_path / "m.obj")), name
 
+def test_jpeg_textures(tmp_path):
+    """Baseline JPEG decoding, pinned bit for bit to libjpeg-turbo through PIL
+    (libjpeg defaults = what SDL2_image's libjpeg backend runs behind IMG_Load,
+    texture.cc:68): islow IDCT, fancy upsampling, fixed-point YCbCr->RGB.  Grey
+    and colour, 4:4:4 / 4:2:2 / 4:2:0, optimised Huffman tables, restart
+    markers, sizes that are not a multiple of the MCU, chroma planes narrow
+    enough for libjpeg's plain-replication branch.  The reference holds no JPEG
+    fixture of its own, so against the reference this stays "parity unpinned"."""
+    PIL_Image = pytest.importorskip("PIL.Image")
+    rnd = np.random.RandomState(3)
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nusemtl a\nf 1/1 2/1 3/1 \n")
+    (tmp_path / "m.mtl").write_text("newmtl a\nKa 1 1 1\nmap_Ka t.jpg\n")
+    f = tmp_path / "t.jpg"
+    checked = 0
+    for (w, h) in ((1, 1), (3, 3), (4, 5), (6, 2), (13, 9), (16, 16), (33, 17), (64, 48), (1, 17), (17, 1), (200, 120)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        smooth = np.stack([(xx * 7 + yy * 3) % 256, (xx * 2 + yy * 11) % 256, (xx * yy) % 256], axis=2).astype(np.uint8)
+        noise = rnd.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        for img in (smooth, noise):
+            for mode, sub, q, extra in (("RGB", 0, 95, {}), ("RGB", 1, 75, {"optimize": True}), ("RGB", 2, 30, {}),
+                                        ("RGB", 2, 100, {"restart_marker_blocks": 3}), ("RGB", 1, 50, {"restart_marker_rows": 1}),
+                                        ("L", None, 80, {}), ("L", None, 40, {"optimize": True, "restart_marker_blocks": 2})):
+                kw = dict(quality=q, **extra)
+                if sub is not None:
+                    kw["subsampling"] = sub
+                PIL_Image.fromarray(img).convert(mode).save(f, "JPEG", **kw)
+                want = np.array(PIL_Image.open(f).convert("RGB"))
+                m = M.MythTracer()
+                assert m.load_obj(str(tmp_path / "m.obj")), (w, h, mode, sub, q)
+                tex = m.flatten()["textures"][0]["texels"]
+                assert tex.dtype == np.uint8 and np.array_equal(tex, want), (w, h, mode, sub, q, extra)
+                checked += 1
+    assert checked == 11 * 2 * 7
+    # progressive files, truncated headers and other damage are refused, not guessed at
+    PIL_Image.fromarray(noise).save(f, "JPEG", progressive=True)
+    assert not M.MythTracer().load_obj(str(tmp_path / "m.obj"))
+    PIL_Image.fromarray(noise).save(f, "JPEG")
+    good = f.read_bytes()
+    sof = good.index(b"\xff\xc0")
+    for blob in (good[:sof + 6], good[:2], good[:sof + 4] + b"\x0c" + good[sof + 5:],       # cut, bare SOI, 12-bit
+                 good[:sof + 9] + b"\x00" + good[sof + 10:],                                # zero components
+                 good.replace(b"\xff\xc4", b"\xff\xe5")):                                  # no Huffman tables
+        f.write_bytes(blob)
+        assert not M.MythTracer().load_obj(str(tmp_path / "m.obj"))
+
 
 def test_wire_formats():
     """WorkChunk / Camera (de)serialisation, mythtracer.cc:314-429, camera.cc:71-96."""
