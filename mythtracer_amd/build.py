@@ -62,7 +62,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 def build_prof(verbose: bool = False) -> str:
     """Diagnostic variant with phase stamps (-DMT_PROF); never used by tests or bench."""
     out = os.path.join(LIB, "libmythtracer_hip_prof.so")
-    cmd = [HIPCC] + HIP_FLAGS + ["-DMT_PROF", "-I", INC, "-I", CSRC, "-o", out,
+    cmd = [HIPCC] + HIP_FLAGS + ["-DMT_PROF"] + os.environ.get("MT_EXTRA_FLAGS", "").split() + ["-I", INC, "-I", CSRC, "-o", out,
                                  os.path.join(CSRC, "mt_capi.hip")]
     subprocess.check_call(cmd)
     return out

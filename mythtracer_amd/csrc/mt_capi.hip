@@ -627,10 +627,36 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
       }
     }
   }
+  // Records of the hit-set traversal (mt_device.h HsRec).
+  std::vector<HsRec> hsr((size_t)nn + 1);
+  memset(hsr.data(), 0, hsr.size() * sizeof(HsRec));
+  for (int i = 0; i < nn; i++) {
+    HsRec &h = hsr[i];
+    const NodeRec &r = recs[i];
+    h.first_child = r.first_child;
+    h.prim_begin = r.prim_begin;
+    h.prim_count = r.prim_count;
+    h.child_mask = r.first_child != 0 ? (r.child_mask & 0xff) : 0;
+    for (int c = 0; c < 8; c++) {
+      for (int k = 0; k < 6; k++) {
+        h.kid[c][k] = r.first_child != 0 ? subs[(size_t)(r.first_child + c) * 6 + k] : (k < 3 ? 3.0e38f : -3.0e38f);
+      }
+    }
+    double u[6] = {3.0e38, 3.0e38, 3.0e38, -3.0e38, -3.0e38, -3.0e38};
+    for (int t = r.prim_begin; t < r.prim_begin + r.prim_count; t++) {
+      const double *b = d->tri_aabb + (size_t)t * 6;
+      for (int k = 0; k < 3; k++) {
+        u[k] = std::min(u[k], b[k]);
+        u[3 + k] = std::max(u[3 + k], b[3 + k]);
+      }
+    }
+    for (int k = 0; k < 6; k++) h.own[k] = (float)u[k];
+  }
   groups.resize(groups.size() + 8 * 6, 0.0f);  // the scan looks four boxes ahead
   int rc;
   if ((rc = upload(s, groups.data(), groups.size(), &s->dev.grp_aabb32)) != MT_OK) return rc;
   if ((rc = upload(s, subs.data(), subs.size(), &s->dev.sub_aabb32)) != MT_OK) return rc;
+  if ((rc = upload(s, hsr.data(), hsr.size(), &s->dev.hs_rec)) != MT_OK) return rc;
   if ((rc = upload(s, recs.data(), recs.size(), &s->dev.nodes)) != MT_OK) return rc;
   const size_t nt = (size_t)d->n_tris;
   {
@@ -640,7 +666,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     if ((rc = upload(s, boxes.data(), boxes.size(), &s->dev.tri_aabb)) != MT_OK) return rc;
     // fp32 copy for the conservative pre-filter (mt_trace.h Filter32); padded by
     // 8 boxes because that loop looks four boxes ahead.
-    std::vector<float> boxes32(nt * 6 + 8 * 6, 0.0f);
+    std::vector<float> boxes32(nt * 6 + 40 * 6, 0.0f);  // (the hit-set traversal copies 32 boxes from a list's start)
     double bmax[3] = {0.0, 0.0, 0.0};
     for (size_t i = 0; i < nt * 6; i++) {
       boxes32[i] = (float)boxes[i];
@@ -786,7 +812,8 @@ int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
                                             "n_transposed_chunks", "n_raypar_tris", "n_traces", "lane_phase_cycles",
                                             "scan_m2f", "scan_m2", "scan_m1", "scan_m0", "n_m2f", "n_m2", "n_m1", "n_m0",
                                             "tris_m2f", "tris_m1", "tris_transposed", "g_groups", "g_live", "g_ranges", "g_range_tris", "nin_sum", "nin_lt8", "nin_lt24", "want_sum",
-                                            "grp_mask_t", "grp_ranges_t", "tr_blocks_t", "tr_tris_t", "tr_bcast_t", "tr_rays", "m2f_call_t"};
+                                            "grp_mask_t", "grp_ranges_t", "tr_blocks_t", "tr_tris_t", "tr_bcast_t", "tr_rays", "m2f_call_t",
+                                            "hs_rec_t", "hs_big_t", "hs_small_t", "hs_trans_t", "hs_kids_t", "hs_ret_t", "hs_close_t", "hs_n_enter", "hs_n_big", "hs_n_small", "hs_n_empty", "hs_n_trans", "hs_n_ret", "hs_n_rethit", "hs_lanes", "hs_big_tris", "hs_small_tris"};
     fprintf(stderr, "[mt prof]");
     for (int i = 0; i < PROF_COUNT; i++) fprintf(stderr, " %s=%llu", names[i], pr[i]);
     fprintf(stderr, "\n");

@@ -42,6 +42,19 @@ static_assert(sizeof(NodeRec) == 96, "NodeRec must be 96 bytes");
 constexpr int kBigNode = 32;
 constexpr int kGroupTris = 16;
 
+// Everything the hit-set traversal (-DMT_HS, mt_trace.h) needs to know about a
+// node before it looks at triangles, in one 256-byte record that a wave
+// stages in LDS with ONE load instruction (16 lanes x 16 bytes), one node ahead
+// of its use: the list, the children, the fp32 union box of every child's
+// subtree and of the node's own list (inverted when empty: every ray misses).
+struct HsRec {
+  int32_t first_child, prim_begin, prim_count, child_mask;
+  float kid[8][6];
+  float own[6];
+  float pad[6];
+};
+static_assert(sizeof(HsRec) == 256, "HsRec must be 256 bytes");
+
 struct DevTexture {
   const void *texels;
   int32_t width, height, format, pad;
@@ -54,6 +67,7 @@ struct DevScene {
   const float *tri_aabb32;   // the same boxes rounded to fp32 (conservative pre-filter)
   const float *grp_aabb32;   // fp32 union box of each block of kGroupTris consecutive stream triangles
   const float *sub_aabb32;   // per node: fp32 union box of all triangles in its subtree
+  const HsRec *hs_rec;       // per node (hit-set traversal)
   double bmax[3];            // max |coordinate| of any triangle box, per axis
   const double *tri_vertex;  // 9 per triangle
   const double *tri_normal;  // 9 per triangle
@@ -86,7 +100,10 @@ enum { PROF_TRACE = 0, PROF_SCAN_RAYPAR, PROF_SCAN_TRANSPOSED, PROF_CHILDREN_UNW
        PROF_TRIS_M2F, PROF_TRIS_M1, PROF_TRIS_TRANSPOSED,
        PROF_G_GROUPS, PROF_G_LIVE, PROF_G_RANGES, PROF_G_RANGE_TRIS,
        PROF_NIN_SUM, PROF_NIN_LT8, PROF_NIN_LT24, PROF_WANT_SUM,
-       PROF_TA_G, PROF_TB_G, PROF_TA_T, PROF_TB_T, PROF_TC_T, PROF_T_RAYS, PROF_M2F_CALL, PROF_COUNT };
+       PROF_TA_G, PROF_TB_G, PROF_TA_T, PROF_TB_T, PROF_TC_T, PROF_T_RAYS, PROF_M2F_CALL,
+       PROF_HS_REC_T, PROF_HS_BIG_T, PROF_HS_SMALL_T, PROF_HS_TRANS_T, PROF_HS_KIDS_T, PROF_HS_RET_T, PROF_HS_CLOSE_T,
+       PROF_HS_N_ENTER, PROF_HS_N_BIG, PROF_HS_N_SMALL, PROF_HS_N_EMPTY, PROF_HS_N_TRANS, PROF_HS_N_RET, PROF_HS_N_RETHIT,
+       PROF_HS_LANES, PROF_HS_BIG_TRIS, PROF_HS_SMALL_TRIS, PROF_COUNT };
 
 enum {
   ST_RAYS_PRIMARY = 0,
@@ -153,9 +170,24 @@ struct RenderParams {
 
 // Bytes of LDS one wave needs for its traversal stack: 20-byte frames, or 16-byte
 // ones when a node index and a triangle index fit one word together
-// (DevScene::pack_shift != 0), plus five per-lane work counters.
+// (DevScene::pack_shift != 0), plus five per-lane work counters.  With -DMT_HS
+// (hit-set traversal, mt_trace.h) trees of up to kHsMaxDepth levels use 24-byte
+// frames for the levels that can hold a node with children, plus two
+// wave-uniform words per level; the old frames share the same bytes.
+constexpr int kHsMaxDepth = 9;
+__host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
+  size_t n = (size_t)depth * 64 * (packed ? 16 : 20);
+#ifdef MT_HS
+  if (depth <= kHsMaxDepth && depth > 1) {
+    // frames, (node, first child) per level, two staged records (16-byte aligned)
+    const size_t hs = (((size_t)(depth - 1) * (64 * 24 + 8) + 15) & ~(size_t)15) + 2 * sizeof(HsRec);
+    if (hs > n) n = hs;
+  }
+#endif
+  return n;
+}
 __host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
-  size_t n = (size_t)depth * 64 * (packed ? 16 : 20) + 5 * 64 * 4;
+  size_t n = wave_frames_bytes(depth, packed) + 5 * 64 * 4;  // -DMT_HS: the counters' bytes stage triangle boxes
 #ifdef MT_VEC_SCAN
   n += 64 * 32;  // staging area of the vector-load scan: 64 boxes of 8 floats
 #endif

@@ -47,6 +47,20 @@ namespace mt {
 #define MT_DUP 0  // diagnostic: execute one section of the traversal twice (timing experiments only)
 #endif
 
+// Per-lane work counters of one traversal (STATS instantiations only).  Default:
+// in LDS behind the stack -- four ds_add per node step instead of live VGPRs.
+// -DMT_HS: in registers (the LDS behind the frames stages node records there;
+// the timed kernels are the ones without counters).
+#ifdef MT_HS
+#define MT_CNT_ADD(i, v) (cntr[i] += (v))
+#define MT_CNT_SET(i, v) (cntr[i] = (v))
+#define MT_CNT_GET(i) (cntr[i])
+#else
+#define MT_CNT_ADD(i, v) __hip_atomic_fetch_add(&cnt[(i) * 64 + lane], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
+#define MT_CNT_SET(i, v) (cnt[(i) * 64 + lane] = (v))
+#define MT_CNT_GET(i) (cnt[(i) * 64 + lane])
+#endif
+
 // Phase profiling (diagnostic build only: python -m mythtracer_amd.build --prof).
 #ifdef MT_PROF
 #define MT_PROF_DECL unsigned long long prof_acc[PROF_COUNT] = {0}; unsigned long long prof_t0 = 0, prof_t1 = 0
@@ -205,10 +219,20 @@ struct WaveStack {
 };
 
 // Möller–Trumbore, primitive_triangle.cc:110-142, for one lane's triangle.
+__device__ __forceinline__ bool moller_trumbore_v(const double *v, double ox, double oy,
+                                                  double oz, double dx, double dy, double dz,
+                                                  double *t_out);
 __device__ __forceinline__ bool moller_trumbore(const double *vtx, double ox, double oy,
                                                 double oz, double dx, double dy, double dz,
                                                 double *t_out) {
-  const MT_CONST double *v = as_const(vtx);
+  const MT_CONST double *p = as_const(vtx);
+  const double v[9] = {p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7], p[8]};
+  return moller_trumbore_v(v, ox, oy, oz, dx, dy, dz, t_out);
+}
+// The same on vertices that are already in registers.
+__device__ __forceinline__ bool moller_trumbore_v(const double *v, double ox, double oy,
+                                                  double oz, double dx, double dy, double dz,
+                                                  double *t_out) {
   const double v0x = v[0], v0y = v[1], v0z = v[2];
   const double e1x = v[3] - v0x, e1y = v[4] - v0y, e1z = v[5] - v0z;
   const double e2x = v[6] - v0x, e2y = v[7] - v0y, e2z = v[8] - v0z;
@@ -1657,6 +1681,16 @@ __device__ __forceinline__ ScanOut scan_octant_dispatch(const DevScene &S, int o
   }
 }
 
+// Asynchronous copy global -> LDS, 16 bytes per active lane: lane i's bytes land at lds_base + 16 i
+// (wave-uniform base in M0).  Written as asm because hipcc 7.2 handles the builtin inconsistently: it
+// either waits vmcnt(0) before the NEXT LDS read of any address (which serialises the copy with the
+// work it was meant to overlap) or, across a loop back-edge, not at all.  The waits are explicit at the
+// readers (s_waitcnt vmcnt); M0 is a reserved register the compiler sets anew before each of its own uses.
+__device__ __forceinline__ void lds_dma16(const char *src, unsigned lds_base) {
+  const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(base), "v"(src) : "memory");
+}
+
 // One closest-hit query per lane.  Must be called by all 64 lanes of the wave
 // (want = false for lanes without a ray).  out_prim = stream index or -1.
 // Result of one traversal, returned by value (in registers).
@@ -1685,6 +1719,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   S.tri_aabb32 = G->tri_aabb32;
   S.grp_aabb32 = G->grp_aabb32;
   S.sub_aabb32 = G->sub_aabb32;
+  S.hs_rec = G->hs_rec;
   S.self = uniform_ptr(scene);
   S.tri_vertex = G->tri_vertex;
   S.bmax[0] = G->bmax[0]; S.bmax[1] = G->bmax[1]; S.bmax[2] = G->bmax[2];
@@ -1713,13 +1748,17 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   MT_LDS unsigned *const stk_ord = stk.ord();
   // per-lane work counters of this traversal live in LDS (behind the stack),
   // not in registers: four ds_add per node step instead of four live VGPRs
-  MT_LDS unsigned *const cnt = (MT_LDS unsigned *)(uintptr_t)(stk.base + (unsigned)stk.depth * 64u * stk.frame_bytes());
+  const unsigned frames_end = stk.base + (unsigned)wave_frames_bytes(stk.depth, stk.pack_shift != 0);
+  MT_LDS unsigned *const cnt = (MT_LDS unsigned *)(uintptr_t)frames_end;
+  (void)cnt;
+  unsigned cntr[5] = {0u, 0u, 0u, 0u, 0u};
+  (void)cntr;
   const int pack_shift = stk.pack_shift;  // wave-uniform
-  const unsigned stage_off = stk.base + (unsigned)stk.depth * 64u * stk.frame_bytes() + 5u * 64u * 4u;  // MT_VEC_SCAN only
+  const unsigned stage_off = frames_end + 5u * 64u * 4u;  // MT_VEC_SCAN only
   (void)stage_off;
   if (STATS) {
-    cnt[0 * 64 + lane] = 0; cnt[1 * 64 + lane] = 0; cnt[2 * 64 + lane] = 0; cnt[3 * 64 + lane] = 0;
-    cnt[4 * 64 + lane] = 0;
+    MT_CNT_SET(0, 0u); MT_CNT_SET(1, 0u); MT_CNT_SET(2, 0u); MT_CNT_SET(3, 0u);
+    MT_CNT_SET(4, 0u);
   }
   RayRegs r;
   r.ox = ox; r.oy = oy; r.oz = oz;
@@ -1764,7 +1803,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // root box test, octtree.cc:35-37 (exact form; once per ray)
     const MT_CONST NodeRec *R = nodes;
     if (STATS) {
-      cnt[0 * 64 + lane] = 1;
+      MT_CNT_SET(0, 1u);
       st.bytes_scalar += 96u;  // the root record
     }
     const double t1 = (R->lo[0] - ox) * r.ix, t2 = (R->hi[0] - ox) * r.ix;
@@ -1823,7 +1862,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         depth++;
         cur = child;
         load_record(child);
-        if (STATS) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], 16u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (STATS) MT_CNT_ADD(4, 16u);
         break;
       }
       if (depth == 0) {
@@ -1867,6 +1906,408 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
 #ifdef MT_DIAG
   unsigned diag_a_trips = 0, diag_transposed = 0, diag_vec = 0;
 #endif
+#ifdef MT_HS
+  // ---- hit-set traversal (regular rays, automatic mode) ---------------------
+  // What PrimitiveIntersectRay returns for a node is a function of three things
+  // only (octtree.cc:169-257): the best hit of the node's own list; for every
+  // child, whether the ray enters its box and at what distance (the sort key);
+  // and what the same function returns for the children that hold a hit --
+  // children without one `continue` and leave no trace.  The loop over the
+  // sorted children takes the FIRST one whose hit is not farther than the own
+  // one and stops: with NaN-free keys and a stable sort that is the entered,
+  // acceptable child with the smallest (entry distance, index).  So the order
+  // in which the children are LOOKED AT is free: here the whole wave walks the
+  // tree depth-first in index order, every node once for all lanes whose
+  // filter does not rule its subtree out (wave-uniform boxes, scalar loads, no
+  // per-lane stack walk, no sort), each child's result is offered to its
+  // parent's frame when the wave comes back from it (exact entry test of that
+  // one child, comparison with the frame's best candidate so far), and a frame
+  // is closed when its last child is done.  Nodes the reference would not have
+  // reached (behind its early exit) may be looked at; that changes the work,
+  // not the result.
+  bool hs_done = false;
+  if (cull && S.force_mode == 0 && S.tree_depth <= kHsMaxDepth && S.n_tris < (1 << 28)) {
+    hs_done = true;
+    const int L = S.tree_depth > 1 ? S.tree_depth - 1 : 0;  // levels that can hold a node with children
+    MT_LDS double *const h_own_t = (MT_LDS double *)(uintptr_t)stk.base;  // [L][64] own list's best distance
+    MT_LDS double *const h_win_t = h_own_t + L * 64;                       // [L][64] best child candidate so far
+    MT_LDS int *const h_own_p = (MT_LDS int *)(h_win_t + L * 64);          // [L][64] own best triangle, -1 none
+    MT_LDS int *const h_win_p = h_own_p + L * 64;                          // [L][64] candidate triangle | child slot << 28, -1 none
+    MT_LDS int *const h_node = h_win_p + L * 64;                           // [L][2] wave-uniform: node, its first child
+    const unsigned stage = ((unsigned)(uintptr_t)(h_node + L * 2) + 15u) & ~15u;  // two staged HsRec
+    const unsigned tstage = frames_end;                                    // 32 staged fp32 triangle boxes (768 B)
+    const char *const hs_bytes = (const char *)S.hs_rec;
+    int lev = -1;                        // frame on top of the stack, -1 none
+    unsigned long long pend = 0ull;      // wave-uniform; byte l: children of frame l still to look at
+    unsigned long long wantbits = 0ull;  // per lane; byte l: children of frame l this lane's filter lets through
+    int node = 0;
+    unsigned long long m = __ballot(cur == 0);
+    int ret_p = -1;
+    double ret_t = 0.0;
+    int slot = 0;  // child slot the result in ret_* comes from
+    bool entering = true;
+    // Records are staged one node ahead: `staged[b]` = node whose record is (being) copied to buffer b.
+    int buf = 0, staged0 = -1, staged1 = -1;
+    auto hs_fetch = [&](int nd, int b) {
+      if (lane < 16) lds_dma16(hs_bytes + (size_t)nd * sizeof(HsRec) + (size_t)lane * 16, stage + (unsigned)b * (unsigned)sizeof(HsRec));
+      if (b == 0) staged0 = nd; else staged1 = nd;
+    };
+    // Children are looked at near to far for the octant of the wave's first ray (child index
+    // bits: 0 = x high, 1 = z high, 2 = y high): a candidate found early lets the lanes drop the
+    // children that sort behind it, which is the reference's early exit (octtree.cc:246).
+    unsigned flip = 0u;
+    if (m != 0ull) {
+      const int fl = __builtin_ctzll(m);
+      flip = (unsigned)(__builtin_amdgcn_readlane(sxl, fl) | (__builtin_amdgcn_readlane(szl, fl) << 1) |
+                        (__builtin_amdgcn_readlane(syl, fl) << 2));
+    }
+    auto pick = [&](unsigned td) -> int {  // td != 0: the child to look at next
+      unsigned t = td;
+      if (flip & 1u) t = ((t & 0x55u) << 1) | ((t >> 1) & 0x55u);
+      if (flip & 2u) t = ((t & 0x33u) << 2) | ((t >> 2) & 0x33u);
+      if (flip & 4u) t = ((t & 0x0fu) << 4) | ((t >> 4) & 0x0fu);
+      return (int)((unsigned)__builtin_ctz(t) ^ flip);
+    };
+    // the node the wave enters after the current one if nothing below it is entered
+    auto next_after = [&](int l, unsigned long long pd) -> int {
+      for (; l >= 0; l--) {
+        const unsigned td = (unsigned)(pd >> (8 * l)) & 0xffu;
+        if (td != 0u) return uniform_i32(h_node[l * 2 + 1]) + pick(td);
+      }
+      return -1;
+    };
+    if (m != 0ull) {
+      hs_fetch(0, 0);
+      for (;;) {
+      if (++steps > step_bound) {
+        status = DEV_ERR_TRAVERSAL_BOUND;
+        break;
+      }
+      // The walk's state is the same in every lane; say so (hipcc's divergence analysis loses it
+      // across the loop and would run the bookkeeping below as per-lane vector code).
+      lev = uniform_i32(lev);
+      node = uniform_i32(node);
+      slot = uniform_i32(slot);
+      buf = uniform_i32(buf);
+      staged0 = uniform_i32(staged0);
+      staged1 = uniform_i32(staged1);
+      entering = uniform_i32(entering ? 1 : 0) != 0;
+      pend = ((unsigned long long)(unsigned)uniform_i32((int)(pend >> 32)) << 32) | (unsigned)uniform_i32((int)pend);
+      m = ((unsigned long long)(unsigned)uniform_i32((int)(m >> 32)) << 32) | (unsigned)uniform_i32((int)m);
+      if (entering) {
+        const bool in = ((m >> lane) & 1ull) != 0ull;
+        MT_PROF_BEGIN(prof_t1);
+        if ((buf == 0 ? staged0 : staged1) != node) hs_fetch(node, buf);  // not the node that was foreseen
+        // hipcc 7.2 does not wait for an LDS-DMA before LDS reads through a pointer it cannot
+        // trace back to the DMA's destination: the wait is explicit
+#ifdef MT_PROF
+        const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MT_PROF
+        MT_PROF_COUNT(PROF_HS_CLOSE_T, __builtin_amdgcn_s_memtime() - tw0);
+#endif
+        const unsigned rec = stage + (unsigned)buf * (unsigned)sizeof(HsRec);
+        const MT_LDS int *ri = (const MT_LDS int *)(uintptr_t)rec;
+        const int fc = uniform_i32(ri[0]), pb = uniform_i32(ri[1]), pc = uniform_i32(ri[2]);
+        const unsigned cm = (unsigned)uniform_i32(ri[3]);
+#ifdef MT_PROF
+        asm volatile("" :: "s"(fc), "s"(pb), "s"(pc), "s"(cm));
+        MT_PROF_END(PROF_HS_REC_T, prof_t1);
+        MT_PROF_COUNT(PROF_HS_N_ENTER, 1);
+        MT_PROF_COUNT(PROF_HS_LANES, __builtin_popcountll(m));
+        MT_PROF_BEGIN(prof_t1);
+#endif
+        // a short list's fp32 boxes are copied to LDS while the children are tested
+        const bool small_list = pc > 0 && pc < kBigNode;
+        if (small_list && lane < 48) lds_dma16((const char *)S.tri_aabb32 + (size_t)pb * 24 + (size_t)lane * 16, tstage);
+        if (STATS) {
+          st.wave_node_steps++;
+          st.wave_tri_steps += (unsigned)pc;
+          st.bytes_scalar += 256u;
+          if (in) {
+            MT_CNT_ADD(1, 1u);
+            MT_CNT_ADD(2, (unsigned)pc);
+            if (fc != 0) MT_CNT_ADD(0, 8u);
+          }
+        }
+        // which children does some lane's filter let through?  All nine boxes (eight subtrees, the
+        // own list) are read in one batch and tested without branches.
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const MT_LDS f4v *r4 = (const MT_LDS f4v *)(uintptr_t)rec;
+        float bxs[56];
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+          const f4v q = r4[1 + i];
+          bxs[i * 4 + 0] = q.x; bxs[i * 4 + 1] = q.y; bxs[i * 4 + 2] = q.z; bxs[i * 4 + 3] = q.w;
+        }
+        unsigned bits = 0u, any = 0u;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const bool pass = subtree_may_hit(bxs + c * 6, f32, sxl != 0, syl != 0, szl != 0);
+          if (pass) bits |= 1u << c;
+        }
+        bits = in ? (bits & cm) : 0u;  // (cm: children with an empty subtree hold an inverted box anyway)
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          if (__ballot(((bits >> c) & 1u) != 0u) != 0ull) any |= 1u << c;
+        }
+        // the own list's union box decides who scans it
+        const bool in_list = in && pc > 0 && subtree_may_hit(bxs + 48, f32, sxl != 0, syl != 0, szl != 0);
+        const unsigned long long lm = __ballot(in_list);
+        // stage the record of the node that comes next while this one's list is scanned
+        bool fetched_next = false;
+        {
+          const int nxt = any != 0u ? fc + pick(any) : next_after(lev, pend);
+          if (nxt >= 0) {
+            hs_fetch(nxt, buf ^ 1);
+            fetched_next = true;
+          }
+          buf ^= 1;
+        }
+#ifdef MT_PROF
+        asm volatile("" :: "v"(bits), "s"(any), "s"(lm));
+        MT_PROF_END(PROF_HS_KIDS_T, prof_t1);
+        MT_PROF_BEGIN(prof_t1);
+#endif
+        int best = -1;
+        double best_t = 0.0;
+        if (small_list && lm != 0ull) {
+          // the boxes were requested before the next node's record: all but that last copy must have landed
+          if (fetched_next) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          unsigned cand = 0u;  // per lane: list positions whose fp32 box the ray may hit
+          {
+            const MT_LDS f4v *t4 = (const MT_LDS f4v *)(uintptr_t)tstage;
+            for (int k = 0; k < pc; k += 4) {  // four boxes = six 16-byte reads; boxes past the list are masked off below
+              float tb[24];
+#pragma unroll
+              for (int i = 0; i < 6; i++) {
+                const f4v q = t4[(k >> 2) * 6 + i];
+                tb[i * 4 + 0] = q.x; tb[i * 4 + 1] = q.y; tb[i * 4 + 2] = q.z; tb[i * 4 + 3] = q.w;
+              }
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                if (subtree_may_hit(tb + j * 6, f32, sxl != 0, syl != 0, szl != 0)) cand |= 1u << (k + j);
+              }
+            }
+            cand &= (pc >= 32 ? 0xffffffffu : ((1u << pc) - 1u));
+            if (!in_list) cand = 0u;
+          }
+          // start fetching the candidates' exact boxes and vertices now (both ends of each: they may
+          // straddle a cache line); the loop below finds them on their way.  "+v": one register for all
+          // of these loads, live until after that loop, so that a late arrival lands nowhere else
+          unsigned warm = 0u;
+          {
+            unsigned w = cand;
+            for (int guard = 0; guard < 4 && w != 0u; guard++) {
+              const int k = __builtin_ctz(w);
+              w &= w - 1u;
+              const char *ep = (const char *)(S.tri_aabb + (size_t)(pb + k) * 6);
+              const char *vp = (const char *)(S.tri_vertex + (size_t)(pb + k) * 9);
+              asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:44\n\t"
+                           "global_load_dword %0, %2, off\n\tglobal_load_dword %0, %2, off offset:68"
+                           : "+v"(warm) : "v"(ep), "v"(vp));
+            }
+          }
+          if (STATS) st.bytes_scalar += 24u * (unsigned)pc;
+          // every lane resolves ITS candidates in list order (octtree.cc:177-196): exact box and
+          // vertices are fetched together, one round trip per candidate
+          unsigned mt = 0u, bv = 0u;
+          for (int guard = 0; __ballot(cand != 0u) != 0ull; guard++) {
+            if (guard > kBigNode) {  // cannot happen: one bit per trip
+              status = DEV_ERR_TRAVERSAL_BOUND;
+              break;
+            }
+            if (cand != 0u) {
+              const int t = pb + __builtin_ctz(cand);
+              cand &= cand - 1u;
+              const double *ep = S.tri_aabb + (size_t)t * 6;
+              const double *vp = S.tri_vertex + (size_t)t * 9;
+              const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
+              const double v[9] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
+              bv += 120u;
+              if (slab_pass_lane<false>(e, r)) {
+                mt++;
+                double tt;
+                if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
+                  if (!(best >= 0 && tt > best_t)) {
+                    best = t;
+                    best_t = tt;
+                  }
+                }
+              }
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(warm));  // nothing of the warming loads outlives this point
+          if (status != DEV_OK) break;
+          if (STATS) {
+            if (mt) MT_CNT_ADD(3, mt);
+            if (bv) MT_CNT_ADD(4, bv);
+          }
+#ifdef MT_PROF
+          asm volatile("" :: "v"(best), "v"(best_t));
+          MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc);
+#endif
+        } else if (lm != 0ull) {
+          const unsigned long long mxs = __ballot(in_list && sxl), mys = __ballot(in_list && syl), mzs = __ballot(in_list && szl);
+          const bool one_octant = (mxs == 0 || mxs == lm) && (mys == 0 || mys == lm) && (mzs == 0 || mzs == lm);
+          const int oct = one_octant ? ((mxs != 0 ? 1 : 0) | (mys != 0 ? 2 : 0) | (mzs != 0 ? 4 : 0)) : 8;
+          const int n_in = __builtin_popcountll(lm);
+          const bool blocks_ok = pc >= kBigNode;
+          const int nblk = (pb + pc - 1) / kGroupTris - pb / kGroupTris + 1;
+          const bool transposed = blocks_ok && (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk);
+          ScanOut o{-1, 0.0, 0u};
+          if (transposed) {
+            o = scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in_list, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
+          } else if (in_list) {
+            o = scan_filtered_dispatch<STATS>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
+            if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
+          }
+          if (in_list) {
+            best = o.best;
+            best_t = o.best_t;
+            if (STATS && o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
+            if (STATS && o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
+          }
+#ifdef MT_PROF
+          asm volatile("" :: "v"(best), "v"(best_t));
+          if (transposed) { MT_PROF_END(PROF_HS_TRANS_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_TRANS, 1); }
+          else if (blocks_ok) { MT_PROF_END(PROF_HS_BIG_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_BIG, 1); MT_PROF_COUNT(PROF_HS_BIG_TRIS, pc); }
+          else { MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc); }
+#endif
+        } else {
+          MT_PROF_COUNT(PROF_HS_N_EMPTY, 1);
+        }
+        entering = false;
+        if (any == 0u) {  // a leaf, or nothing to look at below: the node's result is its own list's
+          ret_p = best;
+          ret_t = best_t;
+          slot = lev >= 0 ? node - uniform_i32(h_node[lev * 2 + 1]) : 0;
+          continue;
+        }
+        // open a frame (for ALL lanes: the ones outside m hold "nothing" in it)
+        lev++;
+        if (lev >= L) {  // cannot happen: a node with children is above the deepest level
+          status = DEV_ERR_UNWIND_BOUND;
+          break;
+        }
+        h_own_t[lev * 64 + lane] = best_t;
+        h_own_p[lev * 64 + lane] = best;
+        h_win_p[lev * 64 + lane] = -1;
+        h_node[lev * 2] = node;
+        h_node[lev * 2 + 1] = fc;
+        const int sh = 8 * lev;
+        wantbits = (wantbits & ~(0xffull << sh)) | ((unsigned long long)bits << sh);
+        pend = (pend & ~(0xffull << sh)) | ((unsigned long long)any << sh);
+        ret_p = -1;  // nothing comes back yet
+      } else {
+        if (lev < 0) break;  // ret_* is the root's result
+        MT_PROF_BEGIN(prof_t1);
+        MT_PROF_COUNT(PROF_HS_N_RET, 1);
+        if (__ballot(ret_p >= 0) != 0ull) {
+          MT_PROF_COUNT(PROF_HS_N_RETHIT, 1);
+          // offer child `slot`'s result to frame `lev`: octtree.cc:204-211 (does the
+          // ray enter that child's box, at what distance) and :226-246 (not farther
+          // than the own hit; first in sorted order = smallest (distance, index))
+          const MT_CONST NodeRec *P = as_const(uniform_ptr(S.nodes + uniform_i32(h_node[lev * 2])));
+          if (STATS) st.bytes_scalar += 96u;
+          double amin[3][2], amax[3][2];
+          {
+            const double t0 = (P->lo[0] - r.ox) * r.ix, tc = (P->c[0] - r.ox) * r.ix, t1 = (P->hi[0] - r.ox) * r.ix;
+            amax[0][0] = mx<false>(t0, tc); amin[0][0] = mn<false>(t0, tc);
+            amax[0][1] = mx<false>(tc, t1); amin[0][1] = mn<false>(tc, t1);
+          }
+          {
+            const double t0 = (P->lo[1] - r.oy) * r.iy, tc = (P->c[1] - r.oy) * r.iy, t1 = (P->hi[1] - r.oy) * r.iy;
+            amax[1][0] = mx<false>(t0, tc); amin[1][0] = mn<false>(t0, tc);
+            amax[1][1] = mx<false>(tc, t1); amin[1][1] = mn<false>(tc, t1);
+          }
+          {
+            const double t0 = (P->lo[2] - r.oz) * r.iz, tc = (P->c[2] - r.oz) * r.iz, t1 = (P->hi[2] - r.oz) * r.iz;
+            amax[2][0] = mx<false>(t0, tc); amin[2][0] = mn<false>(t0, tc);
+            amax[2][1] = mx<false>(tc, t1); amin[2][1] = mn<false>(tc, t1);
+          }
+          // child index bits: 0 = x high, 1 = z high, 2 = y high (octtree.cc:61-100)
+          const bool xh = (slot & 1) != 0, zh = (slot & 2) != 0, yh = (slot & 4) != 0;  // wave-uniform
+          const double tmax = mn3<false>(xh ? amax[0][1] : amax[0][0], yh ? amax[1][1] : amax[1][0], zh ? amax[2][1] : amax[2][0]);
+          const double tmin = mx3<false>(xh ? amin[0][1] : amin[0][0], yh ? amin[1][1] : amin[1][0], zh ? amin[2][1] : amin[2][0]);
+          const bool entered = (tmax >= 0.0) & (tmin <= tmax);
+          const int own_p = h_own_p[lev * 64 + lane];
+          const double own_t = h_own_t[lev * 64 + lane];
+          if (ret_p >= 0 && entered && !(own_p >= 0 && ret_t > own_t)) {
+            const int wp = h_win_p[lev * 64 + lane];
+            bool take = wp < 0;
+            if (!take) {
+              const int kw = (int)((unsigned)wp >> 28);
+              const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
+              const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
+              take = (tmin < wmin) || (tmin == wmin && slot < kw);
+            }
+            if (take) {
+              h_win_p[lev * 64 + lane] = ret_p | (slot << 28);
+              h_win_t[lev * 64 + lane] = ret_t;
+            }
+          }
+          // Lanes that hold a candidate drop the children that sort behind it: the reference's
+          // loop would have stopped before them (they could only be looked at, never taken).
+          {
+            const int sh0 = 8 * lev;
+            unsigned rest = (unsigned)(pend >> sh0) & 0xffu;
+            if (rest != 0u) {
+              const int wp = h_win_p[lev * 64 + lane];
+              const int kw = (int)((unsigned)wp >> 28) & 7;
+              const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
+              const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
+              unsigned my = (unsigned)(wantbits >> sh0) & 0xffu;
+              unsigned still = 0u;
+              while (rest != 0u) {
+                const int c2 = __builtin_ctz(rest);
+                rest &= rest - 1u;
+                const bool cxh = (c2 & 1) != 0, czh = (c2 & 2) != 0, cyh = (c2 & 4) != 0;  // wave-uniform
+                const double cmin = mx3<false>(cxh ? amin[0][1] : amin[0][0], cyh ? amin[1][1] : amin[1][0], czh ? amin[2][1] : amin[2][0]);
+                const bool behind = wp >= 0 && !((cmin < wmin) || (cmin == wmin && c2 < kw));
+                if (behind) my &= ~(1u << c2);
+                if (__ballot(((my >> c2) & 1u) != 0u) != 0ull) still |= 1u << c2;
+              }
+              wantbits = (wantbits & ~(0xffull << sh0)) | ((unsigned long long)my << sh0);
+              pend = (pend & ~(0xffull << sh0)) | ((unsigned long long)still << sh0);
+            }
+          }
+        }
+        const int sh = 8 * lev;
+        const unsigned todo = (unsigned)(pend >> sh) & 0xffu;
+        MT_PROF_END(PROF_HS_RET_T, prof_t1);
+        if (todo == 0u) {  // close the frame: octtree.cc:248-256
+          const int wp = h_win_p[lev * 64 + lane];
+          if (wp >= 0) {
+            ret_p = wp & 0x0fffffff;
+            ret_t = h_win_t[lev * 64 + lane];
+          } else {
+            ret_p = h_own_p[lev * 64 + lane];
+            ret_t = h_own_t[lev * 64 + lane];
+          }
+          const int closed = uniform_i32(h_node[lev * 2]);
+          lev--;
+          slot = lev >= 0 ? closed - uniform_i32(h_node[lev * 2 + 1]) : 0;
+          continue;
+        }
+        const int c = pick(todo);
+        pend &= ~(1ull << (sh + c));
+        m = __ballot(((wantbits >> (sh + c)) & 1ull) != 0ull);
+        node = uniform_i32(h_node[lev * 2 + 1]) + c;
+        entering = true;
+      }
+      }
+    }
+    if (want && status == DEV_OK) {
+      out_prim = ret_p;
+      out_t = ret_t;
+    }
+    cur = -1;
+  }
+  if (!hs_done)
+#endif
   // Main loop.  (A) every lane works through the small nodes on its path by
   // itself.  (B) When all lanes wait at big nodes, the wave takes the
   // SHALLOWEST tree level at which some lane waits and scans every distinct
@@ -1899,15 +2340,15 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
             ? scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz)
             : scan_small_lane_call<true, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz);
         if (STATS) {
-          __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)cur_pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          if (o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          if (o.bytes_v) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], o.bytes_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          MT_CNT_ADD(1, 1u);
+          MT_CNT_ADD(2, (unsigned)cur_pc);
+          if (o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
+          if (o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
         }
         unsigned ordw = 0;
         const int fc = cur_fc;
         if (fc != 0) {
-          if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (STATS) MT_CNT_ADD(0, 8u);
           const NodeRec *Np = S.nodes + cur;
           const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
           ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, S.force_mode != 9)
@@ -1915,7 +2356,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
                                                               irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr);
         }
         if (STATS && fc != 0) {  // node planes + record (88 B) and the subtree boxes of the children entered
-          __hip_atomic_fetch_add(&cnt[4 * 64 + lane], 88u + 24u * (((ordw >> 24) & 15u) + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          MT_CNT_ADD(4, 88u + 24u * (((ordw >> 24) & 15u) + 1u));
         }
         finish_node(fc, ordw, o.best, o.best_t);
       }
@@ -2005,10 +2446,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         best = o.best;
         best_t = o.best_t;
         if (STATS) {
-          __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          if (o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          if (o.bytes_v) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], o.bytes_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          MT_CNT_ADD(1, 1u);
+          MT_CNT_ADD(2, (unsigned)pc);
+          if (o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
+          if (o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
         }
       }
     }
@@ -2017,7 +2458,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     if (at) {
       unsigned ordw = 0;
       if (my_fc != 0) {
-        if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (STATS) MT_CNT_ADD(0, 8u);
         const NodeRec *Np = S.nodes + my_node;
         const float *sub = cull ? S.sub_aabb32 + (size_t)my_fc * 6 : nullptr;
         ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, S.force_mode != 9)
@@ -2058,15 +2499,15 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
             ? scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz)
             : scan_small_lane_call<true, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz);
         if (STATS) {
-          __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)cur_pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          if (o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-          if (o.bytes_v) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], o.bytes_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          MT_CNT_ADD(1, 1u);
+          MT_CNT_ADD(2, (unsigned)cur_pc);
+          if (o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
+          if (o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
         }
         unsigned ordw = 0;
         const int fc = cur_fc;
         if (fc != 0) {
-          if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          if (STATS) MT_CNT_ADD(0, 8u);
           const NodeRec *Np = S.nodes + cur;
           const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
 #if MT_DUP == 1
@@ -2077,7 +2518,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
                                                               irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr);
         }
         if (STATS && fc != 0) {  // node planes + record (88 B) and the subtree boxes of the children entered
-          __hip_atomic_fetch_add(&cnt[4 * 64 + lane], 88u + 24u * (((ordw >> 24) & 15u) + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          MT_CNT_ADD(4, 88u + 24u * (((ordw >> 24) & 15u) + 1u));
         }
         finish_node(fc, ordw, o.best, o.best_t);
       }
@@ -2153,7 +2594,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       const ScanOut o = scan_big_vec<STATS>(S, stage_off, lane, pb, pc, in, r, f32, mode == 2, sx, sy, sz);
       best = o.best;
       best_t = o.best_t;
-      if (STATS && in && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (STATS && in && o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
 #ifdef MT_PROF
       MT_PROF_COUNT(PROF_G_GROUPS, __builtin_amdgcn_readfirstlane(o.n_groups));
       MT_PROF_COUNT(PROF_G_LIVE, __builtin_amdgcn_readfirstlane(o.n_live));
@@ -2180,8 +2621,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           : scan_transposed_call<false, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), MT_RAY_ARGS(r));
       best = o.best;
       best_t = o.best_t;
-      if (STATS && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (STATS && o.bytes_v) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], o.bytes_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      if (STATS && o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
+        if (STATS && o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
       MT_PROF_END(PROF_SCAN_TRANSPOSED, prof_t1);
 #ifdef MT_PROF
       MT_PROF_COUNT(PROF_TA_T, __builtin_amdgcn_readfirstlane(o.t_a));
@@ -2195,8 +2636,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     }
     if (in) {
       if (STATS) {
-        __hip_atomic_fetch_add(&cnt[1 * 64 + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        __hip_atomic_fetch_add(&cnt[2 * 64 + lane], (unsigned)pc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        MT_CNT_ADD(1, 1u);
+        MT_CNT_ADD(2, (unsigned)pc);
       }
       if (!transposed && !vec_scan) {
         const int oct = sx | (sy << 1) | (sz << 2);
@@ -2232,8 +2673,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         else o = scan_exact_call<0, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
         best = o.best;
         best_t = o.best_t;
-        if (STATS && o.mt_tests) __hip_atomic_fetch_add(&cnt[3 * 64 + lane], o.mt_tests, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (STATS && o.bytes_v) __hip_atomic_fetch_add(&cnt[4 * 64 + lane], o.bytes_v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (STATS && o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
+        if (STATS && o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
         if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);  // wave-uniform
       }
 #ifdef MT_PROF
@@ -2253,7 +2694,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
 #endif
       unsigned ordw = 0;
       if (fc != 0) {
-        if (STATS) __hip_atomic_fetch_add(&cnt[0 * 64 + lane], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (STATS) MT_CNT_ADD(0, 8u);
         const NodeRec *Np = S.nodes + n;
         const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
 #if MT_DUP == 1
@@ -2293,11 +2734,11 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   o.status = status;
   o.prim = out_prim;
   o.t = out_t;
-  o.box_tests = STATS ? cnt[0 * 64 + lane] : 0u;
-  o.node_visits = STATS ? cnt[1 * 64 + lane] : 0u;
-  o.tri_tests = STATS ? cnt[2 * 64 + lane] : 0u;
-  o.mt_tests = STATS ? cnt[3 * 64 + lane] : 0u;
-  o.bytes_vector = STATS ? cnt[4 * 64 + lane] : 0u;
+  o.box_tests = STATS ? MT_CNT_GET(0) : 0u;
+  o.node_visits = STATS ? MT_CNT_GET(1) : 0u;
+  o.tri_tests = STATS ? MT_CNT_GET(2) : 0u;
+  o.mt_tests = STATS ? MT_CNT_GET(3) : 0u;
+  o.bytes_vector = STATS ? MT_CNT_GET(4) : 0u;
   o.wave_node_steps = st.wave_node_steps;
   o.wave_tri_steps = st.wave_tri_steps;
   o.bytes_scalar = st.bytes_scalar;
