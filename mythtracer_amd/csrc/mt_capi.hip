@@ -651,6 +651,11 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
       }
     }
     for (int k = 0; k < 6; k++) h.own[k] = (float)u[k];
+    for (int k = 0; k < 3; k++) {
+      h.planes[k] = r.lo[k];
+      h.planes[3 + k] = r.c[k];
+      h.planes[6 + k] = r.hi[k];
+    }
   }
   groups.resize(groups.size() + 8 * 6, 0.0f);  // the scan looks four boxes ahead
   int rc;

@@ -5,11 +5,22 @@
 #include <stdint.h>
 #include "mythtracer_hip.h"
 
+// The hit-set traversal (mt_trace.h) is the default for regular rays in the automatic
+// traversal mode; -DMT_NO_HS builds the library with the ordered per-lane descent only
+// (round 1's traversal, still used for irregular rays and the diagnostic modes 1-7).
+#if !defined(MT_NO_HS) && !defined(MT_HS)
+#define MT_HS 1
+#endif
+
 // Waves per SIMD the frame kernels are compiled for (register budget 512 / n per
 // lane: 3 -> 168 VGPRs).  Swept: 2 (256 VGPRs, no spills) and 4 (128) are both
 // slower than 3.
 #ifndef MT_WAVES_PER_SIMD
+#ifdef MT_HS
+#define MT_WAVES_PER_SIMD 2  // the hit-set traversal hides its latencies itself and wants the registers and the LDS
+#else
 #define MT_WAVES_PER_SIMD 3
+#endif
 #endif
 
 namespace mt {
@@ -51,9 +62,12 @@ struct HsRec {
   int32_t first_child, prim_begin, prim_count, child_mask;
   float kid[8][6];
   float own[6];
-  float pad[6];
+  float pad[2];
+  double planes[9];  // lo xyz, centre xyz, hi xyz (NodeRec): the children's exact boxes
+  double pad2;
 };
-static_assert(sizeof(HsRec) == 256, "HsRec must be 256 bytes");
+static_assert(sizeof(HsRec) == 320, "HsRec must be 320 bytes");
+constexpr int kHsRecLanes = 20;  // 16 bytes per lane
 
 struct DevTexture {
   const void *texels;
@@ -180,7 +194,8 @@ __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
 #ifdef MT_HS
   if (depth <= kHsMaxDepth && depth > 1) {
     // frames, (node, first child) per level, two staged records (16-byte aligned)
-    const size_t hs = (((size_t)(depth - 1) * (64 * 24 + 8) + 15) & ~(size_t)15) + 2 * sizeof(HsRec);
+    // ... and per level the nine planes of the frame's node (80 bytes)
+    const size_t hs = (((size_t)(depth - 1) * (64 * 24 + 8) + 15) & ~(size_t)15) + 2 * sizeof(HsRec) + (size_t)(depth - 1) * 80;
     if (hs > n) n = hs;
   }
 #endif

@@ -636,6 +636,100 @@ __device__ __forceinline__ void scan_quad(const DevScene &S, const RayRegs &r, c
   }
 }
 
+template <bool EX>
+__device__ __forceinline__ bool slab_pass_lane(const double *b, const RayRegs &r);
+// ---- "fused" variant of the filtered scan (hit-set traversal) ------------------
+// The fp32 verdicts of a quad only mark per-lane CANDIDATES (bit = stream position
+// relative to `base`, at most 64 at a time); resolve_candidates then lets every
+// lane work through ITS candidates in stream order -- exact fp64 box and the
+// vertices fetched together, one round trip per candidate, all lanes and boxes
+// in flight at once -- instead of one wave-uniform scalar fetch per surviving box
+// followed by a parked Möller–Trumbore pass.  Same tests on the same triangles in
+// the same order per lane (octtree.cc:177-196), so the same result.
+template <int OCT>
+__device__ __forceinline__ void mark_quad(const Filter32 &f, const QuadRegs &q, int k, int pc, int rel, int lane,
+                                          unsigned long long &cand) {
+  const float b0[6] = {q.lo[0], q.lo[1], q.lo[2], q.lo[3], q.lo[4], q.lo[5]};
+  const float b1[6] = {q.lo[6], q.lo[7], q.lo[8], q.lo[9], q.lo[10], q.lo[11]};
+  const float b2[6] = {q.lo[12], q.lo[13], q.lo[14], q.lo[15], q.hi[0], q.hi[1]};
+  const float b3[6] = {q.hi[2], q.hi[3], q.hi[4], q.hi[5], q.hi[6], q.hi[7]};
+  unsigned long long m[4];
+  m[0] = filter32_pass<OCT>(b0, f);
+  m[1] = (k + 1 < pc) ? filter32_pass<OCT>(b1, f) : 0ull;
+  m[2] = (k + 2 < pc) ? filter32_pass<OCT>(b2, f) : 0ull;
+  m[3] = (k + 3 < pc) ? filter32_pass<OCT>(b3, f) : 0ull;
+  if ((m[0] | m[1] | m[2] | m[3]) == 0ull) return;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    if (m[j] == 0ull) continue;  // wave-uniform
+    cand |= ((m[j] >> lane) & 1ull) << (rel + j);
+  }
+}
+
+template <bool STATS>
+__device__ __forceinline__ void resolve_candidates(const DevScene &S, const RayRegs &r, int base,
+                                                   unsigned long long &cand, int &best, double &best_t,
+                                                   LaneStats &st) {
+  for (int guard = 0; guard < 64 && __ballot(cand != 0ull) != 0ull; guard++) {
+    if (cand != 0ull) {
+      const int t = base + __builtin_ctzll(cand);
+      cand &= cand - 1ull;
+      const double *ep = S.tri_aabb + (size_t)t * 6;
+      const double *vp = S.tri_vertex + (size_t)t * 9;
+      const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
+      const double v[9] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
+      if (STATS) st.v[ST_BYTES_VECTOR] += 120u;
+      if (slab_pass_lane<false>(e, r)) {
+        if (STATS) st.v[ST_MT_TESTS]++;
+        double tt;
+        if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
+          if (!(best >= 0 && tt > best_t)) {
+            best = t;
+            best_t = tt;
+          }
+        }
+      }
+    }
+  }
+  cand = 0ull;
+}
+
+template <int OCT, bool STATS>
+__device__ __forceinline__ void scan_node_fused(const DevScene &S, const RayRegs &r, const Filter32 &f, int pb,
+                                                int pc, int &best, double &best_t, LaneStats &st) {
+  if (pc <= 0) return;
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const MT_CONST float *p = as_const(S.tri_aabb32) + (size_t)pb * 6;
+  unsigned long long cand = 0ull;
+  int base = pb;
+  QuadRegs A, B;
+  issue_quad(A, p);
+  await_quad(A);
+  if (STATS) st.bytes_scalar += 96u * (unsigned)((pc + 3) / 4 + 1);
+  for (int k = 0;;) {
+    issue_quad(B, p + 24);  // unconditional look-ahead: the stream is padded
+    if (pb + k - base > 60) {
+      resolve_candidates<STATS>(S, r, base, cand, best, best_t, st);
+      base = pb + k;
+    }
+    mark_quad<OCT>(f, A, k, pc, pb + k - base, lane, cand);
+    await_quad(B);
+    k += 4;
+    if (k >= pc) break;
+    p += 48;
+    issue_quad(A, p);
+    if (pb + k - base > 60) {
+      resolve_candidates<STATS>(S, r, base, cand, best, best_t, st);
+      base = pb + k;
+    }
+    mark_quad<OCT>(f, B, k, pc, pb + k - base, lane, cand);
+    await_quad(A);
+    k += 4;
+    if (k >= pc) break;
+  }
+  if (__ballot(cand != 0ull) != 0ull) resolve_candidates<STATS>(S, r, base, cand, best, best_t, st);
+}
+
 // Ray-parallel scan with the fp32 pre-filter (octant-uniform mode only).
 template <int OCT, bool STATS>
 __device__ __forceinline__ void scan_node_filtered(const DevScene &S, const RayRegs &r,
@@ -1381,7 +1475,7 @@ __device__ __forceinline__ ScanOut scan_small_lane_f32_call(const DevScene *self
   return o;
 }
 
-template <int OCT, bool STATS>
+template <int OCT, bool STATS, bool FUSED = false>
 __device__ __attribute__((noinline)) ScanOut scan_filtered_call(const DevScene *self, int pb, int pc,
                                                                 MT_RAY_PARAMS, MT_F32_PARAMS) {
   MT_RAY_FROM_PARAMS(r);
@@ -1390,7 +1484,8 @@ __device__ __attribute__((noinline)) ScanOut scan_filtered_call(const DevScene *
   LaneStats st;
   st.clear();
   ScanOut o{-1, 0.0, 0u};
-  scan_node_filtered<OCT, STATS>(S, r, f, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
+  if constexpr (FUSED) scan_node_fused<OCT, STATS>(S, r, f, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
+  else scan_node_filtered<OCT, STATS>(S, r, f, uniform_i32(pb), uniform_i32(pc), o.best, o.best_t, st);
   o.mt_tests = st.v[ST_MT_TESTS];
   o.bytes_v = st.v[ST_BYTES_VECTOR];
   o.bytes_s = st.bytes_scalar;
@@ -1406,7 +1501,7 @@ __device__ __attribute__((noinline)) ScanOut scan_filtered_call(const DevScene *
 // monotonic), so skipping the block changes nothing.  Runs are visited in list
 // order and folded with the reference's rule (octtree.cc:186-194: a later hit
 // wins unless it is strictly farther).
-template <int OCT, bool STATS>
+template <int OCT, bool STATS, bool FUSED = false>
 __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *self, int pb, int pc,
                                                                MT_RAY_PARAMS, MT_F32_PARAMS) {
   MT_RAY_FROM_PARAMS(r);
@@ -1443,7 +1538,8 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
       if (first < pb) first = pb;
       if (last > pb + pc) last = pb + pc;
       // in list order, best / best_t running through (octtree.cc:186-194)
-      scan_node_filtered<OCT, STATS>(S, r, f, first, last - first, o.best, o.best_t, st);
+      if constexpr (FUSED) scan_node_fused<OCT, STATS>(S, r, f, first, last - first, o.best, o.best_t, st);
+      else scan_node_filtered<OCT, STATS>(S, r, f, first, last - first, o.best, o.best_t, st);
 #ifdef MT_PROF
       o.n_ranges++;
       o.n_live += (unsigned)len;
@@ -1640,29 +1736,29 @@ __device__ __attribute__((noinline)) ScanOut scan_transposed_blocks_call(const D
   return o;
 }
 
-template <bool STATS>
+template <bool STATS, bool FUSED = false>
 __device__ __forceinline__ ScanOut scan_filtered_dispatch(const DevScene &S, int oct, const float *g32,
                                                           int pb, int pc, const RayRegs &r,
                                                           const Filter32 &f) {
   switch (oct) {
-    case 0: return (g32 ? scan_grouped_call<0, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
-                        : scan_filtered_call<0, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
-    case 1: return (g32 ? scan_grouped_call<1, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
-                        : scan_filtered_call<1, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
-    case 2: return (g32 ? scan_grouped_call<2, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
-                        : scan_filtered_call<2, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
-    case 3: return (g32 ? scan_grouped_call<3, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
-                        : scan_filtered_call<3, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
-    case 4: return (g32 ? scan_grouped_call<4, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
-                        : scan_filtered_call<4, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
-    case 5: return (g32 ? scan_grouped_call<5, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
-                        : scan_filtered_call<5, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
-    case 6: return (g32 ? scan_grouped_call<6, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
-                        : scan_filtered_call<6, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
-    case 7: return (g32 ? scan_grouped_call<7, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
-                        : scan_filtered_call<7, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
-    default: return (g32 ? scan_grouped_call<8, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
-                        : scan_filtered_call<8, STATS>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 0: return (g32 ? scan_grouped_call<0, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<0, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 1: return (g32 ? scan_grouped_call<1, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<1, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 2: return (g32 ? scan_grouped_call<2, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<2, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 3: return (g32 ? scan_grouped_call<3, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<3, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 4: return (g32 ? scan_grouped_call<4, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<4, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 5: return (g32 ? scan_grouped_call<5, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<5, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 6: return (g32 ? scan_grouped_call<6, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<6, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    case 7: return (g32 ? scan_grouped_call<7, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<7, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
+    default: return (g32 ? scan_grouped_call<8, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f))
+                        : scan_filtered_call<8, STATS, FUSED>(S.self, pb, pc, MT_RAY_ARGS(r), MT_F32_ARGS(f)));
   }
 }
 
@@ -1935,6 +2031,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     MT_LDS int *const h_win_p = h_own_p + L * 64;                          // [L][64] candidate triangle | child slot << 28, -1 none
     MT_LDS int *const h_node = h_win_p + L * 64;                           // [L][2] wave-uniform: node, its first child
     const unsigned stage = ((unsigned)(uintptr_t)(h_node + L * 2) + 15u) & ~15u;  // two staged HsRec
+    MT_LDS double *const h_planes = (MT_LDS double *)(uintptr_t)(stage + 2u * (unsigned)sizeof(HsRec));  // [L][10] wave-uniform
     const unsigned tstage = frames_end;                                    // 32 staged fp32 triangle boxes (768 B)
     const char *const hs_bytes = (const char *)S.hs_rec;
     int lev = -1;                        // frame on top of the stack, -1 none
@@ -1949,7 +2046,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // Records are staged one node ahead: `staged[b]` = node whose record is (being) copied to buffer b.
     int buf = 0, staged0 = -1, staged1 = -1;
     auto hs_fetch = [&](int nd, int b) {
-      if (lane < 16) lds_dma16(hs_bytes + (size_t)nd * sizeof(HsRec) + (size_t)lane * 16, stage + (unsigned)b * (unsigned)sizeof(HsRec));
+      if (lane < kHsRecLanes) lds_dma16(hs_bytes + (size_t)nd * sizeof(HsRec) + (size_t)lane * 16, stage + (unsigned)b * (unsigned)sizeof(HsRec));
       if (b == 0) staged0 = nd; else staged1 = nd;
     };
     // Children are looked at near to far for the octant of the wave's first ray (child index
@@ -2035,25 +2132,32 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         // own list) are read in one batch and tested without branches.
         typedef float f4v __attribute__((ext_vector_type(4)));
         const MT_LDS f4v *r4 = (const MT_LDS f4v *)(uintptr_t)rec;
-        float bxs[56];
-#pragma unroll
-        for (int i = 0; i < 14; i++) {
-          const f4v q = r4[1 + i];
-          bxs[i * 4 + 0] = q.x; bxs[i * 4 + 1] = q.y; bxs[i * 4 + 2] = q.z; bxs[i * 4 + 3] = q.w;
-        }
         unsigned bits = 0u, any = 0u;
+        if (cm != 0u) {  // (most nodes a wave enters are leaves)
+          float bxs[48];
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-          const bool pass = subtree_may_hit(bxs + c * 6, f32, sxl != 0, syl != 0, szl != 0);
-          if (pass) bits |= 1u << c;
-        }
-        bits = in ? (bits & cm) : 0u;  // (cm: children with an empty subtree hold an inverted box anyway)
+          for (int i = 0; i < 12; i++) {
+            const f4v q = r4[1 + i];
+            bxs[i * 4 + 0] = q.x; bxs[i * 4 + 1] = q.y; bxs[i * 4 + 2] = q.z; bxs[i * 4 + 3] = q.w;
+          }
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-          if (__ballot(((bits >> c) & 1u) != 0u) != 0ull) any |= 1u << c;
+          for (int c = 0; c < 8; c++) {
+            const bool pass = subtree_may_hit(bxs + c * 6, f32, sxl != 0, syl != 0, szl != 0);
+            if (pass) bits |= 1u << c;
+          }
+          bits = in ? (bits & cm) : 0u;  // (cm: children with an empty subtree hold an inverted box anyway)
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            if (__ballot(((bits >> c) & 1u) != 0u) != 0ull) any |= 1u << c;
+          }
         }
         // the own list's union box decides who scans it
-        const bool in_list = in && pc > 0 && subtree_may_hit(bxs + 48, f32, sxl != 0, syl != 0, szl != 0);
+        bool in_list = false;
+        if (pc > 0) {
+          const f4v q0 = r4[13], q1 = r4[14];
+          const float ob[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+          in_list = in && subtree_may_hit(ob, f32, sxl != 0, syl != 0, szl != 0);
+        }
         const unsigned long long lm = __ballot(in_list);
         // stage the record of the node that comes next while this one's list is scanned
         bool fetched_next = false;
@@ -2161,7 +2265,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           if (transposed) {
             o = scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in_list, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
           } else if (in_list) {
-            o = scan_filtered_dispatch<STATS>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
+            o = scan_filtered_dispatch<STATS, true>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
             if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
           }
           if (in_list) {
@@ -2197,6 +2301,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         h_win_p[lev * 64 + lane] = -1;
         h_node[lev * 2] = node;
         h_node[lev * 2 + 1] = fc;
+        if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + 240u))[lane];
         const int sh = 8 * lev;
         wantbits = (wantbits & ~(0xffull << sh)) | ((unsigned long long)bits << sh);
         pend = (pend & ~(0xffull << sh)) | ((unsigned long long)any << sh);
@@ -2210,8 +2315,14 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           // offer child `slot`'s result to frame `lev`: octtree.cc:204-211 (does the
           // ray enter that child's box, at what distance) and :226-246 (not farther
           // than the own hit; first in sorted order = smallest (distance, index))
-          const MT_CONST NodeRec *P = as_const(uniform_ptr(S.nodes + uniform_i32(h_node[lev * 2])));
-          if (STATS) st.bytes_scalar += 96u;
+          struct { double lo[3], c[3], hi[3]; } Pv;
+          {
+            const MT_LDS double *pl = h_planes + lev * 10;
+            Pv.lo[0] = pl[0]; Pv.lo[1] = pl[1]; Pv.lo[2] = pl[2];
+            Pv.c[0] = pl[3]; Pv.c[1] = pl[4]; Pv.c[2] = pl[5];
+            Pv.hi[0] = pl[6]; Pv.hi[1] = pl[7]; Pv.hi[2] = pl[8];
+          }
+          const auto *P = &Pv;
           double amin[3][2], amax[3][2];
           {
             const double t0 = (P->lo[0] - r.ox) * r.ix, tc = (P->c[0] - r.ox) * r.ix, t1 = (P->hi[0] - r.ox) * r.ix;

@@ -43,16 +43,20 @@ def engine(request, monkeypatch):
     return request.param
 
 
-PRUNED = ("box_tests", "node_visits", "tri_tests")
+PRUNED = ("box_tests", "node_visits", "tri_tests", "mt_tests")
 
 
 def counters_match(got, want):
-    """Default traversal mode: every ray count, Möller–Trumbore test and shaded
-    hit equals the oracle's; the box / node / triangle-filter evaluations can only
-    be fewer, because subtrees the ray provably cannot hit are not visited
-    (mode 7 visits them all: test_counters_equal_the_oracle)."""
+    """Default traversal mode: every ray count and shaded hit equals the oracle's.
+    The four work counters (box / node / triangle-filter / Möller–Trumbore
+    evaluations) are the traversal's OWN work there: subtrees a ray provably
+    cannot hit are not visited, and the hit-set traversal may look at a node that
+    lies behind the reference's early exit (never the other way round: every
+    triangle the reference puts through Möller–Trumbore is put through it here).
+    Mode 7 reproduces the reference's counts exactly: test_counters_equal_the_oracle."""
     assert {k: v for k, v in got.items() if k not in PRUNED} == {k: v for k, v in want.items() if k not in PRUNED}
-    assert all(got[k] <= want[k] for k in PRUNED if k in got), (got, want)
+    if "mt_tests" in got and "mt_tests" in want:
+        assert got["mt_tests"] >= want["mt_tests"], (got, want)
 
 
 def load(name):
@@ -236,6 +240,9 @@ def test_c_abi_render_direct_and_modes(scenes):
                 assert np.array_equal(r["point"], base[2], equal_nan=True), mode
                 if mode in (1, 2, 4, 7):
                     assert key == base[3], mode
+                elif mode == 0:  # the automatic mode's work counters are its own (counters_match)
+                    counters_match(key, base[3])
+                    assert key["node_visits"] < base[3]["node_visits"], mode
                 else:
                     assert all(key[k] == base[3][k] for k in ALL_KEYS if k not in pruned), mode
                     assert all(0 < key[k] <= base[3][k] for k in pruned), mode
@@ -378,7 +385,10 @@ def test_random_triangle_soups_all_modes(seed):
         assert np.array_equal(got["line"], want["line"]), mode
         assert np.array_equal(got["t"][hit], want["t"][hit]), mode
         assert np.array_equal(got["point"][hit], want["point"][hit]), mode
-        assert got["stats"]["mt_tests"] == want["counters"]["mt_tests"], mode
+        if mode == 0:  # the automatic mode may look behind the reference's early exit (counters_match)
+            assert got["stats"]["mt_tests"] >= want["counters"]["mt_tests"], mode
+        else:
+            assert got["stats"]["mt_tests"] == want["counters"]["mt_tests"], mode
         if mode in (1, 2, 4, 7):
             assert all(got["stats"][k] == want["counters"][k] for k in PRUNED), mode
 
@@ -817,6 +827,7 @@ def test_work_counters_can_be_switched_off(scenes):
         # a host call that asks for statistics counts whatever the switch says
         abi.set_stats(h, False)
         again = abi.render_chunk(h, sens, 200, 112)
-        assert {k: again["stats"][k] for k in ALL_KEYS} == {k: want["stats"][k] for k in ALL_KEYS}
+        # (the work counters of the automatic mode depend on which rays share a wave)
+        assert {k: again["stats"][k] for k in ALL_KEYS if k not in PRUNED} == {k: want["stats"][k] for k in ALL_KEYS if k not in PRUNED}
     finally:
         abi.scene_destroy(h)
