@@ -333,10 +333,15 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (history) {
       float quad_share = 0.8f;  // blocks above this share of an even split are cut into quarters
       if (const char *e = getenv("MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
+      float quad_keep = 1.0f;   // ... and stay so above this fraction of that threshold (1 = no hysteresis: swept, scripts/quad_sweep.py --
+                                // settings that steady the repeated frame cost the moving camera 50 %)
+      if (const char *e = getenv("MT_DEBUG_QUAD_KEEP")) quad_keep = (float)atof(e);
+      float quad_work = 1.7f;   // work of a block rendered as quarters / rendered whole
+      if (const char *e = getenv("MT_DEBUG_QUAD_WORK")) quad_work = (float)atof(e);
       hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
-                         reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : 1.7f, 3.0f, 16000u);
+                         reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f, 16000u);
       hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
-                         s->grid_blocks * s->waves_per_block, quad_share);
+                         s->grid_blocks * s->waves_per_block, quad_share, quad_keep);
     } else if (s->stats_enabled) {
       hipLaunchKernelGGL(primary_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
     } else {

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
   for (int b = tid; b < kPoolSchedBuckets; b += kPoolSchedThreads) s_count[b] = 0u;
   __syncthreads();
   unsigned long long part = 0ull;
-  for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) part += P.item_forecast[i];
+  for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) part += P.item_forecast[i] & 0x7fffffffu;  // (bit 31: a note for the state machine's scheduler)
   atomicAdd(&s_sum, part);
   __syncthreads();
   const float share = (float)s_sum / (float)(n_waves > 0 ? n_waves : 1);
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
   for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) {
     int level;
     unsigned unit;
-    sched_decide(P.item_cost[i], P.item_forecast[i], cut_above, sp, level, unit);
+    sched_decide(P.item_cost[i], P.item_forecast[i] & 0x7fffffffu, cut_above, sp, level, unit);
     atomicAdd(&s_count[pool_cost_bucket(unit)], level == 0 ? 1u : (level == 1 ? 4u : 16u));
   }
   __syncthreads();
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
   for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) {
     int level;
     unsigned unit;
-    sched_decide(P.item_cost[i], P.item_forecast[i], cut_above, sp, level, unit);
+    sched_decide(P.item_cost[i], P.item_forecast[i] & 0x7fffffffu, cut_above, sp, level, unit);
     const unsigned n = level == 0 ? 1u : (level == 1 ? 4u : 16u);
     const unsigned at = atomicAdd(&s_start[pool_cost_bucket(unit)], n);
     for (unsigned q = 0; q < n; q++) {

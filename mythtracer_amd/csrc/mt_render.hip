@@ -259,7 +259,8 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
     return (unsigned)((word >> 31) ? c / w1 : c);
   };
   if (!reproject) {
-    P.item_forecast[i] = cost_of(P.item_cost[i]);
+    // (bit 31, state machine only: the block was rendered as quarters -- schedule_kernel's hysteresis)
+    P.item_forecast[i] = cost_of(P.item_cost[i]) | (pool ? 0u : (P.item_cost[i] & 0x80000000u));
     return;
   }
   const int per_tile = P.blocks_x * P.blocks_y;
@@ -322,7 +323,7 @@ __device__ __forceinline__ int cost_bucket(unsigned c) {  // descending cost = a
   const int f = e >= 3 ? (int)((c >> (e - 3)) & 7u) : 0;      // eighth within it
   return kSchedBuckets - 1 - (e * 8 + f);
 }
-__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves, float quad_share) {
+__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves, float quad_share, float quad_keep_share) {
   __shared__ unsigned long long s_sum;
   __shared__ unsigned s_count[kSchedBuckets];
   __shared__ unsigned s_start[kSchedBuckets];
@@ -332,17 +333,21 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
   __syncthreads();
   // (forecast_kernel has scaled the costs measured in quad mode -- sums over four
   // quarters, kQuadWork = 1.7 -- back to whole blocks)
-  const float kQuadShare = quad_share, kQuarterTime = 0.45f;
+  const float kQuadShare = quad_share, kQuarterTime = 0.45f, kQuadKeep = quad_keep_share;
   unsigned long long part = 0ull;
-  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) part += P.item_forecast[i];
+  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) part += P.item_forecast[i] & 0x7fffffffu;
   atomicAdd(&s_sum, part);
   __syncthreads();
   const float share = (float)s_sum / (float)(n_waves > 0 ? n_waves : 1);
   const float quad_above = share * kQuadShare;
+  // a block that was rendered as quarters stays so until its forecast falls well below the
+  // threshold: the scaled-back sum of four quarters and the cost of the whole block are two
+  // different measurements, and a block near the threshold would change its form every frame
+  const float quad_keep = quad_above * kQuadKeep;
   // pass 1: bucket counts (a quad block contributes four units)
   for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
-    const unsigned c = P.item_forecast[i];
-    const bool quad = (float)c > quad_above && c > 0u;
+    const unsigned c = P.item_forecast[i] & 0x7fffffffu;
+    const bool quad = (float)c > ((P.item_forecast[i] >> 31) ? quad_keep : quad_above) && c > 0u;
     const unsigned unit = quad ? (unsigned)((float)c * kQuarterTime) : c;
     atomicAdd(&s_count[cost_bucket(unit)], quad ? 4u : 1u);
   }
@@ -359,8 +364,8 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
   // pass 2: scatter, and reset the costs for the coming frame (bit 31 notes
   // that the block will be measured as quarters)
   for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
-    const unsigned c = P.item_forecast[i];
-    const bool quad = (float)c > quad_above && c > 0u;
+    const unsigned c = P.item_forecast[i] & 0x7fffffffu;
+    const bool quad = (float)c > ((P.item_forecast[i] >> 31) ? quad_keep : quad_above) && c > 0u;
     const unsigned unit = quad ? (unsigned)((float)c * kQuarterTime) : c;
     const unsigned at = atomicAdd(&s_start[cost_bucket(unit)], quad ? 4u : 1u);
     if (quad) {
