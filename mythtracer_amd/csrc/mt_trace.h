@@ -121,6 +121,10 @@ __device__ __forceinline__ double mx3(double a, double b, double c) {
 // Arguments of a non-inlined device function arrive in VGPRs; these put a
 // wave-uniform value back into SGPRs so that it can feed scalar loads.
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
 template <typename T>
 __device__ __forceinline__ T *uniform_ptr(T *p) {
   const unsigned long long v = (unsigned long long)(uintptr_t)p;
@@ -1893,7 +1897,7 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
     if (flip & 1u) t = ((t & 0x55u) << 1) | ((t >> 1) & 0x55u);
     if (flip & 2u) t = ((t & 0x33u) << 2) | ((t >> 2) & 0x33u);
     if (flip & 4u) t = ((t & 0x0fu) << 4) | ((t >> 4) & 0x0fu);
-    return (int)((unsigned)__builtin_ctz(t) ^ flip);
+    return uniform_i32((int)((unsigned)__builtin_ctz(t) ^ flip));
   };
   // the node the wave enters after the current one if nothing below it is entered
   auto next_after = [&](int l, unsigned long long pd) -> int {
@@ -1919,8 +1923,8 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
     staged0 = uniform_i32(staged0);
     staged1 = uniform_i32(staged1);
     entering = uniform_i32(entering ? 1 : 0) != 0;
-    pend = ((unsigned long long)(unsigned)uniform_i32((int)(pend >> 32)) << 32) | (unsigned)uniform_i32((int)pend);
-    m = ((unsigned long long)(unsigned)uniform_i32((int)(m >> 32)) << 32) | (unsigned)uniform_i32((int)m);
+    pend = uniform_u64(pend);
+    m = uniform_u64(m);
     if (entering) {
       const bool in = ((m >> lane) & 1ull) != 0ull;
       MT_PROF_BEGIN(prof_t1);
@@ -1980,6 +1984,7 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
         for (int c = 0; c < 8; c++) {
           if (__ballot(((bits >> c) & 1u) != 0u) != 0ull) any |= 1u << c;
         }
+        any = (unsigned)uniform_i32((int)any);
       }
       // the own list's union box decides who scans it
       bool in_list = false;
@@ -1992,7 +1997,7 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
       // stage the record of the node that comes next while this one's list is scanned
       bool fetched_next = false;
       {
-        const int nxt = any != 0u ? fc + pick(any) : next_after(lev, pend);
+        const int nxt = uniform_i32(any != 0u ? fc + pick(any) : next_after(lev, pend));
         if (nxt >= 0) {
           hs_fetch(nxt, buf ^ 1);
           fetched_next = true;
@@ -2134,7 +2139,7 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
       if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + 240u))[lane];
       const int sh = 8 * lev;
       wantbits = (wantbits & ~(0xffull << sh)) | ((unsigned long long)bits << sh);
-      pend = (pend & ~(0xffull << sh)) | ((unsigned long long)any << sh);
+      pend = uniform_u64((pend & ~(0xffull << sh)) | ((unsigned long long)any << sh));
       ret_p = -1;  // nothing comes back yet
     } else {
       if (lev < 0) break;  // ret_* is the root's result
@@ -2194,7 +2199,7 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
         // loop would have stopped before them (they could only be looked at, never taken).
         {
           const int sh0 = 8 * lev;
-          unsigned rest = (unsigned)(pend >> sh0) & 0xffu;
+          unsigned rest = (unsigned)uniform_i32((int)((unsigned)(pend >> sh0) & 0xffu));
           if (rest != 0u) {
             const int wp = h_win_p[lev * 64 + lane];
             const int kw = (int)((unsigned)wp >> 28) & 7;
@@ -2212,12 +2217,12 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
               if (__ballot(((my >> c2) & 1u) != 0u) != 0ull) still |= 1u << c2;
             }
             wantbits = (wantbits & ~(0xffull << sh0)) | ((unsigned long long)my << sh0);
-            pend = (pend & ~(0xffull << sh0)) | ((unsigned long long)still << sh0);
+            pend = uniform_u64((pend & ~(0xffull << sh0)) | ((unsigned long long)still << sh0));
           }
         }
       }
       const int sh = 8 * lev;
-      const unsigned todo = (unsigned)(pend >> sh) & 0xffu;
+      const unsigned todo = (unsigned)uniform_i32((int)((unsigned)(pend >> sh) & 0xffu));
       MT_PROF_END(PROF_HS_RET_T, prof_t1);
       if (todo == 0u) {  // close the frame: octtree.cc:248-256
         const int wp = h_win_p[lev * 64 + lane];
@@ -2230,11 +2235,11 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
         }
         const int closed = uniform_i32(h_node[lev * 2]);
         lev--;
-        slot = lev >= 0 ? closed - uniform_i32(h_node[lev * 2 + 1]) : 0;
+        slot = uniform_i32(lev >= 0 ? closed - uniform_i32(h_node[lev * 2 + 1]) : 0);
         continue;
       }
       const int c = pick(todo);
-      pend &= ~(1ull << (sh + c));
+      pend = uniform_u64(pend & ~(1ull << (sh + c)));
       m = __ballot(((wantbits >> (sh + c)) & 1ull) != 0ull);
       node = uniform_i32(h_node[lev * 2 + 1]) + c;
       entering = true;

@@ -368,6 +368,13 @@ def test_random_triangle_soups_all_modes(seed):
         elif kind == 2:  # origin on lattice planes
             org = [float(round(x)) for x in org]
             d = [rnd.rng(-1, 1) for _ in range(3)]
+        elif kind == 3:  # lattice origin, diagonal direction with power-of-two ratios: regular rays whose
+            #              entry distances into sibling boxes tie exactly (order by index, octtree.cc:213-216)
+            org = [float(round(x)) for x in org]
+            d = [(1.0 if rnd.rng(0, 1) < 0.5 else -1.0) * (1.0, 2.0, 4.0)[int(rnd.rng(0, 3)) % 3] for _ in range(3)]
+        elif kind == 4:  # from one lattice point towards another, no zero component
+            org = [float(round(x)) for x in org]
+            d = [float(round(rnd.rng(1, 40))) * (1.0 if rnd.rng(0, 1) < 0.5 else -1.0) for _ in range(3)]
         else:
             tgt = [rnd.rng(0, 64) for _ in range(3)]
             d = [tgt[a] - org[a] for a in range(3)]
