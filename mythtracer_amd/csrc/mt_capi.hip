@@ -215,11 +215,13 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   int engine = s->engine;
   if (const char *e = getenv("MT_ENGINE")) engine = atoi(e);
   if (engine != 1 && engine != 2) {
-    float per_wave = 6.0f;  // blocks per wave below which a launch is taken to be tail-bound
+    // blocks per wave below which a launch is taken to be tail-bound (one rank's share of the 4K frame
+    // at N = 8 has 7.9 per wave: ray pool 4.4 ms, state machine 4.7; at N = 4, 15.8: 7.3 against 6.6)
+    float per_wave = 9.0f;
     if (const char *e = getenv("MT_DEBUG_POOL_BELOW")) per_wave = (float)atof(e);
     // ... and the first frame of a geometry: without measured costs the order
     // of the work is a guess, and the pool's short pixel chains forgive a bad
-    // guess (13 ms against the state machine's 15.5 on the 1080p frame)
+    // guess (12 ms against the state machine's 14.5 on the 1080p frame)
     engine = (!have_costs || (float)P.n_items < per_wave * (float)waves) ? 2 : 1;
   }
   const bool pool_engine = engine == 2;

@@ -43,6 +43,9 @@
 namespace mt {
 
 #define MT_CONST __attribute__((address_space(4)))
+#ifndef MT_KNOCK
+#define MT_KNOCK 0  // timing experiments only: 1 = no big-list scans, 2 = no small-list scans (wrong images)
+#endif
 #ifndef MT_DUP
 #define MT_DUP 0  // diagnostic: execute one section of the traversal twice (timing experiments only)
 #endif
@@ -1998,7 +2001,7 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
       bool fetched_next = false;
       {
         const int nxt = uniform_i32(any != 0u ? fc + pick(any) : next_after(lev, pend));
-        if (nxt >= 0) {
+        if (nxt >= 0 && MT_KNOCK != 3) {
           hs_fetch(nxt, buf ^ 1);
           fetched_next = true;
         }
@@ -2011,7 +2014,7 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
 #endif
       int best = -1;
       double best_t = 0.0;
-      if (small_list && lm != 0ull) {
+      if (small_list && lm != 0ull && MT_KNOCK != 2) {
         // the boxes were requested before the next node's record: all but that last copy must have landed
         if (fetched_next) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2088,7 +2091,7 @@ __device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, uns
         asm volatile("" :: "v"(best), "v"(best_t));
         MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc);
 #endif
-      } else if (lm != 0ull) {
+      } else if (lm != 0ull && MT_KNOCK != 1) {
         const unsigned long long mxs = __ballot(in_list && sxl), mys = __ballot(in_list && syl), mzs = __ballot(in_list && szl);
         const bool one_octant = (mxs == 0 || mxs == lm) && (mys == 0 || mys == lm) && (mzs == 0 || mzs == lm);
         const int oct = one_octant ? ((mxs != 0 ? 1 : 0) | (mys != 0 ? 2 : 0) | (mzs != 0 ? 4 : 0)) : 8;
