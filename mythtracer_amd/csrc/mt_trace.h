@@ -43,9 +43,6 @@
 namespace mt {
 
 #define MT_CONST __attribute__((address_space(4)))
-#ifndef MT_KNOCK
-#define MT_KNOCK 0  // timing experiments only: 1 = no big-list scans, 2 = no small-list scans (wrong images)
-#endif
 #ifndef MT_DUP
 #define MT_DUP 0  // diagnostic: execute one section of the traversal twice (timing experiments only)
 #endif
@@ -124,10 +121,6 @@ __device__ __forceinline__ double mx3(double a, double b, double c) {
 // Arguments of a non-inlined device function arrive in VGPRs; these put a
 // wave-uniform value back into SGPRs so that it can feed scalar loads.
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
-  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-         (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-}
 template <typename T>
 __device__ __forceinline__ T *uniform_ptr(T *p) {
   const unsigned long long v = (unsigned long long)(uintptr_t)p;
@@ -1806,469 +1799,6 @@ struct TraceOut {
 
 };
 
-#ifdef MT_HS
-// ---- hit-set traversal (regular rays, automatic mode) ---------------------
-// What PrimitiveIntersectRay returns for a node is a function of three things
-// only (octtree.cc:169-257): the best hit of the node's own list; for every
-// child, whether the ray enters its box and at what distance (the sort key);
-// and what the same function returns for the children that hold a hit --
-// children without one `continue` and leave no trace.  The loop over the
-// sorted children takes the FIRST one whose hit is not farther than the own
-// one and stops: with NaN-free keys and a stable sort that is the entered,
-// acceptable child with the smallest (entry distance, index).  So the order
-// in which the children are LOOKED AT is free: here the whole wave walks the
-// tree depth-first in index order, every node once for all lanes whose
-// filter does not rule its subtree out (wave-uniform boxes, scalar loads, no
-// per-lane stack walk, no sort), each child's result is offered to its
-// parent's frame when the wave comes back from it (exact entry test of that
-// one child, comparison with the frame's best candidate so far), and a frame
-// is closed when its last child is done.  Nodes the reference would not have
-// reached (behind its early exit) may be looked at; that changes the work,
-// not the result.
-// A function of its own (called once per traversal): its register allocation is not
-// burdened with the ordered descent's state, which trace_wave keeps for irregular rays.
-template <bool STATS>
-__device__ __attribute__((noinline)) TraceOut hs_walk(const DevScene *scene, unsigned stack_base, int lane,
-                                                      bool at_root, MT_RAY_PARAMS, MT_F32_PARAMS) {
-  MT_RAY_FROM_PARAMS(r);
-  MT_F32_FROM_PARAMS(f32);
-  const MT_CONST DevScene *G = as_const(uniform_ptr(scene));
-  DevScene S;
-  S.tri_aabb = G->tri_aabb;
-  S.tri_aabb32 = G->tri_aabb32;
-  S.grp_aabb32 = G->grp_aabb32;
-  S.hs_rec = G->hs_rec;
-  S.self = uniform_ptr(scene);
-  S.tri_vertex = G->tri_vertex;
-  S.n_nodes = G->n_nodes;
-  S.tree_depth = G->tree_depth;
-  S.pack_shift = G->pack_shift;
-  S.prof = G->prof;
-  stack_base = (unsigned)uniform_i32((int)stack_base);
-  LaneStats st;
-  st.clear();
-  unsigned cntr[5] = {0u, 0u, 0u, 0u, 0u};
-  (void)cntr;
-  MT_PROF_DECL;
-  (void)0;
-  const unsigned frames_end = stack_base + (unsigned)wave_frames_bytes(S.tree_depth, S.pack_shift != 0);
-  const int sxl = __builtin_signbit(r.ix) ? 1 : 0;
-  const int syl = __builtin_signbit(r.iy) ? 1 : 0;
-  const int szl = __builtin_signbit(r.iz) ? 1 : 0;
-  const long long step_bound = 64ll * (long long)S.n_nodes + 64;
-  long long steps = 0;
-  int status = DEV_OK;
-  int ret_p_out = -1;
-  double ret_t_out = 0.0;
-  {
-  const int L = S.tree_depth > 1 ? S.tree_depth - 1 : 0;  // levels that can hold a node with children
-  MT_LDS double *const h_own_t = (MT_LDS double *)(uintptr_t)stack_base;  // [L][64] own list's best distance
-  MT_LDS double *const h_win_t = h_own_t + L * 64;                       // [L][64] best child candidate so far
-  MT_LDS int *const h_own_p = (MT_LDS int *)(h_win_t + L * 64);          // [L][64] own best triangle, -1 none
-  MT_LDS int *const h_win_p = h_own_p + L * 64;                          // [L][64] candidate triangle | child slot << 28, -1 none
-  MT_LDS int *const h_node = h_win_p + L * 64;                           // [L][2] wave-uniform: node, its first child
-  const unsigned stage = ((unsigned)(uintptr_t)(h_node + L * 2) + 15u) & ~15u;  // two staged HsRec
-  MT_LDS double *const h_planes = (MT_LDS double *)(uintptr_t)(stage + 2u * (unsigned)sizeof(HsRec));  // [L][10] wave-uniform
-  const unsigned tstage = frames_end;                                    // 32 staged fp32 triangle boxes (768 B)
-  const char *const hs_bytes = (const char *)S.hs_rec;
-  int lev = -1;                        // frame on top of the stack, -1 none
-  unsigned long long pend = 0ull;      // wave-uniform; byte l: children of frame l still to look at
-  unsigned long long wantbits = 0ull;  // per lane; byte l: children of frame l this lane's filter lets through
-  int node = 0;
-  unsigned long long m = __ballot(at_root);
-  int ret_p = -1;
-  double ret_t = 0.0;
-  int slot = 0;  // child slot the result in ret_* comes from
-  bool entering = true;
-  // Records are staged one node ahead: `staged[b]` = node whose record is (being) copied to buffer b.
-  int buf = 0, staged0 = -1, staged1 = -1;
-  auto hs_fetch = [&](int nd, int b) {
-    if (lane < kHsRecLanes) lds_dma16(hs_bytes + (size_t)nd * sizeof(HsRec) + (size_t)lane * 16, stage + (unsigned)b * (unsigned)sizeof(HsRec));
-    if (b == 0) staged0 = nd; else staged1 = nd;
-  };
-  // Children are looked at near to far for the octant of the wave's first ray (child index
-  // bits: 0 = x high, 1 = z high, 2 = y high): a candidate found early lets the lanes drop the
-  // children that sort behind it, which is the reference's early exit (octtree.cc:246).
-  unsigned flip = 0u;
-  if (m != 0ull) {
-    const int fl = __builtin_ctzll(m);
-    flip = (unsigned)(__builtin_amdgcn_readlane(sxl, fl) | (__builtin_amdgcn_readlane(szl, fl) << 1) |
-                      (__builtin_amdgcn_readlane(syl, fl) << 2));
-  }
-  auto pick = [&](unsigned td) -> int {  // td != 0: the child to look at next
-    unsigned t = td;
-    if (flip & 1u) t = ((t & 0x55u) << 1) | ((t >> 1) & 0x55u);
-    if (flip & 2u) t = ((t & 0x33u) << 2) | ((t >> 2) & 0x33u);
-    if (flip & 4u) t = ((t & 0x0fu) << 4) | ((t >> 4) & 0x0fu);
-    return uniform_i32((int)((unsigned)__builtin_ctz(t) ^ flip));
-  };
-  // the node the wave enters after the current one if nothing below it is entered
-  auto next_after = [&](int l, unsigned long long pd) -> int {
-    for (; l >= 0; l--) {
-      const unsigned td = (unsigned)(pd >> (8 * l)) & 0xffu;
-      if (td != 0u) return uniform_i32(h_node[l * 2 + 1]) + pick(td);
-    }
-    return -1;
-  };
-  if (m != 0ull) {
-    hs_fetch(0, 0);
-    for (;;) {
-    if (++steps > step_bound) {
-      status = DEV_ERR_TRAVERSAL_BOUND;
-      break;
-    }
-    // The walk's state is the same in every lane; say so (hipcc's divergence analysis loses it
-    // across the loop and would run the bookkeeping below as per-lane vector code).
-    lev = uniform_i32(lev);
-    node = uniform_i32(node);
-    slot = uniform_i32(slot);
-    buf = uniform_i32(buf);
-    staged0 = uniform_i32(staged0);
-    staged1 = uniform_i32(staged1);
-    entering = uniform_i32(entering ? 1 : 0) != 0;
-    pend = uniform_u64(pend);
-    m = uniform_u64(m);
-    if (entering) {
-      const bool in = ((m >> lane) & 1ull) != 0ull;
-      MT_PROF_BEGIN(prof_t1);
-      if ((buf == 0 ? staged0 : staged1) != node) hs_fetch(node, buf);  // not the node that was foreseen
-      // hipcc 7.2 does not wait for an LDS-DMA before LDS reads through a pointer it cannot
-      // trace back to the DMA's destination: the wait is explicit
-#ifdef MT_PROF
-      const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
-#endif
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#ifdef MT_PROF
-      MT_PROF_COUNT(PROF_HS_CLOSE_T, __builtin_amdgcn_s_memtime() - tw0);
-#endif
-      const unsigned rec = stage + (unsigned)buf * (unsigned)sizeof(HsRec);
-      const MT_LDS int *ri = (const MT_LDS int *)(uintptr_t)rec;
-      const int fc = uniform_i32(ri[0]), pb = uniform_i32(ri[1]), pc = uniform_i32(ri[2]);
-      const unsigned cm = (unsigned)uniform_i32(ri[3]);
-#ifdef MT_PROF
-      asm volatile("" :: "s"(fc), "s"(pb), "s"(pc), "s"(cm));
-      MT_PROF_END(PROF_HS_REC_T, prof_t1);
-      MT_PROF_COUNT(PROF_HS_N_ENTER, 1);
-      MT_PROF_COUNT(PROF_HS_LANES, __builtin_popcountll(m));
-      MT_PROF_BEGIN(prof_t1);
-#endif
-      // a short list's fp32 boxes are copied to LDS while the children are tested
-      const bool small_list = pc > 0 && pc < kBigNode;
-      if (small_list && lane < 48) lds_dma16((const char *)S.tri_aabb32 + (size_t)pb * 24 + (size_t)lane * 16, tstage);
-      if (STATS) {
-        st.wave_node_steps++;
-        st.wave_tri_steps += (unsigned)pc;
-        st.bytes_scalar += 256u;
-        if (in) {
-          MT_CNT_ADD(1, 1u);
-          MT_CNT_ADD(2, (unsigned)pc);
-          if (fc != 0) MT_CNT_ADD(0, 8u);
-        }
-      }
-      // which children does some lane's filter let through?  All nine boxes (eight subtrees, the
-      // own list) are read in one batch and tested without branches.
-      typedef float f4v __attribute__((ext_vector_type(4)));
-      const MT_LDS f4v *r4 = (const MT_LDS f4v *)(uintptr_t)rec;
-      unsigned bits = 0u, any = 0u;
-      if (cm != 0u) {  // (most nodes a wave enters are leaves)
-        float bxs[48];
-#pragma unroll
-        for (int i = 0; i < 12; i++) {
-          const f4v q = r4[1 + i];
-          bxs[i * 4 + 0] = q.x; bxs[i * 4 + 1] = q.y; bxs[i * 4 + 2] = q.z; bxs[i * 4 + 3] = q.w;
-        }
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          const bool pass = subtree_may_hit(bxs + c * 6, f32, sxl != 0, syl != 0, szl != 0);
-          if (pass) bits |= 1u << c;
-        }
-        bits = in ? (bits & cm) : 0u;  // (cm: children with an empty subtree hold an inverted box anyway)
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          if (__ballot(((bits >> c) & 1u) != 0u) != 0ull) any |= 1u << c;
-        }
-        any = (unsigned)uniform_i32((int)any);
-      }
-      // the own list's union box decides who scans it
-      bool in_list = false;
-      if (pc > 0) {
-        const f4v q0 = r4[13], q1 = r4[14];
-        const float ob[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
-        in_list = in && subtree_may_hit(ob, f32, sxl != 0, syl != 0, szl != 0);
-      }
-      const unsigned long long lm = __ballot(in_list);
-      // stage the record of the node that comes next while this one's list is scanned
-      bool fetched_next = false;
-      {
-        const int nxt = uniform_i32(any != 0u ? fc + pick(any) : next_after(lev, pend));
-        if (nxt >= 0 && MT_KNOCK != 3) {
-          hs_fetch(nxt, buf ^ 1);
-          fetched_next = true;
-        }
-        buf ^= 1;
-      }
-#ifdef MT_PROF
-      asm volatile("" :: "v"(bits), "s"(any), "s"(lm));
-      MT_PROF_END(PROF_HS_KIDS_T, prof_t1);
-      MT_PROF_BEGIN(prof_t1);
-#endif
-      int best = -1;
-      double best_t = 0.0;
-      if (small_list && lm != 0ull && MT_KNOCK != 2) {
-        // the boxes were requested before the next node's record: all but that last copy must have landed
-        if (fetched_next) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned cand = 0u;  // per lane: list positions whose fp32 box the ray may hit
-        {
-          const MT_LDS f4v *t4 = (const MT_LDS f4v *)(uintptr_t)tstage;
-          for (int k = 0; k < pc; k += 4) {  // four boxes = six 16-byte reads; boxes past the list are masked off below
-            float tb[24];
-#pragma unroll
-            for (int i = 0; i < 6; i++) {
-              const f4v q = t4[(k >> 2) * 6 + i];
-              tb[i * 4 + 0] = q.x; tb[i * 4 + 1] = q.y; tb[i * 4 + 2] = q.z; tb[i * 4 + 3] = q.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-              if (subtree_may_hit(tb + j * 6, f32, sxl != 0, syl != 0, szl != 0)) cand |= 1u << (k + j);
-            }
-          }
-          cand &= (pc >= 32 ? 0xffffffffu : ((1u << pc) - 1u));
-          if (!in_list) cand = 0u;
-        }
-        // start fetching the candidates' exact boxes and vertices now (both ends of each: they may
-        // straddle a cache line); the loop below finds them on their way.  "+v": one register for all
-        // of these loads, live until after that loop, so that a late arrival lands nowhere else
-        unsigned warm = 0u;
-        {
-          unsigned w = cand;
-          for (int guard = 0; guard < 4 && w != 0u; guard++) {
-            const int k = __builtin_ctz(w);
-            w &= w - 1u;
-            const char *ep = (const char *)(S.tri_aabb + (size_t)(pb + k) * 6);
-            const char *vp = (const char *)(S.tri_vertex + (size_t)(pb + k) * 9);
-            asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:44\n\t"
-                         "global_load_dword %0, %2, off\n\tglobal_load_dword %0, %2, off offset:68"
-                         : "+v"(warm) : "v"(ep), "v"(vp));
-          }
-        }
-        if (STATS) st.bytes_scalar += 24u * (unsigned)pc;
-        // every lane resolves ITS candidates in list order (octtree.cc:177-196): exact box and
-        // vertices are fetched together, one round trip per candidate
-        unsigned mt = 0u, bv = 0u;
-        for (int guard = 0; __ballot(cand != 0u) != 0ull; guard++) {
-          if (guard > kBigNode) {  // cannot happen: one bit per trip
-            status = DEV_ERR_TRAVERSAL_BOUND;
-            break;
-          }
-          if (cand != 0u) {
-            const int t = pb + __builtin_ctz(cand);
-            cand &= cand - 1u;
-            const double *ep = S.tri_aabb + (size_t)t * 6;
-            const double *vp = S.tri_vertex + (size_t)t * 9;
-            const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
-            const double v[9] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
-            bv += 120u;
-            if (slab_pass_lane<false>(e, r)) {
-              mt++;
-              double tt;
-              if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
-                if (!(best >= 0 && tt > best_t)) {
-                  best = t;
-                  best_t = tt;
-                }
-              }
-            }
-          }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(warm));  // nothing of the warming loads outlives this point
-        if (status != DEV_OK) break;
-        if (STATS) {
-          if (mt) MT_CNT_ADD(3, mt);
-          if (bv) MT_CNT_ADD(4, bv);
-        }
-#ifdef MT_PROF
-        asm volatile("" :: "v"(best), "v"(best_t));
-        MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc);
-#endif
-      } else if (lm != 0ull && MT_KNOCK != 1) {
-        const unsigned long long mxs = __ballot(in_list && sxl), mys = __ballot(in_list && syl), mzs = __ballot(in_list && szl);
-        const bool one_octant = (mxs == 0 || mxs == lm) && (mys == 0 || mys == lm) && (mzs == 0 || mzs == lm);
-        const int oct = one_octant ? ((mxs != 0 ? 1 : 0) | (mys != 0 ? 2 : 0) | (mzs != 0 ? 4 : 0)) : 8;
-        const int n_in = __builtin_popcountll(lm);
-        const bool blocks_ok = pc >= kBigNode;
-        const int nblk = (pb + pc - 1) / kGroupTris - pb / kGroupTris + 1;
-        const bool transposed = blocks_ok && (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk);
-        ScanOut o{-1, 0.0, 0u};
-        if (transposed) {
-          o = scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in_list, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
-        } else if (in_list) {
-          o = scan_filtered_dispatch<STATS, true>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
-          if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
-        }
-        if (in_list) {
-          best = o.best;
-          best_t = o.best_t;
-          if (STATS && o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
-          if (STATS && o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
-        }
-#ifdef MT_PROF
-        asm volatile("" :: "v"(best), "v"(best_t));
-        if (transposed) { MT_PROF_END(PROF_HS_TRANS_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_TRANS, 1); }
-        else if (blocks_ok) { MT_PROF_END(PROF_HS_BIG_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_BIG, 1); MT_PROF_COUNT(PROF_HS_BIG_TRIS, pc); }
-        else { MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc); }
-#endif
-      } else {
-        MT_PROF_COUNT(PROF_HS_N_EMPTY, 1);
-      }
-      entering = false;
-      if (any == 0u) {  // a leaf, or nothing to look at below: the node's result is its own list's
-        ret_p = best;
-        ret_t = best_t;
-        slot = lev >= 0 ? node - uniform_i32(h_node[lev * 2 + 1]) : 0;
-        continue;
-      }
-      // open a frame (for ALL lanes: the ones outside m hold "nothing" in it)
-      lev++;
-      if (lev >= L) {  // cannot happen: a node with children is above the deepest level
-        status = DEV_ERR_UNWIND_BOUND;
-        break;
-      }
-      h_own_t[lev * 64 + lane] = best_t;
-      h_own_p[lev * 64 + lane] = best;
-      h_win_p[lev * 64 + lane] = -1;
-      h_node[lev * 2] = node;
-      h_node[lev * 2 + 1] = fc;
-      if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + 240u))[lane];
-      const int sh = 8 * lev;
-      wantbits = (wantbits & ~(0xffull << sh)) | ((unsigned long long)bits << sh);
-      pend = uniform_u64((pend & ~(0xffull << sh)) | ((unsigned long long)any << sh));
-      ret_p = -1;  // nothing comes back yet
-    } else {
-      if (lev < 0) break;  // ret_* is the root's result
-      MT_PROF_BEGIN(prof_t1);
-      MT_PROF_COUNT(PROF_HS_N_RET, 1);
-      if (__ballot(ret_p >= 0) != 0ull) {
-        MT_PROF_COUNT(PROF_HS_N_RETHIT, 1);
-        // offer child `slot`'s result to frame `lev`: octtree.cc:204-211 (does the
-        // ray enter that child's box, at what distance) and :226-246 (not farther
-        // than the own hit; first in sorted order = smallest (distance, index))
-        struct { double lo[3], c[3], hi[3]; } Pv;
-        {
-          const MT_LDS double *pl = h_planes + lev * 10;
-          Pv.lo[0] = pl[0]; Pv.lo[1] = pl[1]; Pv.lo[2] = pl[2];
-          Pv.c[0] = pl[3]; Pv.c[1] = pl[4]; Pv.c[2] = pl[5];
-          Pv.hi[0] = pl[6]; Pv.hi[1] = pl[7]; Pv.hi[2] = pl[8];
-        }
-        const auto *P = &Pv;
-        double amin[3][2], amax[3][2];
-        {
-          const double t0 = (P->lo[0] - r.ox) * r.ix, tc = (P->c[0] - r.ox) * r.ix, t1 = (P->hi[0] - r.ox) * r.ix;
-          amax[0][0] = mx<false>(t0, tc); amin[0][0] = mn<false>(t0, tc);
-          amax[0][1] = mx<false>(tc, t1); amin[0][1] = mn<false>(tc, t1);
-        }
-        {
-          const double t0 = (P->lo[1] - r.oy) * r.iy, tc = (P->c[1] - r.oy) * r.iy, t1 = (P->hi[1] - r.oy) * r.iy;
-          amax[1][0] = mx<false>(t0, tc); amin[1][0] = mn<false>(t0, tc);
-          amax[1][1] = mx<false>(tc, t1); amin[1][1] = mn<false>(tc, t1);
-        }
-        {
-          const double t0 = (P->lo[2] - r.oz) * r.iz, tc = (P->c[2] - r.oz) * r.iz, t1 = (P->hi[2] - r.oz) * r.iz;
-          amax[2][0] = mx<false>(t0, tc); amin[2][0] = mn<false>(t0, tc);
-          amax[2][1] = mx<false>(tc, t1); amin[2][1] = mn<false>(tc, t1);
-        }
-        // child index bits: 0 = x high, 1 = z high, 2 = y high (octtree.cc:61-100)
-        const bool xh = (slot & 1) != 0, zh = (slot & 2) != 0, yh = (slot & 4) != 0;  // wave-uniform
-        const double tmax = mn3<false>(xh ? amax[0][1] : amax[0][0], yh ? amax[1][1] : amax[1][0], zh ? amax[2][1] : amax[2][0]);
-        const double tmin = mx3<false>(xh ? amin[0][1] : amin[0][0], yh ? amin[1][1] : amin[1][0], zh ? amin[2][1] : amin[2][0]);
-        const bool entered = (tmax >= 0.0) & (tmin <= tmax);
-        const int own_p = h_own_p[lev * 64 + lane];
-        const double own_t = h_own_t[lev * 64 + lane];
-        if (ret_p >= 0 && entered && !(own_p >= 0 && ret_t > own_t)) {
-          const int wp = h_win_p[lev * 64 + lane];
-          bool take = wp < 0;
-          if (!take) {
-            const int kw = (int)((unsigned)wp >> 28);
-            const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
-            const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
-            take = (tmin < wmin) || (tmin == wmin && slot < kw);
-          }
-          if (take) {
-            h_win_p[lev * 64 + lane] = ret_p | (slot << 28);
-            h_win_t[lev * 64 + lane] = ret_t;
-          }
-        }
-        // Lanes that hold a candidate drop the children that sort behind it: the reference's
-        // loop would have stopped before them (they could only be looked at, never taken).
-        {
-          const int sh0 = 8 * lev;
-          unsigned rest = (unsigned)uniform_i32((int)((unsigned)(pend >> sh0) & 0xffu));
-          if (rest != 0u) {
-            const int wp = h_win_p[lev * 64 + lane];
-            const int kw = (int)((unsigned)wp >> 28) & 7;
-            const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
-            const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
-            unsigned my = (unsigned)(wantbits >> sh0) & 0xffu;
-            unsigned still = 0u;
-            while (rest != 0u) {
-              const int c2 = __builtin_ctz(rest);
-              rest &= rest - 1u;
-              const bool cxh = (c2 & 1) != 0, czh = (c2 & 2) != 0, cyh = (c2 & 4) != 0;  // wave-uniform
-              const double cmin = mx3<false>(cxh ? amin[0][1] : amin[0][0], cyh ? amin[1][1] : amin[1][0], czh ? amin[2][1] : amin[2][0]);
-              const bool behind = wp >= 0 && !((cmin < wmin) || (cmin == wmin && c2 < kw));
-              if (behind) my &= ~(1u << c2);
-              if (__ballot(((my >> c2) & 1u) != 0u) != 0ull) still |= 1u << c2;
-            }
-            wantbits = (wantbits & ~(0xffull << sh0)) | ((unsigned long long)my << sh0);
-            pend = uniform_u64((pend & ~(0xffull << sh0)) | ((unsigned long long)still << sh0));
-          }
-        }
-      }
-      const int sh = 8 * lev;
-      const unsigned todo = (unsigned)uniform_i32((int)((unsigned)(pend >> sh) & 0xffu));
-      MT_PROF_END(PROF_HS_RET_T, prof_t1);
-      if (todo == 0u) {  // close the frame: octtree.cc:248-256
-        const int wp = h_win_p[lev * 64 + lane];
-        if (wp >= 0) {
-          ret_p = wp & 0x0fffffff;
-          ret_t = h_win_t[lev * 64 + lane];
-        } else {
-          ret_p = h_own_p[lev * 64 + lane];
-          ret_t = h_own_t[lev * 64 + lane];
-        }
-        const int closed = uniform_i32(h_node[lev * 2]);
-        lev--;
-        slot = uniform_i32(lev >= 0 ? closed - uniform_i32(h_node[lev * 2 + 1]) : 0);
-        continue;
-      }
-      const int c = pick(todo);
-      pend = uniform_u64(pend & ~(1ull << (sh + c)));
-      m = __ballot(((wantbits >> (sh + c)) & 1ull) != 0ull);
-      node = uniform_i32(h_node[lev * 2 + 1]) + c;
-      entering = true;
-    }
-    }
-  }
-    ret_p_out = ret_p;
-    ret_t_out = ret_t;
-  }
-  MT_PROF_FLUSH(S.prof, lane);
-  TraceOut o;
-  o.status = status;
-  o.prim = status == DEV_OK ? ret_p_out : -1;
-  o.t = status == DEV_OK ? ret_t_out : 0.0;
-  o.box_tests = STATS ? cntr[0] : 0u;
-  o.node_visits = STATS ? cntr[1] : 0u;
-  o.tri_tests = STATS ? cntr[2] : 0u;
-  o.mt_tests = STATS ? cntr[3] : 0u;
-  o.bytes_vector = STATS ? cntr[4] : 0u;
-  o.wave_node_steps = st.wave_node_steps;
-  o.wave_tri_steps = st.wave_tri_steps;
-  o.bytes_scalar = st.bytes_scalar;
-  return o;
-}
-#endif
-
 // NOT inlined on purpose: as a function of its own the traversal gets its own
 // register allocation, free of the shading kernel's SGPR/VGPR pressure.  It
 // takes ONE pointer to the scene description in device memory (read with
@@ -2473,22 +2003,417 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   unsigned diag_a_trips = 0, diag_transposed = 0, diag_vec = 0;
 #endif
 #ifdef MT_HS
-  // regular rays, automatic mode: the hit-set traversal (hs_walk)
+  // ---- hit-set traversal (regular rays, automatic mode) ---------------------
+  // What PrimitiveIntersectRay returns for a node is a function of three things
+  // only (octtree.cc:169-257): the best hit of the node's own list; for every
+  // child, whether the ray enters its box and at what distance (the sort key);
+  // and what the same function returns for the children that hold a hit --
+  // children without one `continue` and leave no trace.  The loop over the
+  // sorted children takes the FIRST one whose hit is not farther than the own
+  // one and stops: with NaN-free keys and a stable sort that is the entered,
+  // acceptable child with the smallest (entry distance, index).  So the order
+  // in which the children are LOOKED AT is free: here the whole wave walks the
+  // tree depth-first in index order, every node once for all lanes whose
+  // filter does not rule its subtree out (wave-uniform boxes, scalar loads, no
+  // per-lane stack walk, no sort), each child's result is offered to its
+  // parent's frame when the wave comes back from it (exact entry test of that
+  // one child, comparison with the frame's best candidate so far), and a frame
+  // is closed when its last child is done.  Nodes the reference would not have
+  // reached (behind its early exit) may be looked at; that changes the work,
+  // not the result.
   bool hs_done = false;
   if (cull && S.force_mode == 0 && S.tree_depth <= kHsMaxDepth && S.n_tris < (1 << 28)) {
     hs_done = true;
-    const TraceOut h = hs_walk<STATS>(S.self, stk.base, lane, cur == 0, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
-    status = h.status;
-    if (want && status == DEV_OK) {
-      out_prim = h.prim;
-      out_t = h.t;
+    const int L = S.tree_depth > 1 ? S.tree_depth - 1 : 0;  // levels that can hold a node with children
+    MT_LDS double *const h_own_t = (MT_LDS double *)(uintptr_t)stk.base;  // [L][64] own list's best distance
+    MT_LDS double *const h_win_t = h_own_t + L * 64;                       // [L][64] best child candidate so far
+    MT_LDS int *const h_own_p = (MT_LDS int *)(h_win_t + L * 64);          // [L][64] own best triangle, -1 none
+    MT_LDS int *const h_win_p = h_own_p + L * 64;                          // [L][64] candidate triangle | child slot << 28, -1 none
+    MT_LDS int *const h_node = h_win_p + L * 64;                           // [L][2] wave-uniform: node, its first child
+    const unsigned stage = ((unsigned)(uintptr_t)(h_node + L * 2) + 15u) & ~15u;  // two staged HsRec
+    MT_LDS double *const h_planes = (MT_LDS double *)(uintptr_t)(stage + 2u * (unsigned)sizeof(HsRec));  // [L][10] wave-uniform
+    const unsigned tstage = frames_end;                                    // 32 staged fp32 triangle boxes (768 B)
+    const char *const hs_bytes = (const char *)S.hs_rec;
+    int lev = -1;                        // frame on top of the stack, -1 none
+    unsigned long long pend = 0ull;      // wave-uniform; byte l: children of frame l still to look at
+    unsigned long long wantbits = 0ull;  // per lane; byte l: children of frame l this lane's filter lets through
+    int node = 0;
+    unsigned long long m = __ballot(cur == 0);
+    int ret_p = -1;
+    double ret_t = 0.0;
+    int slot = 0;  // child slot the result in ret_* comes from
+    bool entering = true;
+    // Records are staged one node ahead: `staged[b]` = node whose record is (being) copied to buffer b.
+    int buf = 0, staged0 = -1, staged1 = -1;
+    auto hs_fetch = [&](int nd, int b) {
+      if (lane < kHsRecLanes) lds_dma16(hs_bytes + (size_t)nd * sizeof(HsRec) + (size_t)lane * 16, stage + (unsigned)b * (unsigned)sizeof(HsRec));
+      if (b == 0) staged0 = nd; else staged1 = nd;
+    };
+    // Children are looked at near to far for the octant of the wave's first ray (child index
+    // bits: 0 = x high, 1 = z high, 2 = y high): a candidate found early lets the lanes drop the
+    // children that sort behind it, which is the reference's early exit (octtree.cc:246).
+    unsigned flip = 0u;
+    if (m != 0ull) {
+      const int fl = __builtin_ctzll(m);
+      flip = (unsigned)(__builtin_amdgcn_readlane(sxl, fl) | (__builtin_amdgcn_readlane(szl, fl) << 1) |
+                        (__builtin_amdgcn_readlane(syl, fl) << 2));
     }
-    if (STATS) {
-      cntr[0] += h.box_tests; cntr[1] += h.node_visits; cntr[2] += h.tri_tests; cntr[3] += h.mt_tests;
-      cntr[4] += h.bytes_vector;
-      st.wave_node_steps += (unsigned)__builtin_amdgcn_readfirstlane((int)h.wave_node_steps);
-      st.wave_tri_steps += (unsigned)__builtin_amdgcn_readfirstlane((int)h.wave_tri_steps);
-      st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)h.bytes_scalar);
+    auto pick = [&](unsigned td) -> int {  // td != 0: the child to look at next
+      unsigned t = td;
+      if (flip & 1u) t = ((t & 0x55u) << 1) | ((t >> 1) & 0x55u);
+      if (flip & 2u) t = ((t & 0x33u) << 2) | ((t >> 2) & 0x33u);
+      if (flip & 4u) t = ((t & 0x0fu) << 4) | ((t >> 4) & 0x0fu);
+      return (int)((unsigned)__builtin_ctz(t) ^ flip);
+    };
+    // the node the wave enters after the current one if nothing below it is entered
+    auto next_after = [&](int l, unsigned long long pd) -> int {
+      for (; l >= 0; l--) {
+        const unsigned td = (unsigned)(pd >> (8 * l)) & 0xffu;
+        if (td != 0u) return uniform_i32(h_node[l * 2 + 1]) + pick(td);
+      }
+      return -1;
+    };
+    if (m != 0ull) {
+      hs_fetch(0, 0);
+      for (;;) {
+      if (++steps > step_bound) {
+        status = DEV_ERR_TRAVERSAL_BOUND;
+        break;
+      }
+      // The walk's state is the same in every lane; say so (hipcc's divergence analysis loses it
+      // across the loop and would run the bookkeeping below as per-lane vector code).
+      lev = uniform_i32(lev);
+      node = uniform_i32(node);
+      slot = uniform_i32(slot);
+      buf = uniform_i32(buf);
+      staged0 = uniform_i32(staged0);
+      staged1 = uniform_i32(staged1);
+      entering = uniform_i32(entering ? 1 : 0) != 0;
+      pend = ((unsigned long long)(unsigned)uniform_i32((int)(pend >> 32)) << 32) | (unsigned)uniform_i32((int)pend);
+      m = ((unsigned long long)(unsigned)uniform_i32((int)(m >> 32)) << 32) | (unsigned)uniform_i32((int)m);
+      if (entering) {
+        const bool in = ((m >> lane) & 1ull) != 0ull;
+        MT_PROF_BEGIN(prof_t1);
+        if ((buf == 0 ? staged0 : staged1) != node) hs_fetch(node, buf);  // not the node that was foreseen
+        // hipcc 7.2 does not wait for an LDS-DMA before LDS reads through a pointer it cannot
+        // trace back to the DMA's destination: the wait is explicit
+#ifdef MT_PROF
+        const unsigned long long tw0 = __builtin_amdgcn_s_memtime();
+#endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MT_PROF
+        MT_PROF_COUNT(PROF_HS_CLOSE_T, __builtin_amdgcn_s_memtime() - tw0);
+#endif
+        const unsigned rec = stage + (unsigned)buf * (unsigned)sizeof(HsRec);
+        const MT_LDS int *ri = (const MT_LDS int *)(uintptr_t)rec;
+        const int fc = uniform_i32(ri[0]), pb = uniform_i32(ri[1]), pc = uniform_i32(ri[2]);
+        const unsigned cm = (unsigned)uniform_i32(ri[3]);
+#ifdef MT_PROF
+        asm volatile("" :: "s"(fc), "s"(pb), "s"(pc), "s"(cm));
+        MT_PROF_END(PROF_HS_REC_T, prof_t1);
+        MT_PROF_COUNT(PROF_HS_N_ENTER, 1);
+        MT_PROF_COUNT(PROF_HS_LANES, __builtin_popcountll(m));
+        MT_PROF_BEGIN(prof_t1);
+#endif
+        // a short list's fp32 boxes are copied to LDS while the children are tested
+        const bool small_list = pc > 0 && pc < kBigNode;
+        if (small_list && lane < 48) lds_dma16((const char *)S.tri_aabb32 + (size_t)pb * 24 + (size_t)lane * 16, tstage);
+        if (STATS) {
+          st.wave_node_steps++;
+          st.wave_tri_steps += (unsigned)pc;
+          st.bytes_scalar += 256u;
+          if (in) {
+            MT_CNT_ADD(1, 1u);
+            MT_CNT_ADD(2, (unsigned)pc);
+            if (fc != 0) MT_CNT_ADD(0, 8u);
+          }
+        }
+        // which children does some lane's filter let through?  All nine boxes (eight subtrees, the
+        // own list) are read in one batch and tested without branches.
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const MT_LDS f4v *r4 = (const MT_LDS f4v *)(uintptr_t)rec;
+        unsigned bits = 0u, any = 0u;
+        if (cm != 0u) {  // (most nodes a wave enters are leaves)
+          float bxs[48];
+#pragma unroll
+          for (int i = 0; i < 12; i++) {
+            const f4v q = r4[1 + i];
+            bxs[i * 4 + 0] = q.x; bxs[i * 4 + 1] = q.y; bxs[i * 4 + 2] = q.z; bxs[i * 4 + 3] = q.w;
+          }
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            const bool pass = subtree_may_hit(bxs + c * 6, f32, sxl != 0, syl != 0, szl != 0);
+            if (pass) bits |= 1u << c;
+          }
+          bits = in ? (bits & cm) : 0u;  // (cm: children with an empty subtree hold an inverted box anyway)
+#pragma unroll
+          for (int c = 0; c < 8; c++) {
+            if (__ballot(((bits >> c) & 1u) != 0u) != 0ull) any |= 1u << c;
+          }
+        }
+        // the own list's union box decides who scans it
+        bool in_list = false;
+        if (pc > 0) {
+          const f4v q0 = r4[13], q1 = r4[14];
+          const float ob[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
+          in_list = in && subtree_may_hit(ob, f32, sxl != 0, syl != 0, szl != 0);
+        }
+        const unsigned long long lm = __ballot(in_list);
+        // stage the record of the node that comes next while this one's list is scanned
+        bool fetched_next = false;
+        {
+          const int nxt = any != 0u ? fc + pick(any) : next_after(lev, pend);
+          if (nxt >= 0) {
+            hs_fetch(nxt, buf ^ 1);
+            fetched_next = true;
+          }
+          buf ^= 1;
+        }
+#ifdef MT_PROF
+        asm volatile("" :: "v"(bits), "s"(any), "s"(lm));
+        MT_PROF_END(PROF_HS_KIDS_T, prof_t1);
+        MT_PROF_BEGIN(prof_t1);
+#endif
+        int best = -1;
+        double best_t = 0.0;
+        if (small_list && lm != 0ull) {
+          // the boxes were requested before the next node's record: all but that last copy must have landed
+          if (fetched_next) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          unsigned cand = 0u;  // per lane: list positions whose fp32 box the ray may hit
+          {
+            const MT_LDS f4v *t4 = (const MT_LDS f4v *)(uintptr_t)tstage;
+            for (int k = 0; k < pc; k += 4) {  // four boxes = six 16-byte reads; boxes past the list are masked off below
+              float tb[24];
+#pragma unroll
+              for (int i = 0; i < 6; i++) {
+                const f4v q = t4[(k >> 2) * 6 + i];
+                tb[i * 4 + 0] = q.x; tb[i * 4 + 1] = q.y; tb[i * 4 + 2] = q.z; tb[i * 4 + 3] = q.w;
+              }
+#pragma unroll
+              for (int j = 0; j < 4; j++) {
+                if (subtree_may_hit(tb + j * 6, f32, sxl != 0, syl != 0, szl != 0)) cand |= 1u << (k + j);
+              }
+            }
+            cand &= (pc >= 32 ? 0xffffffffu : ((1u << pc) - 1u));
+            if (!in_list) cand = 0u;
+          }
+          // start fetching the candidates' exact boxes and vertices now (both ends of each: they may
+          // straddle a cache line); the loop below finds them on their way.  "+v": one register for all
+          // of these loads, live until after that loop, so that a late arrival lands nowhere else
+          unsigned warm = 0u;
+          {
+            unsigned w = cand;
+            for (int guard = 0; guard < 4 && w != 0u; guard++) {
+              const int k = __builtin_ctz(w);
+              w &= w - 1u;
+              const char *ep = (const char *)(S.tri_aabb + (size_t)(pb + k) * 6);
+              const char *vp = (const char *)(S.tri_vertex + (size_t)(pb + k) * 9);
+              asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:44\n\t"
+                           "global_load_dword %0, %2, off\n\tglobal_load_dword %0, %2, off offset:68"
+                           : "+v"(warm) : "v"(ep), "v"(vp));
+            }
+          }
+          if (STATS) st.bytes_scalar += 24u * (unsigned)pc;
+          // every lane resolves ITS candidates in list order (octtree.cc:177-196): exact box and
+          // vertices are fetched together, one round trip per candidate
+          unsigned mt = 0u, bv = 0u;
+          for (int guard = 0; __ballot(cand != 0u) != 0ull; guard++) {
+            if (guard > kBigNode) {  // cannot happen: one bit per trip
+              status = DEV_ERR_TRAVERSAL_BOUND;
+              break;
+            }
+            if (cand != 0u) {
+              const int t = pb + __builtin_ctz(cand);
+              cand &= cand - 1u;
+              const double *ep = S.tri_aabb + (size_t)t * 6;
+              const double *vp = S.tri_vertex + (size_t)t * 9;
+              const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
+              const double v[9] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
+              bv += 120u;
+              if (slab_pass_lane<false>(e, r)) {
+                mt++;
+                double tt;
+                if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
+                  if (!(best >= 0 && tt > best_t)) {
+                    best = t;
+                    best_t = tt;
+                  }
+                }
+              }
+            }
+          }
+          asm volatile("s_waitcnt vmcnt(0)" : "+v"(warm));  // nothing of the warming loads outlives this point
+          if (status != DEV_OK) break;
+          if (STATS) {
+            if (mt) MT_CNT_ADD(3, mt);
+            if (bv) MT_CNT_ADD(4, bv);
+          }
+#ifdef MT_PROF
+          asm volatile("" :: "v"(best), "v"(best_t));
+          MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc);
+#endif
+        } else if (lm != 0ull) {
+          const unsigned long long mxs = __ballot(in_list && sxl), mys = __ballot(in_list && syl), mzs = __ballot(in_list && szl);
+          const bool one_octant = (mxs == 0 || mxs == lm) && (mys == 0 || mys == lm) && (mzs == 0 || mzs == lm);
+          const int oct = one_octant ? ((mxs != 0 ? 1 : 0) | (mys != 0 ? 2 : 0) | (mzs != 0 ? 4 : 0)) : 8;
+          const int n_in = __builtin_popcountll(lm);
+          const bool blocks_ok = pc >= kBigNode;
+          const int nblk = (pb + pc - 1) / kGroupTris - pb / kGroupTris + 1;
+          const bool transposed = blocks_ok && (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk);
+          ScanOut o{-1, 0.0, 0u};
+          if (transposed) {
+            o = scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in_list, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
+          } else if (in_list) {
+            o = scan_filtered_dispatch<STATS, true>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
+            if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
+          }
+          if (in_list) {
+            best = o.best;
+            best_t = o.best_t;
+            if (STATS && o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
+            if (STATS && o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
+          }
+#ifdef MT_PROF
+          asm volatile("" :: "v"(best), "v"(best_t));
+          if (transposed) { MT_PROF_END(PROF_HS_TRANS_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_TRANS, 1); }
+          else if (blocks_ok) { MT_PROF_END(PROF_HS_BIG_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_BIG, 1); MT_PROF_COUNT(PROF_HS_BIG_TRIS, pc); }
+          else { MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc); }
+#endif
+        } else {
+          MT_PROF_COUNT(PROF_HS_N_EMPTY, 1);
+        }
+        entering = false;
+        if (any == 0u) {  // a leaf, or nothing to look at below: the node's result is its own list's
+          ret_p = best;
+          ret_t = best_t;
+          slot = lev >= 0 ? node - uniform_i32(h_node[lev * 2 + 1]) : 0;
+          continue;
+        }
+        // open a frame (for ALL lanes: the ones outside m hold "nothing" in it)
+        lev++;
+        if (lev >= L) {  // cannot happen: a node with children is above the deepest level
+          status = DEV_ERR_UNWIND_BOUND;
+          break;
+        }
+        h_own_t[lev * 64 + lane] = best_t;
+        h_own_p[lev * 64 + lane] = best;
+        h_win_p[lev * 64 + lane] = -1;
+        h_node[lev * 2] = node;
+        h_node[lev * 2 + 1] = fc;
+        if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + 240u))[lane];
+        const int sh = 8 * lev;
+        wantbits = (wantbits & ~(0xffull << sh)) | ((unsigned long long)bits << sh);
+        pend = (pend & ~(0xffull << sh)) | ((unsigned long long)any << sh);
+        ret_p = -1;  // nothing comes back yet
+      } else {
+        if (lev < 0) break;  // ret_* is the root's result
+        MT_PROF_BEGIN(prof_t1);
+        MT_PROF_COUNT(PROF_HS_N_RET, 1);
+        if (__ballot(ret_p >= 0) != 0ull) {
+          MT_PROF_COUNT(PROF_HS_N_RETHIT, 1);
+          // offer child `slot`'s result to frame `lev`: octtree.cc:204-211 (does the
+          // ray enter that child's box, at what distance) and :226-246 (not farther
+          // than the own hit; first in sorted order = smallest (distance, index))
+          struct { double lo[3], c[3], hi[3]; } Pv;
+          {
+            const MT_LDS double *pl = h_planes + lev * 10;
+            Pv.lo[0] = pl[0]; Pv.lo[1] = pl[1]; Pv.lo[2] = pl[2];
+            Pv.c[0] = pl[3]; Pv.c[1] = pl[4]; Pv.c[2] = pl[5];
+            Pv.hi[0] = pl[6]; Pv.hi[1] = pl[7]; Pv.hi[2] = pl[8];
+          }
+          const auto *P = &Pv;
+          double amin[3][2], amax[3][2];
+          {
+            const double t0 = (P->lo[0] - r.ox) * r.ix, tc = (P->c[0] - r.ox) * r.ix, t1 = (P->hi[0] - r.ox) * r.ix;
+            amax[0][0] = mx<false>(t0, tc); amin[0][0] = mn<false>(t0, tc);
+            amax[0][1] = mx<false>(tc, t1); amin[0][1] = mn<false>(tc, t1);
+          }
+          {
+            const double t0 = (P->lo[1] - r.oy) * r.iy, tc = (P->c[1] - r.oy) * r.iy, t1 = (P->hi[1] - r.oy) * r.iy;
+            amax[1][0] = mx<false>(t0, tc); amin[1][0] = mn<false>(t0, tc);
+            amax[1][1] = mx<false>(tc, t1); amin[1][1] = mn<false>(tc, t1);
+          }
+          {
+            const double t0 = (P->lo[2] - r.oz) * r.iz, tc = (P->c[2] - r.oz) * r.iz, t1 = (P->hi[2] - r.oz) * r.iz;
+            amax[2][0] = mx<false>(t0, tc); amin[2][0] = mn<false>(t0, tc);
+            amax[2][1] = mx<false>(tc, t1); amin[2][1] = mn<false>(tc, t1);
+          }
+          // child index bits: 0 = x high, 1 = z high, 2 = y high (octtree.cc:61-100)
+          const bool xh = (slot & 1) != 0, zh = (slot & 2) != 0, yh = (slot & 4) != 0;  // wave-uniform
+          const double tmax = mn3<false>(xh ? amax[0][1] : amax[0][0], yh ? amax[1][1] : amax[1][0], zh ? amax[2][1] : amax[2][0]);
+          const double tmin = mx3<false>(xh ? amin[0][1] : amin[0][0], yh ? amin[1][1] : amin[1][0], zh ? amin[2][1] : amin[2][0]);
+          const bool entered = (tmax >= 0.0) & (tmin <= tmax);
+          const int own_p = h_own_p[lev * 64 + lane];
+          const double own_t = h_own_t[lev * 64 + lane];
+          if (ret_p >= 0 && entered && !(own_p >= 0 && ret_t > own_t)) {
+            const int wp = h_win_p[lev * 64 + lane];
+            bool take = wp < 0;
+            if (!take) {
+              const int kw = (int)((unsigned)wp >> 28);
+              const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
+              const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
+              take = (tmin < wmin) || (tmin == wmin && slot < kw);
+            }
+            if (take) {
+              h_win_p[lev * 64 + lane] = ret_p | (slot << 28);
+              h_win_t[lev * 64 + lane] = ret_t;
+            }
+          }
+          // Lanes that hold a candidate drop the children that sort behind it: the reference's
+          // loop would have stopped before them (they could only be looked at, never taken).
+          {
+            const int sh0 = 8 * lev;
+            unsigned rest = (unsigned)(pend >> sh0) & 0xffu;
+            if (rest != 0u) {
+              const int wp = h_win_p[lev * 64 + lane];
+              const int kw = (int)((unsigned)wp >> 28) & 7;
+              const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
+              const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
+              unsigned my = (unsigned)(wantbits >> sh0) & 0xffu;
+              unsigned still = 0u;
+              while (rest != 0u) {
+                const int c2 = __builtin_ctz(rest);
+                rest &= rest - 1u;
+                const bool cxh = (c2 & 1) != 0, czh = (c2 & 2) != 0, cyh = (c2 & 4) != 0;  // wave-uniform
+                const double cmin = mx3<false>(cxh ? amin[0][1] : amin[0][0], cyh ? amin[1][1] : amin[1][0], czh ? amin[2][1] : amin[2][0]);
+                const bool behind = wp >= 0 && !((cmin < wmin) || (cmin == wmin && c2 < kw));
+                if (behind) my &= ~(1u << c2);
+                if (__ballot(((my >> c2) & 1u) != 0u) != 0ull) still |= 1u << c2;
+              }
+              wantbits = (wantbits & ~(0xffull << sh0)) | ((unsigned long long)my << sh0);
+              pend = (pend & ~(0xffull << sh0)) | ((unsigned long long)still << sh0);
+            }
+          }
+        }
+        const int sh = 8 * lev;
+        const unsigned todo = (unsigned)(pend >> sh) & 0xffu;
+        MT_PROF_END(PROF_HS_RET_T, prof_t1);
+        if (todo == 0u) {  // close the frame: octtree.cc:248-256
+          const int wp = h_win_p[lev * 64 + lane];
+          if (wp >= 0) {
+            ret_p = wp & 0x0fffffff;
+            ret_t = h_win_t[lev * 64 + lane];
+          } else {
+            ret_p = h_own_p[lev * 64 + lane];
+            ret_t = h_own_t[lev * 64 + lane];
+          }
+          const int closed = uniform_i32(h_node[lev * 2]);
+          lev--;
+          slot = lev >= 0 ? closed - uniform_i32(h_node[lev * 2 + 1]) : 0;
+          continue;
+        }
+        const int c = pick(todo);
+        pend &= ~(1ull << (sh + c));
+        m = __ballot(((wantbits >> (sh + c)) & 1ull) != 0ull);
+        node = uniform_i32(h_node[lev * 2 + 1]) + c;
+        entering = true;
+      }
+      }
+    }
+    if (want && status == DEV_OK) {
+      out_prim = ret_p;
+      out_t = ret_t;
     }
     cur = -1;
   }
