@@ -223,8 +223,8 @@ int mt_scene_set_scheduling(mt_scene *scene, int use_cost_history);
  * of rays, so that a call's shadow loops and child calls are traced side by
  * side (shortest chain of dependent passes per pixel; wins when a launch has
  * few blocks per wave, e.g. one rank's share of a multi-GPU frame).  0 =
- * automatic (default): 2 for launches with fewer than 6 blocks per resident
- * wave, else 1.  Also forgets the recorded costs.  (No reference counterpart.) */
+ * automatic (default): 2 for launches with fewer than 9 blocks per resident
+ * wave and for launches without measured block costs, else 1.  Also forgets the recorded costs.  (No reference counterpart.) */
 int mt_scene_set_engine(mt_scene *scene, int engine);
 
 /* Device durations of the launches made since the previous call (at most the
@@ -246,18 +246,23 @@ int mt_intersect_rays(mt_scene *scene, int n, const double *rays,
                       int32_t *tri, int32_t *line_no, double *t,
                       double *point, mt_stats *stats);
 
-/* Test hook: 0 = automatic (default), 1 = always use the exact
+/* Test hook: 0 = automatic (default: regular rays take the hit-set walk --
+ * every node once per wave, children in any order, the reference's choice among
+ * them by its (entry distance, index) rule; DESIGN.md section 3.1 -- and the
+ * ordered descent of the modes below serves the rest), 1 = always use the exact
  * std::min/std::max comparison path, 2 = allow min/max instructions but not
  * the octant-uniform path, 3 = automatic but never the triangle-parallel
  * (transposed) node scan, 4 = automatic but without the fp32 conservative
  * pre-filter, 5 = automatic but every node through a wave step (no
  * lane-parallel scan of small nodes), 6 = automatic but without the block
  * boxes that skip runs of triangles, 7 = automatic but without the subtree
- * boxes that skip children.  Results are identical in every
- * mode; the
- * counters box_tests / node_visits / tri_tests equal the reference's
- * un-pruned traversal in modes 1, 2, 4 and 7 (no subtree is skipped there)
- * and count only the nodes actually visited in the others. */
+ * boxes that skip children.  Results are identical in every mode; the
+ * counters box_tests / node_visits / tri_tests / mt_tests equal the
+ * reference's traversal in modes 1, 2, 4 and 7 (no subtree is skipped there);
+ * in the others the first three count only the nodes actually visited, and in
+ * mode 0 all four are the walk's own work (it may look at a node that lies
+ * behind the reference's early exit: mt_tests is then not smaller than the
+ * reference's, never the other way round). */
 int mt_scene_set_traversal_mode(mt_scene *scene, int mode);
 
 #ifdef __cplusplus

@@ -5,7 +5,14 @@
 // and Triangle::IntersectRay (primitive_triangle.cc:81-143) of the reference,
 // with bit-identical results.
 //
-// Design (one ray per lane):
+// Two traversals live here (one ray per lane in both).  Regular rays in the
+// automatic mode take the HIT-SET WALK (the MT_HS block of trace_wave: the
+// wave walks the tree depth-first, every node once for all its lanes, children
+// in any order; the reference's choice among the children that hold a hit is
+// reproduced by its own rule, "the entered, acceptable child with the smallest
+// (entry distance, index)" -- see the comment there and DESIGN.md section 3.1).
+// Irregular rays, the diagnostic modes and trees deeper than kHsMaxDepth take
+// the ORDERED DESCENT:
 //   * every lane keeps its own recursion state (the reference's call stack of
 //     PrimitiveIntersectRay) in an LDS-resident per-lane stack;
 //   * small nodes (< kBigNode triangles) are scanned lane-parallel, every lane
