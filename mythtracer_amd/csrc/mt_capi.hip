@@ -658,6 +658,14 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
       }
     }
     for (int k = 0; k < 6; k++) h.own[k] = (float)u[k];
+    for (int c = 0; c < 8 && r.first_child != 0; c++) {
+      const NodeRec &k = recs[r.first_child + c];
+      h.kid_begin[c] = k.prim_begin;
+      if (k.first_child == 0 && k.prim_count >= 1 && k.prim_count <= kHsLeafTris) {
+        h.kid_leaf |= 1 << c;
+        h.kid_count[c] = (uint8_t)k.prim_count;
+      }
+    }
     for (int k = 0; k < 3; k++) {
       h.planes[k] = r.lo[k];
       h.planes[3 + k] = r.c[k];
@@ -736,9 +744,10 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   s->allocs.push_back(s->d_dev);
   s->dev.self = s->d_dev;
 #ifdef MT_PROF
-  HIP_TRY(hipMalloc((void **)&s->d_prof, PROF_COUNT * sizeof(unsigned long long)));
+  // (behind the phase sums: a time line of one wave, -DMT_PROF builds only -- kProfTimeline stamps)
+  HIP_TRY(hipMalloc((void **)&s->d_prof, (PROF_COUNT + 1 + kProfTimeline) * sizeof(unsigned long long)));
   s->allocs.push_back(s->d_prof);
-  HIP_TRY(hipMemset(s->d_prof, 0, PROF_COUNT * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(s->d_prof, 0, (PROF_COUNT + 1 + kProfTimeline) * sizeof(unsigned long long)));
   s->dev.prof = s->d_prof;
 #endif
   if (getenv("MT_DEBUG_HEARTBEAT")) {
@@ -819,6 +828,15 @@ int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
     unsigned long long pr[PROF_COUNT];
     HIP_TRY(hipMemcpy(pr, s->d_prof, sizeof pr, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(s->d_prof, 0, sizeof pr));
+    if (const char *tl = getenv("MT_DEBUG_TIMELINE")) {  // dump and reset the time line
+      std::vector<unsigned long long> host(1 + kProfTimeline);
+      HIP_TRY(hipMemcpy(host.data(), s->d_prof + PROF_COUNT, host.size() * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemset(s->d_prof + PROF_COUNT, 0, host.size() * 8));
+      if (FILE *f = fopen(tl, "wb")) {
+        fwrite(host.data(), 8, host.size(), f);
+        fclose(f);
+      }
+    }
     static const char *names[PROF_COUNT] = {"trace_cycles", "scan_raypar_cycles", "scan_transposed_cycles",
                                             "children_unwind_cycles", "n_raypar_scans", "n_transposed_scans",
                                             "n_transposed_chunks", "n_raypar_tris", "n_traces", "lane_phase_cycles",

@@ -62,12 +62,15 @@ struct HsRec {
   int32_t first_child, prim_begin, prim_count, child_mask;
   float kid[8][6];
   float own[6];
-  float pad[2];
-  double planes[9];  // lo xyz, centre xyz, hi xyz (NodeRec): the children's exact boxes
-  double pad2;
+  uint8_t kid_count[8];  // prim_count of the children that are "short leaves" (kid_leaf), else 0
+  double planes[9];      // lo xyz, centre xyz, hi xyz (NodeRec): the children's exact boxes
+  int32_t kid_leaf;      // bit c: child c is a leaf with 1..kHsLeafTris triangles -- its list is scanned from the parent's step
+  int32_t pad;
+  int32_t kid_begin[8];  // prim_begin of the children
 };
-static_assert(sizeof(HsRec) == 320, "HsRec must be 320 bytes");
-constexpr int kHsRecLanes = 20;  // 16 bytes per lane
+static_assert(sizeof(HsRec) == 352, "HsRec must be 352 bytes");
+constexpr int kHsRecLanes = 22;   // 16 bytes per lane
+constexpr int kHsLeafTris = 16;   // 16 fp32 boxes = 384 bytes = 24 lanes of one LDS-DMA instruction
 
 struct DevTexture {
   const void *texels;
@@ -108,6 +111,7 @@ struct DevScene {
   const DevScene *self;
 };
 
+constexpr int kProfTimeline = 16384;  // -DMT_PROF: stamps of one wave's walk (tag in the low byte)
 enum { PROF_TRACE = 0, PROF_SCAN_RAYPAR, PROF_SCAN_TRANSPOSED, PROF_CHILDREN_UNWIND, PROF_N_RAYPAR,
        PROF_N_TRANSPOSED, PROF_N_CHUNKS, PROF_N_RAYPAR_TRIS, PROF_N_TRACES, PROF_SHADE,
        PROF_SCAN_M2F, PROF_SCAN_M2, PROF_SCAN_M1, PROF_SCAN_M0, PROF_N_M2F, PROF_N_M2, PROF_N_M1, PROF_N_M0,
@@ -194,8 +198,10 @@ __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
 #ifdef MT_HS
   if (depth <= kHsMaxDepth && depth > 1) {
     // frames, (node, first child) per level, two staged records (16-byte aligned)
-    // ... and per level the nine planes of the frame's node (80 bytes)
-    const size_t hs = (((size_t)(depth - 1) * (64 * 24 + 8) + 15) & ~(size_t)15) + 2 * sizeof(HsRec) + (size_t)(depth - 1) * 80;
+    // ... per level the nine planes of the frame's node (80 bytes), and the staged lists of up to eight
+    // short leaf children (384 bytes each)
+    const size_t hs = (((size_t)(depth - 1) * (64 * 24 + 8) + 15) & ~(size_t)15) + 2 * sizeof(HsRec) + (size_t)(depth - 1) * 80 +
+                      8 * 384 + 2 * 384;  // ... and two staged blocks of a long list
     if (hs > n) n = hs;
   }
 #endif

@@ -458,6 +458,9 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
     item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
 
     const unsigned long long item_t0 = __builtin_amdgcn_s_memtime();
+#ifdef MT_DIAG
+    unsigned long long diag_trace_ticks = 0;
+#endif
     const ItemGeom g = item_geometry(P, item, sub, lane);
     bool alive = g.inside;
     const size_t px_index = g.px_index;
@@ -532,7 +535,14 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
                             (size_t)wave_id * 100 * 64 + lane;
         for (int q = 0; q < 100; q++) dup_buf[q * 64] = (unsigned)(q + lane) ^ (unsigned)passes;
 #endif
+#ifdef MT_DIAG
+        const unsigned long long diag_tt0 = __builtin_amdgcn_s_memtime();
+#endif
         const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, tracing, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+#ifdef MT_DIAG
+        asm volatile("" :: "v"(to.prim));
+        diag_trace_ticks += __builtin_amdgcn_s_memtime() - diag_tt0;
+#endif
 #if MT_DUP == 7
         {
           unsigned acc = 0;
@@ -863,6 +873,9 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
           P.item_cycles[(size_t)w * 2] = ticks;
           P.item_cycles[(size_t)w * 2 + 1] =
               ((unsigned long long)passes << 40) | ((unsigned long long)item << 8) | (unsigned)(sub + 1);
+#ifdef MT_DIAG
+          P.item_cycles[(size_t)(P.n_items * 32u + w) * 2] = diag_trace_ticks;
+#endif
         }
       }
     }

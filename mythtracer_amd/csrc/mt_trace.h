@@ -50,6 +50,12 @@
 namespace mt {
 
 #define MT_CONST __attribute__((address_space(4)))
+#ifndef MT_KNOCK
+// timing experiments of the hit-set walk (scripts/ab_lib.py): 1 = no long-list scans, 7 = no list scans at all (wrong
+// images both), 2 = short lists through the call path, 3 = no record prefetch, 4 / 5 / 6 = child tests / short-list fp32
+// tests / short-list candidates executed twice
+#define MT_KNOCK 0
+#endif
 #ifndef MT_DUP
 #define MT_DUP 0  // diagnostic: execute one section of the traversal twice (timing experiments only)
 #endif
@@ -74,6 +80,8 @@ namespace mt {
 #define MT_PROF_BEGIN(var) var = __builtin_amdgcn_s_memtime()
 #define MT_PROF_END(slot, var) prof_acc[slot] += __builtin_amdgcn_s_memtime() - var
 #define MT_PROF_COUNT(slot, n) prof_acc[slot] += (unsigned long long)(n)
+#define MT_TL(tag) do { if (tl_on && tl_i < 512u && tl_base + tl_i < (unsigned long long)kProfTimeline) { \
+    S.prof[PROF_COUNT + 1 + tl_base + tl_i] = (__builtin_amdgcn_s_memtime() << 8) | (unsigned)(tag); tl_i++; } } while (0)
 #define MT_PROF_FLUSH(ptr, lane) do { if ((ptr) && (lane) == 0) { for (int pi_ = 0; pi_ < PROF_COUNT; pi_++) if (prof_acc[pi_]) atomicAdd((ptr) + pi_, prof_acc[pi_]); } } while (0)
 #else
 #define MT_PROF_DECL
@@ -81,6 +89,7 @@ namespace mt {
 #define MT_PROF_END(slot, var)
 #define MT_PROF_COUNT(slot, n)
 #define MT_PROF_FLUSH(ptr, lane)
+#define MT_TL(tag)
 #endif
 
 template <typename T>
@@ -128,6 +137,10 @@ __device__ __forceinline__ double mx3(double a, double b, double c) {
 // Arguments of a non-inlined device function arrive in VGPRs; these put a
 // wave-uniform value back into SGPRs so that it can feed scalar loads.
 __device__ __forceinline__ int uniform_i32(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+  return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+         (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
 template <typename T>
 __device__ __forceinline__ T *uniform_ptr(T *p) {
   const unsigned long long v = (unsigned long long)(uintptr_t)p;
@@ -2040,7 +2053,17 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     const unsigned stage = ((unsigned)(uintptr_t)(h_node + L * 2) + 15u) & ~15u;  // two staged HsRec
     MT_LDS double *const h_planes = (MT_LDS double *)(uintptr_t)(stage + 2u * (unsigned)sizeof(HsRec));  // [L][10] wave-uniform
     const unsigned tstage = frames_end;                                    // 32 staged fp32 triangle boxes (768 B)
+    const unsigned lstage = (unsigned)(uintptr_t)(h_planes + L * 10);      // the lists of up to 8 short leaf children, 384 B each
+    const unsigned bstage = lstage + 8u * 384u;                            // two blocks (16 boxes each) of a long list (-DMT_HS_LDS_LONG)
+    (void)bstage;
     const char *const hs_bytes = (const char *)S.hs_rec;
+#ifdef MT_PROF
+    const bool tl_on = S.prof != nullptr && lane == 0 && stk.base == 0u && __builtin_amdgcn_workgroup_id_x() == 0;
+    unsigned long long tl_base = 0ull;  // 512 slots per traversal, reserved with ONE atomic; the stamps are plain stores
+    unsigned tl_i = 0u;
+    if (tl_on) tl_base = atomicAdd(S.prof + PROF_COUNT, 512ull);
+    MT_TL(1);  // walk begins
+#endif
     int lev = -1;                        // frame on top of the stack, -1 none
     unsigned long long pend = 0ull;      // wave-uniform; byte l: children of frame l still to look at
     unsigned long long wantbits = 0ull;  // per lane; byte l: children of frame l this lane's filter lets through
@@ -2080,6 +2103,168 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       }
       return -1;
     };
+    // copies `bytes` (<= 2048, wave-uniform) from src to LDS: one or two LDS-DMA instructions; returns how many
+    [[maybe_unused]] auto dma_range = [&](const char *src, unsigned lds, int bytes) -> int {
+      if (lane * 16 < bytes) lds_dma16(src + (size_t)lane * 16, lds);
+      if (bytes > 1024) {
+        if (lane * 16 < bytes - 1024) lds_dma16(src + 1024 + (size_t)lane * 16, lds + 1024u);
+        return 2;
+      }
+      return 1;
+    };
+    // waits until at most n of the copies / loads issued so far are still in flight (they complete in order)
+    auto wait_vm = [&](int n) {
+      switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+      }
+    };
+    // fp32 verdicts on a staged short list (boxes at lds, n of them): bit k = this lane's ray may hit box k
+    auto list_bits = [&](unsigned lds, int n) -> unsigned {
+      typedef float f4v_ __attribute__((ext_vector_type(4)));
+      const MT_LDS f4v_ *t4 = (const MT_LDS f4v_ *)(uintptr_t)lds;
+      unsigned cand = 0u;
+      for (int k = 0; k < n; k += 4) {  // four boxes = six 16-byte reads; boxes past the list are masked off below
+        float tb[24];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const f4v_ q = t4[(k >> 2) * 6 + i];
+          tb[i * 4 + 0] = q.x; tb[i * 4 + 1] = q.y; tb[i * 4 + 2] = q.z; tb[i * 4 + 3] = q.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if (subtree_may_hit(tb + j * 6, f32, sxl != 0, syl != 0, szl != 0)) cand |= 1u << (k + j);
+        }
+      }
+      return cand & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u));
+    };
+    // every lane resolves ITS candidates of the list starting at stream position pb_ in list order
+    // (octtree.cc:177-196): exact box and vertices are fetched together, one round trip per candidate
+    auto resolve_list = [&](int pb_, unsigned cand, int &b_, double &bt_, unsigned &mt_, unsigned &bv_) {
+      // start fetching the candidates' exact boxes and vertices now (both ends of each: they may
+      // straddle a cache line); the loop below finds them on their way.  "+v": one register for all
+      // of these loads, live until after that loop, so that a late arrival lands nowhere else
+      unsigned warm = 0u;
+      {
+        unsigned w = cand;
+        for (int guard = 0; guard < 4 && w != 0u; guard++) {
+          const int k = __builtin_ctz(w);
+          w &= w - 1u;
+          const char *ep = (const char *)(S.tri_aabb + (size_t)(pb_ + k) * 6);
+          const char *vp = (const char *)(S.tri_vertex + (size_t)(pb_ + k) * 9);
+          asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:44\n\t"
+                       "global_load_dword %0, %2, off\n\tglobal_load_dword %0, %2, off offset:68"
+                       : "+v"(warm) : "v"(ep), "v"(vp));
+        }
+      }
+      for (int guard = 0; guard <= kBigNode && __ballot(cand != 0u) != 0ull; guard++) {
+        if (cand != 0u) {
+          const int t = pb_ + __builtin_ctz(cand);
+          cand &= cand - 1u;
+          const double *ep = S.tri_aabb + (size_t)t * 6;
+          const double *vp = S.tri_vertex + (size_t)t * 9;
+          const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
+          const double v[9] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
+          bv_ += 120u;
+          if (slab_pass_lane<false>(e, r)) {
+            mt_++;
+            double tt;
+            if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
+              if (!(b_ >= 0 && tt > bt_)) {
+                b_ = t;
+                bt_ = tt;
+              }
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(warm));  // nothing of the warming loads outlives this point
+    };
+    // Offers the result (rp_, rt_; rp_ < 0 = none) that the lanes brought back from child slot_ to the frame
+    // on top, and lets the lanes that hold a candidate drop the children that sort behind it.
+    auto offer = [&](int slot_, int rp_, double rt_) {
+      // offer child `slot_`'s result to frame `lev`: octtree.cc:204-211 (does the
+      // ray enter that child's box, at what distance) and :226-246 (not farther
+      // than the own hit; first in sorted order = smallest (distance, index))
+      struct { double lo[3], c[3], hi[3]; } Pv;
+      {
+        const MT_LDS double *pl = h_planes + lev * 10;
+        Pv.lo[0] = pl[0]; Pv.lo[1] = pl[1]; Pv.lo[2] = pl[2];
+        Pv.c[0] = pl[3]; Pv.c[1] = pl[4]; Pv.c[2] = pl[5];
+        Pv.hi[0] = pl[6]; Pv.hi[1] = pl[7]; Pv.hi[2] = pl[8];
+      }
+      const auto *P = &Pv;
+      double amin[3][2], amax[3][2];
+      {
+        const double t0 = (P->lo[0] - r.ox) * r.ix, tc = (P->c[0] - r.ox) * r.ix, t1 = (P->hi[0] - r.ox) * r.ix;
+        amax[0][0] = mx<false>(t0, tc); amin[0][0] = mn<false>(t0, tc);
+        amax[0][1] = mx<false>(tc, t1); amin[0][1] = mn<false>(tc, t1);
+      }
+      {
+        const double t0 = (P->lo[1] - r.oy) * r.iy, tc = (P->c[1] - r.oy) * r.iy, t1 = (P->hi[1] - r.oy) * r.iy;
+        amax[1][0] = mx<false>(t0, tc); amin[1][0] = mn<false>(t0, tc);
+        amax[1][1] = mx<false>(tc, t1); amin[1][1] = mn<false>(tc, t1);
+      }
+      {
+        const double t0 = (P->lo[2] - r.oz) * r.iz, tc = (P->c[2] - r.oz) * r.iz, t1 = (P->hi[2] - r.oz) * r.iz;
+        amax[2][0] = mx<false>(t0, tc); amin[2][0] = mn<false>(t0, tc);
+        amax[2][1] = mx<false>(tc, t1); amin[2][1] = mn<false>(tc, t1);
+      }
+      // child index bits: 0 = x high, 1 = z high, 2 = y high (octtree.cc:61-100)
+      const bool xh = (slot_ & 1) != 0, zh = (slot_ & 2) != 0, yh = (slot_ & 4) != 0;  // wave-uniform
+      const double tmax = mn3<false>(xh ? amax[0][1] : amax[0][0], yh ? amax[1][1] : amax[1][0], zh ? amax[2][1] : amax[2][0]);
+      const double tmin = mx3<false>(xh ? amin[0][1] : amin[0][0], yh ? amin[1][1] : amin[1][0], zh ? amin[2][1] : amin[2][0]);
+      const bool entered = (tmax >= 0.0) & (tmin <= tmax);
+      const int own_p = h_own_p[lev * 64 + lane];
+      const double own_t = h_own_t[lev * 64 + lane];
+      if (rp_ >= 0 && entered && !(own_p >= 0 && rt_ > own_t)) {
+        const int wp = h_win_p[lev * 64 + lane];
+        bool take = wp < 0;
+        if (!take) {
+          const int kw = (int)((unsigned)wp >> 28);
+          const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
+          const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
+          take = (tmin < wmin) || (tmin == wmin && slot_ < kw);
+        }
+        if (take) {
+          h_win_p[lev * 64 + lane] = rp_ | (slot_ << 28);
+          h_win_t[lev * 64 + lane] = rt_;
+        }
+      }
+      // Lanes that hold a candidate drop the children that sort behind it: the reference's
+      // loop would have stopped before them (they could only be looked at, never taken).
+      {
+        const int sh0 = 8 * lev;
+        unsigned rest = (unsigned)(pend >> sh0) & 0xffu;
+        if (rest != 0u) {
+          const int wp = h_win_p[lev * 64 + lane];
+          const int kw = (int)((unsigned)wp >> 28) & 7;
+          const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
+          const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
+          unsigned my = (unsigned)(wantbits >> sh0) & 0xffu;
+          unsigned still = 0u;
+          while (rest != 0u) {
+            const int c2 = __builtin_ctz(rest);
+            rest &= rest - 1u;
+            const bool cxh = (c2 & 1) != 0, czh = (c2 & 2) != 0, cyh = (c2 & 4) != 0;  // wave-uniform
+            const double cmin = mx3<false>(cxh ? amin[0][1] : amin[0][0], cyh ? amin[1][1] : amin[1][0], czh ? amin[2][1] : amin[2][0]);
+            const bool behind = wp >= 0 && !((cmin < wmin) || (cmin == wmin && c2 < kw));
+            if (behind) my &= ~(1u << c2);
+            if (__ballot(((my >> c2) & 1u) != 0u) != 0ull) still |= 1u << c2;
+          }
+          wantbits = (wantbits & ~(0xffull << sh0)) | ((unsigned long long)my << sh0);
+          pend = (pend & ~(0xffull << sh0)) | ((unsigned long long)still << sh0);
+        }
+      }
+    };
     if (m != 0ull) {
       hs_fetch(0, 0);
       for (;;) {
@@ -2099,6 +2284,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       pend = ((unsigned long long)(unsigned)uniform_i32((int)(pend >> 32)) << 32) | (unsigned)uniform_i32((int)pend);
       m = ((unsigned long long)(unsigned)uniform_i32((int)(m >> 32)) << 32) | (unsigned)uniform_i32((int)m);
       if (entering) {
+        MT_TL(2);  // ENTER
         const bool in = ((m >> lane) & 1ull) != 0ull;
         MT_PROF_BEGIN(prof_t1);
         if ((buf == 0 ? staged0 : staged1) != node) hs_fetch(node, buf);  // not the node that was foreseen
@@ -2111,6 +2297,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
 #ifdef MT_PROF
         MT_PROF_COUNT(PROF_HS_CLOSE_T, __builtin_amdgcn_s_memtime() - tw0);
 #endif
+        MT_TL(3);  // record landed
         const unsigned rec = stage + (unsigned)buf * (unsigned)sizeof(HsRec);
         const MT_LDS int *ri = (const MT_LDS int *)(uintptr_t)rec;
         const int fc = uniform_i32(ri[0]), pb = uniform_i32(ri[1]), pc = uniform_i32(ri[2]);
@@ -2125,6 +2312,14 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         // a short list's fp32 boxes are copied to LDS while the children are tested
         const bool small_list = pc > 0 && pc < kBigNode;
         if (small_list && lane < 48) lds_dma16((const char *)S.tri_aabb32 + (size_t)pb * 24 + (size_t)lane * 16, tstage);
+        // ... and the block boxes of a long list (48 at a time: the counters' bytes hold 53)
+        const bool long_list = pc >= kBigNode;
+        const int lb0 = pb / kGroupTris, lnb = long_list ? (pb + pc - 1) / kGroupTris - lb0 + 1 : 0;
+#ifdef MT_HS_LDS_LONG
+        if (long_list) dma_range((const char *)S.grp_aabb32 + (size_t)lb0 * 24, tstage, (lnb < 48 ? lnb : 48) * 24);
+#else
+        (void)lnb;
+#endif
         if (STATS) {
           st.wave_node_steps++;
           st.wave_tri_steps += (unsigned)pc;
@@ -2152,10 +2347,35 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
             const bool pass = subtree_may_hit(bxs + c * 6, f32, sxl != 0, syl != 0, szl != 0);
             if (pass) bits |= 1u << c;
           }
+#if MT_KNOCK == 4  // timing experiment: the child tests twice
+          {
+            unsigned bits2 = 0u;
+            asm volatile("" : "+v"(bxs[0]), "+v"(bxs[7]), "+v"(bxs[14]), "+v"(bxs[21]), "+v"(bxs[28]), "+v"(bxs[35]), "+v"(bxs[42]), "+v"(bxs[47]));
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+              if (subtree_may_hit(bxs + c * 6, f32, sxl != 0, syl != 0, szl != 0)) bits2 |= 1u << c;
+            }
+            asm volatile("" :: "v"(bits2));
+          }
+#endif
           bits = in ? (bits & cm) : 0u;  // (cm: children with an empty subtree hold an inverted box anyway)
 #pragma unroll
           for (int c = 0; c < 8; c++) {
             if (__ballot(((bits >> c) & 1u) != 0u) != 0ull) any |= 1u << c;
+          }
+        }
+        MT_TL(4);  // child tests done
+        // Children that are leaves with a short list are not entered: their boxes are copied to LDS now
+        // (all of them at once, while the own list is scanned) and their lists are scanned from this step.
+        unsigned inl = 0u;
+        int n_leaf_dma = 0;
+        if (any != 0u) {
+          inl = any & ((unsigned)uniform_i32(ri[78]) & 0xffu);
+          for (unsigned w = inl; w != 0u; w &= w - 1u) {
+            const int c = __builtin_ctz(w);
+            const int kb = uniform_i32(ri[80 + c]);
+            if (lane < 24) lds_dma16((const char *)S.tri_aabb32 + (size_t)kb * 24 + (size_t)lane * 16, lstage + (unsigned)c * 384u);
+            n_leaf_dma++;
           }
         }
         // the own list's union box decides who scans it
@@ -2169,8 +2389,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         // stage the record of the node that comes next while this one's list is scanned
         bool fetched_next = false;
         {
-          const int nxt = any != 0u ? fc + pick(any) : next_after(lev, pend);
-          if (nxt >= 0) {
+          const unsigned step_kids = any & ~inl;
+          const int nxt = step_kids != 0u ? fc + pick(step_kids) : next_after(lev, pend);
+          if (nxt >= 0 && MT_KNOCK != 3) {
             hs_fetch(nxt, buf ^ 1);
             fetched_next = true;
           }
@@ -2181,76 +2402,30 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         MT_PROF_END(PROF_HS_KIDS_T, prof_t1);
         MT_PROF_BEGIN(prof_t1);
 #endif
+        MT_TL(5);  // copies issued, next node known
         int best = -1;
         double best_t = 0.0;
-        if (small_list && lm != 0ull) {
+        if (small_list && lm != 0ull && MT_KNOCK != 2 && MT_KNOCK != 7) {
           // the boxes were requested before the next node's record: all but that last copy must have landed
-          if (fetched_next) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          unsigned cand = 0u;  // per lane: list positions whose fp32 box the ray may hit
+          wait_vm(n_leaf_dma + (fetched_next ? 1 : 0));
+          unsigned cand = in_list ? list_bits(tstage, pc) : 0u;  // per lane: list positions whose fp32 box the ray may hit
+#if MT_KNOCK == 5  // timing experiment: the fp32 tests of a short list twice
           {
-            const MT_LDS f4v *t4 = (const MT_LDS f4v *)(uintptr_t)tstage;
-            for (int k = 0; k < pc; k += 4) {  // four boxes = six 16-byte reads; boxes past the list are masked off below
-              float tb[24];
-#pragma unroll
-              for (int i = 0; i < 6; i++) {
-                const f4v q = t4[(k >> 2) * 6 + i];
-                tb[i * 4 + 0] = q.x; tb[i * 4 + 1] = q.y; tb[i * 4 + 2] = q.z; tb[i * 4 + 3] = q.w;
-              }
-#pragma unroll
-              for (int j = 0; j < 4; j++) {
-                if (subtree_may_hit(tb + j * 6, f32, sxl != 0, syl != 0, szl != 0)) cand |= 1u << (k + j);
-              }
-            }
-            cand &= (pc >= 32 ? 0xffffffffu : ((1u << pc) - 1u));
-            if (!in_list) cand = 0u;
+            asm volatile("" ::: "memory");
+            const unsigned c2 = in_list ? list_bits(tstage, pc) : 0u;
+            asm volatile("" :: "v"(c2));
           }
-          // start fetching the candidates' exact boxes and vertices now (both ends of each: they may
-          // straddle a cache line); the loop below finds them on their way.  "+v": one register for all
-          // of these loads, live until after that loop, so that a late arrival lands nowhere else
-          unsigned warm = 0u;
-          {
-            unsigned w = cand;
-            for (int guard = 0; guard < 4 && w != 0u; guard++) {
-              const int k = __builtin_ctz(w);
-              w &= w - 1u;
-              const char *ep = (const char *)(S.tri_aabb + (size_t)(pb + k) * 6);
-              const char *vp = (const char *)(S.tri_vertex + (size_t)(pb + k) * 9);
-              asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:44\n\t"
-                           "global_load_dword %0, %2, off\n\tglobal_load_dword %0, %2, off offset:68"
-                           : "+v"(warm) : "v"(ep), "v"(vp));
-            }
-          }
+#endif
           if (STATS) st.bytes_scalar += 24u * (unsigned)pc;
-          // every lane resolves ITS candidates in list order (octtree.cc:177-196): exact box and
-          // vertices are fetched together, one round trip per candidate
           unsigned mt = 0u, bv = 0u;
-          for (int guard = 0; __ballot(cand != 0u) != 0ull; guard++) {
-            if (guard > kBigNode) {  // cannot happen: one bit per trip
-              status = DEV_ERR_TRAVERSAL_BOUND;
-              break;
-            }
-            if (cand != 0u) {
-              const int t = pb + __builtin_ctz(cand);
-              cand &= cand - 1u;
-              const double *ep = S.tri_aabb + (size_t)t * 6;
-              const double *vp = S.tri_vertex + (size_t)t * 9;
-              const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
-              const double v[9] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
-              bv += 120u;
-              if (slab_pass_lane<false>(e, r)) {
-                mt++;
-                double tt;
-                if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
-                  if (!(best >= 0 && tt > best_t)) {
-                    best = t;
-                    best_t = tt;
-                  }
-                }
-              }
-            }
+#if MT_KNOCK == 6  // timing experiment: candidates of a short list resolved twice
+          {
+            int b2 = -1; double t2 = 0.0; unsigned m2 = 0u, v2 = 0u;
+            resolve_list(pb, cand, b2, t2, m2, v2);
+            asm volatile("" :: "v"(b2), "v"(t2));
           }
-          asm volatile("s_waitcnt vmcnt(0)" : "+v"(warm));  // nothing of the warming loads outlives this point
+#endif
+          resolve_list(pb, cand, best, best_t, mt, bv);
           if (status != DEV_OK) break;
           if (STATS) {
             if (mt) MT_CNT_ADD(3, mt);
@@ -2260,7 +2435,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           asm volatile("" :: "v"(best), "v"(best_t));
           MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc);
 #endif
-        } else if (lm != 0ull) {
+        } else if (lm != 0ull && MT_KNOCK != 1 && MT_KNOCK != 7) {
           const unsigned long long mxs = __ballot(in_list && sxl), mys = __ballot(in_list && syl), mzs = __ballot(in_list && szl);
           const bool one_octant = (mxs == 0 || mxs == lm) && (mys == 0 || mys == lm) && (mzs == 0 || mzs == lm);
           const int oct = one_octant ? ((mxs != 0 ? 1 : 0) | (mys != 0 ? 2 : 0) | (mzs != 0 ? 4 : 0)) : 8;
@@ -2271,10 +2446,89 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           ScanOut o{-1, 0.0, 0u};
           if (transposed) {
             o = scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in_list, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
-          } else if (in_list) {
+          }
+#ifndef MT_HS_LDS_LONG  // (default: the long lists go through the scalar-stream scans; the LDS form below is 10 % slower)
+          else if (in_list) {
             o = scan_filtered_dispatch<STATS, true>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
             if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
           }
+#else
+          else if (!blocks_ok) {
+            if (in_list) {  // (a short list that took this path: timing experiments only)
+              o = scan_filtered_dispatch<STATS, true>(S, oct, nullptr, pb, pc, r, f32);
+              if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
+            }
+          } else {
+            // Long list from LDS, no call: block boxes (copied while the children were tested) -> per-lane
+            // live bits; every block that is live for some lane: its 16 triangle boxes copied (the next live
+            // block's copy is issued before the current one is looked at), fp32 verdicts, candidates resolved
+            // in list order.  Same tests on the same boxes as scan_grouped_call.
+            (void)oct;
+            unsigned mt = 0u, bv = 0u;
+            for (int c0 = 0; c0 < lnb; c0 += 48) {
+              const int n = lnb - c0 < 48 ? lnb - c0 : 48;
+              if (c0 > 0) {
+                dma_range((const char *)S.grp_aabb32 + (size_t)(lb0 + c0) * 24, tstage, n * 24);
+                wait_vm(0);
+              } else {
+                wait_vm(n_leaf_dma + (fetched_next ? 1 : 0));
+              }
+              if (STATS) st.bytes_scalar += 24u * (unsigned)n;
+              unsigned long long live = 0ull, anyb = 0ull;
+              {
+                typedef float f4v_ __attribute__((ext_vector_type(4)));
+                const MT_LDS f4v_ *t4 = (const MT_LDS f4v_ *)(uintptr_t)tstage;
+                for (int k = 0; k < n; k += 4) {
+                  float tb[24];
+#pragma unroll
+                  for (int i = 0; i < 6; i++) {
+                    const f4v_ q = t4[(k >> 2) * 6 + i];
+                    tb[i * 4 + 0] = q.x; tb[i * 4 + 1] = q.y; tb[i * 4 + 2] = q.z; tb[i * 4 + 3] = q.w;
+                  }
+#pragma unroll
+                  for (int j = 0; j < 4; j++) {
+                    const bool pass = in_list && (k + j < n) && subtree_may_hit(tb + j * 6, f32, sxl != 0, syl != 0, szl != 0);
+                    if (pass) live |= 1ull << (k + j);
+                    if (__ballot(pass) != 0ull) anyb |= 1ull << (k + j);
+                  }
+                }
+              }
+              anyb = uniform_u64(anyb);
+              int nextj = anyb != 0ull ? __builtin_ctzll(anyb) : -1;
+              int bb = 0;
+              auto block_range = [&](int j, int &first, int &cnt) {
+                const int blk = lb0 + c0 + j;
+                first = blk * kGroupTris < pb ? pb : blk * kGroupTris;
+                const int last = blk * kGroupTris + kGroupTris > pb + pc ? pb + pc : blk * kGroupTris + kGroupTris;
+                cnt = last - first;
+              };
+              if (nextj >= 0) {
+                int f0, n0;
+                block_range(nextj, f0, n0);
+                dma_range((const char *)S.tri_aabb32 + (size_t)f0 * 24, bstage, n0 * 24);
+              }
+              for (int guard = 0; nextj >= 0 && guard < 64; guard++) {
+                const int j = nextj;
+                anyb &= anyb - 1ull;
+                nextj = anyb != 0ull ? __builtin_ctzll(anyb) : -1;
+                if (nextj >= 0) {
+                  int f1, n1;
+                  block_range(nextj, f1, n1);
+                  dma_range((const char *)S.tri_aabb32 + (size_t)f1 * 24, bstage + (unsigned)(bb ^ 1) * 384u, n1 * 24);
+                }
+                wait_vm(nextj >= 0 ? 1 : 0);
+                int first, cnt;
+                block_range(j, first, cnt);
+                const unsigned cand = ((live >> j) & 1ull) != 0ull ? list_bits(bstage + (unsigned)bb * 384u, cnt) : 0u;
+                if (STATS) st.bytes_scalar += 24u * (unsigned)cnt;
+                resolve_list(first, cand, o.best, o.best_t, mt, bv);
+                bb ^= 1;
+              }
+            }
+            o.mt_tests = mt;
+            o.bytes_v = bv;
+          }
+#endif
           if (in_list) {
             best = o.best;
             best_t = o.best_t;
@@ -2290,6 +2544,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         } else {
           MT_PROF_COUNT(PROF_HS_N_EMPTY, 1);
         }
+        MT_TL(6);  // own list done
         entering = false;
         if (any == 0u) {  // a leaf, or nothing to look at below: the node's result is its own list's
           ret_p = best;
@@ -2311,87 +2566,46 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + 240u))[lane];
         const int sh = 8 * lev;
         wantbits = (wantbits & ~(0xffull << sh)) | ((unsigned long long)bits << sh);
-        pend = (pend & ~(0xffull << sh)) | ((unsigned long long)any << sh);
+        pend = (pend & ~(0xffull << sh)) | ((unsigned long long)(any & ~inl) << sh);
         ret_p = -1;  // nothing comes back yet
+        if (inl != 0u) {
+          // the short leaf children, near to far: their lists are in LDS by now (only the next node's
+          // record may still be on its way); each result is offered to the frame as if the wave came back
+          wait_vm(fetched_next ? 1 : 0);
+          unsigned w = inl;
+          while (w != 0u) {
+            const int c = pick(w);
+            w &= ~(1u << c);
+            const bool wants = ((wantbits >> (sh + c)) & 1ull) != 0ull;
+            const int pcc = (int)(((unsigned)uniform_i32(ri[58 + (c >> 2)]) >> (8 * (c & 3))) & 0xffu);
+            const int pbc = uniform_i32(ri[80 + c]);
+            unsigned cand = wants ? list_bits(lstage + (unsigned)c * 384u, pcc) : 0u;
+            int lb = -1;
+            double lt = 0.0;
+            unsigned mt = 0u, bv = 0u;
+            resolve_list(pbc, cand, lb, lt, mt, bv);
+            if (STATS) {
+              st.wave_tri_steps += (unsigned)pcc;  // (wave_node_steps counts the walk's steps: none is taken for this leaf)
+              st.bytes_scalar += 24u * (unsigned)pcc;
+              if (wants) {
+                MT_CNT_ADD(1, 1u);
+                MT_CNT_ADD(2, (unsigned)pcc);
+              }
+              if (mt) MT_CNT_ADD(3, mt);
+              if (bv) MT_CNT_ADD(4, bv);
+            }
+            if (__ballot(lb >= 0) != 0ull) offer(c, lb, lt);
+          }
+        }
+        MT_TL(7);  // frame open, short leaf children done
       } else {
+        MT_TL(8);  // back at a frame
         if (lev < 0) break;  // ret_* is the root's result
         MT_PROF_BEGIN(prof_t1);
         MT_PROF_COUNT(PROF_HS_N_RET, 1);
         if (__ballot(ret_p >= 0) != 0ull) {
           MT_PROF_COUNT(PROF_HS_N_RETHIT, 1);
-          // offer child `slot`'s result to frame `lev`: octtree.cc:204-211 (does the
-          // ray enter that child's box, at what distance) and :226-246 (not farther
-          // than the own hit; first in sorted order = smallest (distance, index))
-          struct { double lo[3], c[3], hi[3]; } Pv;
-          {
-            const MT_LDS double *pl = h_planes + lev * 10;
-            Pv.lo[0] = pl[0]; Pv.lo[1] = pl[1]; Pv.lo[2] = pl[2];
-            Pv.c[0] = pl[3]; Pv.c[1] = pl[4]; Pv.c[2] = pl[5];
-            Pv.hi[0] = pl[6]; Pv.hi[1] = pl[7]; Pv.hi[2] = pl[8];
-          }
-          const auto *P = &Pv;
-          double amin[3][2], amax[3][2];
-          {
-            const double t0 = (P->lo[0] - r.ox) * r.ix, tc = (P->c[0] - r.ox) * r.ix, t1 = (P->hi[0] - r.ox) * r.ix;
-            amax[0][0] = mx<false>(t0, tc); amin[0][0] = mn<false>(t0, tc);
-            amax[0][1] = mx<false>(tc, t1); amin[0][1] = mn<false>(tc, t1);
-          }
-          {
-            const double t0 = (P->lo[1] - r.oy) * r.iy, tc = (P->c[1] - r.oy) * r.iy, t1 = (P->hi[1] - r.oy) * r.iy;
-            amax[1][0] = mx<false>(t0, tc); amin[1][0] = mn<false>(t0, tc);
-            amax[1][1] = mx<false>(tc, t1); amin[1][1] = mn<false>(tc, t1);
-          }
-          {
-            const double t0 = (P->lo[2] - r.oz) * r.iz, tc = (P->c[2] - r.oz) * r.iz, t1 = (P->hi[2] - r.oz) * r.iz;
-            amax[2][0] = mx<false>(t0, tc); amin[2][0] = mn<false>(t0, tc);
-            amax[2][1] = mx<false>(tc, t1); amin[2][1] = mn<false>(tc, t1);
-          }
-          // child index bits: 0 = x high, 1 = z high, 2 = y high (octtree.cc:61-100)
-          const bool xh = (slot & 1) != 0, zh = (slot & 2) != 0, yh = (slot & 4) != 0;  // wave-uniform
-          const double tmax = mn3<false>(xh ? amax[0][1] : amax[0][0], yh ? amax[1][1] : amax[1][0], zh ? amax[2][1] : amax[2][0]);
-          const double tmin = mx3<false>(xh ? amin[0][1] : amin[0][0], yh ? amin[1][1] : amin[1][0], zh ? amin[2][1] : amin[2][0]);
-          const bool entered = (tmax >= 0.0) & (tmin <= tmax);
-          const int own_p = h_own_p[lev * 64 + lane];
-          const double own_t = h_own_t[lev * 64 + lane];
-          if (ret_p >= 0 && entered && !(own_p >= 0 && ret_t > own_t)) {
-            const int wp = h_win_p[lev * 64 + lane];
-            bool take = wp < 0;
-            if (!take) {
-              const int kw = (int)((unsigned)wp >> 28);
-              const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
-              const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
-              take = (tmin < wmin) || (tmin == wmin && slot < kw);
-            }
-            if (take) {
-              h_win_p[lev * 64 + lane] = ret_p | (slot << 28);
-              h_win_t[lev * 64 + lane] = ret_t;
-            }
-          }
-          // Lanes that hold a candidate drop the children that sort behind it: the reference's
-          // loop would have stopped before them (they could only be looked at, never taken).
-          {
-            const int sh0 = 8 * lev;
-            unsigned rest = (unsigned)(pend >> sh0) & 0xffu;
-            if (rest != 0u) {
-              const int wp = h_win_p[lev * 64 + lane];
-              const int kw = (int)((unsigned)wp >> 28) & 7;
-              const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
-              const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
-              unsigned my = (unsigned)(wantbits >> sh0) & 0xffu;
-              unsigned still = 0u;
-              while (rest != 0u) {
-                const int c2 = __builtin_ctz(rest);
-                rest &= rest - 1u;
-                const bool cxh = (c2 & 1) != 0, czh = (c2 & 2) != 0, cyh = (c2 & 4) != 0;  // wave-uniform
-                const double cmin = mx3<false>(cxh ? amin[0][1] : amin[0][0], cyh ? amin[1][1] : amin[1][0], czh ? amin[2][1] : amin[2][0]);
-                const bool behind = wp >= 0 && !((cmin < wmin) || (cmin == wmin && c2 < kw));
-                if (behind) my &= ~(1u << c2);
-                if (__ballot(((my >> c2) & 1u) != 0u) != 0ull) still |= 1u << c2;
-              }
-              wantbits = (wantbits & ~(0xffull << sh0)) | ((unsigned long long)my << sh0);
-              pend = (pend & ~(0xffull << sh0)) | ((unsigned long long)still << sh0);
-            }
-          }
+          offer(slot, ret_p, ret_t);
         }
         const int sh = 8 * lev;
         const unsigned todo = (unsigned)(pend >> sh) & 0xffu;
@@ -2410,6 +2624,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           slot = lev >= 0 ? closed - uniform_i32(h_node[lev * 2 + 1]) : 0;
           continue;
         }
+        MT_TL(9);  // offer done, next child picked
         const int c = pick(todo);
         pend &= ~(1ull << (sh + c));
         m = __ballot(((wantbits >> (sh + c)) & 1ull) != 0ull);
