@@ -672,9 +672,27 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
       h.planes[6 + k] = r.hi[k];
     }
   }
+  // Second level (mt_device.h kSuperBlocks): one fp32 union box per 8 consecutive blocks, for the long lists.
+  std::vector<float> supers;
+  {
+    const size_t nblk = groups.size() / 6;
+    for (size_t b = 0; b < nblk; b += kSuperBlocks) {
+      float u[6];
+      for (int k = 0; k < 6; k++) u[k] = groups[b * 6 + k];
+      for (size_t j = b + 1; j < std::min(b + (size_t)kSuperBlocks, nblk); j++) {
+        for (int k = 0; k < 3; k++) {
+          u[k] = std::min(u[k], groups[j * 6 + k]);
+          u[3 + k] = std::max(u[3 + k], groups[j * 6 + 3 + k]);
+        }
+      }
+      for (int k = 0; k < 6; k++) supers.push_back(u[k]);
+    }
+    supers.resize(supers.size() + 8 * 6, 0.0f);  // look-ahead padding
+  }
   groups.resize(groups.size() + 8 * 6, 0.0f);  // the scan looks four boxes ahead
   int rc;
   if ((rc = upload(s, groups.data(), groups.size(), &s->dev.grp_aabb32)) != MT_OK) return rc;
+  if ((rc = upload(s, supers.data(), supers.size(), &s->dev.sup_aabb32)) != MT_OK) return rc;
   if ((rc = upload(s, subs.data(), subs.size(), &s->dev.sub_aabb32)) != MT_OK) return rc;
   if ((rc = upload(s, hsr.data(), hsr.size(), &s->dev.hs_rec)) != MT_OK) return rc;
   if ((rc = upload(s, recs.data(), recs.size(), &s->dev.nodes)) != MT_OK) return rc;

@@ -52,6 +52,11 @@ static_assert(sizeof(NodeRec) == 96, "NodeRec must be 96 bytes");
 // (primitive_triangle.cc:73-76) for every member, so the block is skipped.
 constexpr int kBigNode = 32;
 constexpr int kGroupTris = 16;
+constexpr int kSuperBlocks = 8;   // blocks per second-level box
+#ifndef MT_SUPER_MIN
+#define MT_SUPER_MIN 24
+#endif
+constexpr int kSuperMin = MT_SUPER_MIN;  // lists that touch at least this many blocks are scanned through the second level
 
 // Everything the hit-set traversal (-DMT_HS, mt_trace.h) needs to know about a
 // node before it looks at triangles, in one 256-byte record that a wave
@@ -83,6 +88,7 @@ struct DevScene {
   const double *tri_aabb;    // 6 per triangle, node-stream order
   const float *tri_aabb32;   // the same boxes rounded to fp32 (conservative pre-filter)
   const float *grp_aabb32;   // fp32 union box of each block of kGroupTris consecutive stream triangles
+  const float *sup_aabb32;   // fp32 union box of each run of kSuperBlocks consecutive blocks (long lists)
   const float *sub_aabb32;   // per node: fp32 union box of all triangles in its subtree
   const HsRec *hs_rec;       // per node (hit-set traversal)
   double bmax[3];            // max |coordinate| of any triangle box, per axis

@@ -1435,6 +1435,7 @@ __device__ __forceinline__ DevScene scan_ctx_self(const DevScene *self) {
   S.tri_aabb = G->tri_aabb;
   S.tri_aabb32 = G->tri_aabb32;
   S.grp_aabb32 = G->grp_aabb32;
+  S.sup_aabb32 = G->sup_aabb32;
   S.tri_vertex = G->tri_vertex;
   return S;
 }
@@ -1543,8 +1544,27 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
 #ifdef MT_PROF
     const unsigned long long tg0 = __builtin_amdgcn_s_memtime();
 #endif
-    unsigned long long live = group_live_mask<OCT>(gp + (size_t)(b0 + g0) * 6, n, f);
-    if (STATS) st.bytes_scalar += 96u * (unsigned)((n + 3) / 4 + 1);  // block boxes, four per fetch
+    unsigned long long live;
+    if (FUSED && nb >= kSuperMin) {
+      // two levels: the boxes of the runs of 8 blocks this chunk touches first, block boxes only inside the live runs
+      // (a ray that misses a run's union box misses every block box in it: the same monotonicity argument)
+      const int s0 = (b0 + g0) / kSuperBlocks, s1 = (b0 + g0 + n - 1) / kSuperBlocks;
+      unsigned long long sl = group_live_mask<OCT>(as_const(S.sup_aabb32) + (size_t)s0 * 6, s1 - s0 + 1, f);
+      if (STATS) st.bytes_scalar += 96u * (unsigned)((s1 - s0 + 4) / 4 + 1);
+      live = 0ull;
+      while (sl != 0ull) {
+        const int si = s0 + __builtin_ctzll(sl);
+        sl &= sl - 1ull;
+        int first = si * kSuperBlocks, last = first + kSuperBlocks;
+        if (first < b0 + g0) first = b0 + g0;
+        if (last > b0 + g0 + n) last = b0 + g0 + n;
+        live |= group_live_mask<OCT>(gp + (size_t)first * 6, last - first, f) << (first - (b0 + g0));
+        if (STATS) st.bytes_scalar += 96u * 3u;
+      }
+    } else {
+      live = group_live_mask<OCT>(gp + (size_t)(b0 + g0) * 6, n, f);
+    }
+    if (STATS && !(FUSED && nb >= kSuperMin)) st.bytes_scalar += 96u * (unsigned)((n + 3) / 4 + 1);  // block boxes, four per fetch
 #ifdef MT_PROF
     const unsigned long long tg1 = __builtin_amdgcn_s_memtime();
     o.t_a += (unsigned)(tg1 - tg0);
