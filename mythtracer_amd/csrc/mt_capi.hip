@@ -704,7 +704,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     if ((rc = upload(s, boxes.data(), boxes.size(), &s->dev.tri_aabb)) != MT_OK) return rc;
     // fp32 copy for the conservative pre-filter (mt_trace.h Filter32); padded by
     // 8 boxes because that loop looks four boxes ahead.
-    std::vector<float> boxes32(nt * 6 + 40 * 6, 0.0f);  // (the hit-set traversal copies 32 boxes from a list's start)
+    std::vector<float> boxes32(nt * 6 + 64 * 6, 0.0f);  // (padding: the look-ahead of the scans; the hit-set traversal copies whole 16-byte pieces)
     double bmax[3] = {0.0, 0.0, 0.0};
     for (size_t i = 0; i < nt * 6; i++) {
       boxes32[i] = (float)boxes[i];

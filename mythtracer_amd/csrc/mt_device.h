@@ -75,6 +75,10 @@ struct HsRec {
 };
 static_assert(sizeof(HsRec) == 352, "HsRec must be 352 bytes");
 constexpr int kHsRecLanes = 22;   // 16 bytes per lane
+#ifndef MT_HS_SHORT
+#define MT_HS_SHORT 64
+#endif
+constexpr int kHsShortList = MT_HS_SHORT;  // own lists up to this length are scanned from LDS (64 fp32 boxes staged behind the frames; one candidate bit each)
 constexpr int kHsLeafTris = 16;   // 16 fp32 boxes = 384 bytes = 24 lanes of one LDS-DMA instruction
 
 struct DevTexture {
@@ -214,7 +218,11 @@ __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
   return n;
 }
 __host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
-  size_t n = wave_frames_bytes(depth, packed) + 5 * 64 * 4;  // -DMT_HS: the counters' bytes stage triangle boxes
+#ifdef MT_HS
+  size_t n = wave_frames_bytes(depth, packed) + 64 * 24;  // the fp32 boxes of a short list (the counters are in registers)
+#else
+  size_t n = wave_frames_bytes(depth, packed) + 5 * 64 * 4;
+#endif
 #ifdef MT_VEC_SCAN
   n += 64 * 32;  // staging area of the vector-load scan: 64 boxes of 8 floats
 #endif

@@ -2148,10 +2148,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       }
     };
     // fp32 verdicts on a staged short list (boxes at lds, n of them): bit k = this lane's ray may hit box k
-    auto list_bits = [&](unsigned lds, int n) -> unsigned {
+    auto list_bits = [&](unsigned lds, int n) -> unsigned long long {
       typedef float f4v_ __attribute__((ext_vector_type(4)));
       const MT_LDS f4v_ *t4 = (const MT_LDS f4v_ *)(uintptr_t)lds;
-      unsigned cand = 0u;
+      unsigned long long cand = 0ull;
       for (int k = 0; k < n; k += 4) {  // four boxes = six 16-byte reads; boxes past the list are masked off below
         float tb[24];
 #pragma unroll
@@ -2161,23 +2161,23 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          if (subtree_may_hit(tb + j * 6, f32, sxl != 0, syl != 0, szl != 0)) cand |= 1u << (k + j);
+          if (subtree_may_hit(tb + j * 6, f32, sxl != 0, syl != 0, szl != 0)) cand |= 1ull << (k + j);
         }
       }
-      return cand & (n >= 32 ? 0xffffffffu : ((1u << n) - 1u));
+      return cand & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
     };
     // every lane resolves ITS candidates of the list starting at stream position pb_ in list order
     // (octtree.cc:177-196): exact box and vertices are fetched together, one round trip per candidate
-    auto resolve_list = [&](int pb_, unsigned cand, int &b_, double &bt_, unsigned &mt_, unsigned &bv_) {
+    auto resolve_list = [&](int pb_, unsigned long long cand, int &b_, double &bt_, unsigned &mt_, unsigned &bv_) {
       // start fetching the candidates' exact boxes and vertices now (both ends of each: they may
       // straddle a cache line); the loop below finds them on their way.  "+v": one register for all
       // of these loads, live until after that loop, so that a late arrival lands nowhere else
       unsigned warm = 0u;
       {
-        unsigned w = cand;
-        for (int guard = 0; guard < 4 && w != 0u; guard++) {
-          const int k = __builtin_ctz(w);
-          w &= w - 1u;
+        unsigned long long w = cand;
+        for (int guard = 0; guard < 4 && w != 0ull; guard++) {
+          const int k = __builtin_ctzll(w);
+          w &= w - 1ull;
           const char *ep = (const char *)(S.tri_aabb + (size_t)(pb_ + k) * 6);
           const char *vp = (const char *)(S.tri_vertex + (size_t)(pb_ + k) * 9);
           asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:44\n\t"
@@ -2185,10 +2185,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
                        : "+v"(warm) : "v"(ep), "v"(vp));
         }
       }
-      for (int guard = 0; guard <= kBigNode && __ballot(cand != 0u) != 0ull; guard++) {
-        if (cand != 0u) {
-          const int t = pb_ + __builtin_ctz(cand);
-          cand &= cand - 1u;
+      for (int guard = 0; guard <= 64 && __ballot(cand != 0ull) != 0ull; guard++) {
+        if (cand != 0ull) {
+          const int t = pb_ + __builtin_ctzll(cand);
+          cand &= cand - 1ull;
           const double *ep = S.tri_aabb + (size_t)t * 6;
           const double *vp = S.tri_vertex + (size_t)t * 9;
           const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
@@ -2330,10 +2330,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         MT_PROF_BEGIN(prof_t1);
 #endif
         // a short list's fp32 boxes are copied to LDS while the children are tested
-        const bool small_list = pc > 0 && pc < kBigNode;
-        if (small_list && lane < 48) lds_dma16((const char *)S.tri_aabb32 + (size_t)pb * 24 + (size_t)lane * 16, tstage);
+        const bool small_list = pc > 0 && pc <= kHsShortList;
+        if (small_list) dma_range((const char *)S.tri_aabb32 + (size_t)pb * 24, tstage, pc * 24);
         // ... and the block boxes of a long list (48 at a time: the counters' bytes hold 53)
-        const bool long_list = pc >= kBigNode;
+        const bool long_list = pc > kHsShortList;
         const int lb0 = pb / kGroupTris, lnb = long_list ? (pb + pc - 1) / kGroupTris - lb0 + 1 : 0;
 #ifdef MT_HS_LDS_LONG
         if (long_list) dma_range((const char *)S.grp_aabb32 + (size_t)lb0 * 24, tstage, (lnb < 48 ? lnb : 48) * 24);
@@ -2428,11 +2428,11 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (small_list && lm != 0ull && MT_KNOCK != 2 && MT_KNOCK != 7) {
           // the boxes were requested before the next node's record: all but that last copy must have landed
           wait_vm(n_leaf_dma + (fetched_next ? 1 : 0));
-          unsigned cand = in_list ? list_bits(tstage, pc) : 0u;  // per lane: list positions whose fp32 box the ray may hit
+          unsigned long long cand = in_list ? list_bits(tstage, pc) : 0ull;  // per lane: list positions whose fp32 box the ray may hit
 #if MT_KNOCK == 5  // timing experiment: the fp32 tests of a short list twice
           {
             asm volatile("" ::: "memory");
-            const unsigned c2 = in_list ? list_bits(tstage, pc) : 0u;
+            const unsigned long long c2 = in_list ? list_bits(tstage, pc) : 0ull;
             asm volatile("" :: "v"(c2));
           }
 #endif
@@ -2460,7 +2460,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           const bool one_octant = (mxs == 0 || mxs == lm) && (mys == 0 || mys == lm) && (mzs == 0 || mzs == lm);
           const int oct = one_octant ? ((mxs != 0 ? 1 : 0) | (mys != 0 ? 2 : 0) | (mzs != 0 ? 4 : 0)) : 8;
           const int n_in = __builtin_popcountll(lm);
-          const bool blocks_ok = pc >= kBigNode;
+          const bool blocks_ok = pc > kHsShortList;
           const int nblk = (pb + pc - 1) / kGroupTris - pb / kGroupTris + 1;
           const bool transposed = blocks_ok && (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk);
           ScanOut o{-1, 0.0, 0u};
@@ -2539,7 +2539,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
                 wait_vm(nextj >= 0 ? 1 : 0);
                 int first, cnt;
                 block_range(j, first, cnt);
-                const unsigned cand = ((live >> j) & 1ull) != 0ull ? list_bits(bstage + (unsigned)bb * 384u, cnt) : 0u;
+                const unsigned long long cand = ((live >> j) & 1ull) != 0ull ? list_bits(bstage + (unsigned)bb * 384u, cnt) : 0ull;
                 if (STATS) st.bytes_scalar += 24u * (unsigned)cnt;
                 resolve_list(first, cand, o.best, o.best_t, mt, bv);
                 bb ^= 1;
@@ -2599,7 +2599,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
             const bool wants = ((wantbits >> (sh + c)) & 1ull) != 0ull;
             const int pcc = (int)(((unsigned)uniform_i32(ri[58 + (c >> 2)]) >> (8 * (c & 3))) & 0xffu);
             const int pbc = uniform_i32(ri[80 + c]);
-            unsigned cand = wants ? list_bits(lstage + (unsigned)c * 384u, pcc) : 0u;
+            unsigned long long cand = wants ? list_bits(lstage + (unsigned)c * 384u, pcc) : 0ull;
             int lb = -1;
             double lt = 0.0;
             unsigned mt = 0u, bv = 0u;
