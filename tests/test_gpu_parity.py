@@ -292,6 +292,31 @@ def _render_both(m, o, cam, W, H, lights):
     return g
 
 
+def test_deep_octree_uses_the_ordered_descent():
+    """A tight cluster of small triangles in a big room makes the octree 14+ levels
+    deep: deeper than the hit-set walk's per-lane child masks hold (kHsMaxDepth =
+    9 levels), so every ray takes the ordered descent with its per-lane stack.
+    Same pixels, hit points and (mode 7) counters as the oracle."""
+    rnd = scenegen.SplitMix64(77)
+    m, o = _both()
+    tris = [[[0, 0, 0], [64, 0, 0], [0, 0, 64]], [[64, 0, 64], [0, 0, 64], [64, 0, 0]]]  # a floor
+    for k in range(120):
+        c = [20.0 + rnd.rng(0, 0.01), 3.0 + rnd.rng(0, 0.01), 30.0 + rnd.rng(0, 0.01)]
+        tris.append([[c[a] + rnd.rng(-0.002, 0.002) for a in range(3)] for _ in range(3)])
+    for k in range(200):
+        c = [rnd.rng(4, 60), rnd.rng(0.5, 6), rnd.rng(4, 60)]
+        tris.append([[c[a] + rnd.rng(-1.5, 1.5) for a in range(3)] for _ in range(3)])
+    for s in (m, o):
+        s.add_material("a", (.2, .2, .2), (.7, .6, .5), (.3, .3, .3), ns=6, refl=0.2)
+        for k, v in enumerate(tris):
+            s.add_triangle(v, None, mtl=0, line_no=k)
+    assert o.tree()["depth"] > 9
+    lights = [(30, 40, 20, .2, .2, .2, .8, .8, .8, .4, .4, .4)]
+    _render_both(m, o, (19.0, 8.0, 12.0, 15.0, 0.0, 0.0, 70.0), 96, 64, lights)
+    g = _render_both(m, o, (20.005, 3.005, 29.9, 0.0, 0.0, 0.0, 8.0), 64, 64, lights)  # straight at the cluster
+    assert ((g["line"] >= 2) & (g["line"] < 122)).mean() > 0.3
+
+
 def test_reference_octtree_test_scenario():
     """VerStarting/octtree_test.cc:14-73 (with the CacheAABB call it forgot):
     front ray -> tr0, back ray -> tr1, far-away ray -> nothing."""
