@@ -2069,7 +2069,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     MT_LDS double *const h_win_t = h_own_t + L * 64;                       // [L][64] best child candidate so far
     MT_LDS int *const h_own_p = (MT_LDS int *)(h_win_t + L * 64);          // [L][64] own best triangle, -1 none
     MT_LDS int *const h_win_p = h_own_p + L * 64;                          // [L][64] candidate triangle | child slot << 28, -1 none
-    MT_LDS int *const h_node = h_win_p + L * 64;                           // [L][2] wave-uniform: node, its first child
+    MT_LDS int *const h_node = h_win_p + L * 64;                           // [L][2] (layout only; the values live in lane_node / lane_fc)
+    // wave-uniform per level: the frame's node and its first child, level l in LANE l of a register pair
+    // (v_readlane / v_writelane with the level as lane select: no LDS round trip in the walk's bookkeeping)
+    int lane_node = 0, lane_fc = 0;
     const unsigned stage = ((unsigned)(uintptr_t)(h_node + L * 2) + 15u) & ~15u;  // two staged HsRec
     MT_LDS double *const h_planes = (MT_LDS double *)(uintptr_t)(stage + 2u * (unsigned)sizeof(HsRec));  // [L][10] wave-uniform
     const unsigned tstage = frames_end;                                    // 32 staged fp32 triangle boxes (768 B)
@@ -2119,7 +2122,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     auto next_after = [&](int l, unsigned long long pd) -> int {
       for (; l >= 0; l--) {
         const unsigned td = (unsigned)(pd >> (8 * l)) & 0xffu;
-        if (td != 0u) return uniform_i32(h_node[l * 2 + 1]) + pick(td);
+        if (td != 0u) return __builtin_amdgcn_readlane(lane_fc, l) + pick(td);
       }
       return -1;
     };
@@ -2569,7 +2572,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (any == 0u) {  // a leaf, or nothing to look at below: the node's result is its own list's
           ret_p = best;
           ret_t = best_t;
-          slot = lev >= 0 ? node - uniform_i32(h_node[lev * 2 + 1]) : 0;
+          slot = lev >= 0 ? node - __builtin_amdgcn_readlane(lane_fc, lev) : 0;
           continue;
         }
         // open a frame (for ALL lanes: the ones outside m hold "nothing" in it)
@@ -2581,8 +2584,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         h_own_t[lev * 64 + lane] = best_t;
         h_own_p[lev * 64 + lane] = best;
         h_win_p[lev * 64 + lane] = -1;
-        h_node[lev * 2] = node;
-        h_node[lev * 2 + 1] = fc;
+        lane_node = lane == lev ? node : lane_node;
+        lane_fc = lane == lev ? fc : lane_fc;
         if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + 240u))[lane];
         const int sh = 8 * lev;
         wantbits = (wantbits & ~(0xffull << sh)) | ((unsigned long long)bits << sh);
@@ -2639,16 +2642,16 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
             ret_p = h_own_p[lev * 64 + lane];
             ret_t = h_own_t[lev * 64 + lane];
           }
-          const int closed = uniform_i32(h_node[lev * 2]);
+          const int closed = __builtin_amdgcn_readlane(lane_node, lev);
           lev--;
-          slot = lev >= 0 ? closed - uniform_i32(h_node[lev * 2 + 1]) : 0;
+          slot = lev >= 0 ? closed - __builtin_amdgcn_readlane(lane_fc, lev) : 0;
           continue;
         }
         MT_TL(9);  // offer done, next child picked
         const int c = pick(todo);
         pend &= ~(1ull << (sh + c));
         m = __ballot(((wantbits >> (sh + c)) & 1ull) != 0ull);
-        node = uniform_i32(h_node[lev * 2 + 1]) + c;
+        node = __builtin_amdgcn_readlane(lane_fc, lev) + c;
         entering = true;
       }
       }
