@@ -2346,7 +2346,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (STATS) {
           st.wave_node_steps++;
           st.wave_tri_steps += (unsigned)pc;
-          st.bytes_scalar += 256u;
+          st.bytes_scalar += (unsigned)sizeof(HsRec);  // the staged record, once for the wave
           if (in) {
             MT_CNT_ADD(1, 1u);
             MT_CNT_ADD(2, (unsigned)pc);
