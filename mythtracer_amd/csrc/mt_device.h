@@ -202,16 +202,17 @@ struct RenderParams {
 // (hit-set traversal, mt_trace.h) trees of up to kHsMaxDepth levels use 24-byte
 // frames for the levels that can hold a node with children, plus two
 // wave-uniform words per level; the old frames share the same bytes.
-constexpr int kHsMaxDepth = 9;
+constexpr int kHsMaxDepth = 12;    // levels of an octree the hit-set walk takes (LDS: 24-byte frames for all but the leaf level)
+constexpr int kHsLeafLevels = 8;  // ... and up to this many frame levels the short leaf children are staged as well
 __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
   size_t n = (size_t)depth * 64 * (packed ? 16 : 20);
 #ifdef MT_HS
   if (depth <= kHsMaxDepth && depth > 1) {
-    // frames, (node, first child) per level, two staged records (16-byte aligned)
-    // ... per level the nine planes of the frame's node (80 bytes), and the staged lists of up to eight
-    // short leaf children (384 bytes each)
-    const size_t hs = (((size_t)(depth - 1) * (64 * 24 + 8) + 15) & ~(size_t)15) + 2 * sizeof(HsRec) + (size_t)(depth - 1) * 80 +
-                      8 * 384 + 2 * 384;  // ... and two staged blocks of a long list
+    // frames, (node, first child) per level, two staged records (16-byte aligned), per level the nine planes of
+    // the frame's node (80 bytes); trees of up to kHsLeafLevels frame levels also stage the lists of up to eight
+    // short leaf children (384 bytes each) and, with -DMT_HS_LDS_LONG, two blocks of a long list
+    size_t hs = (((size_t)(depth - 1) * (64 * 24 + 8) + 15) & ~(size_t)15) + 2 * sizeof(HsRec) + (size_t)(depth - 1) * 80;
+    if (depth - 1 <= kHsLeafLevels) hs += 8 * 384 + 2 * 384;
     if (hs > n) n = hs;
   }
 #endif

@@ -11,7 +11,7 @@
 // in any order; the reference's choice among the children that hold a hit is
 // reproduced by its own rule, "the entered, acceptable child with the smallest
 // (entry distance, index)" -- see the comment there and DESIGN.md section 3.1).
-// Irregular rays, the diagnostic modes and trees deeper than kHsMaxDepth take
+// Irregular rays, the diagnostic modes and trees deeper than kHsMaxDepth (12 levels) take
 // the ORDERED DESCENT:
 //   * every lane keeps its own recursion state (the reference's call stack of
 //     PrimitiveIntersectRay) in an LDS-resident per-lane stack;
@@ -2088,8 +2088,19 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     MT_TL(1);  // walk begins
 #endif
     int lev = -1;                        // frame on top of the stack, -1 none
-    unsigned long long pend = 0ull;      // wave-uniform; byte l: children of frame l still to look at
-    unsigned long long wantbits = 0ull;  // per lane; byte l: children of frame l this lane's filter lets through
+    // wave-uniform; byte l of the pair: children of frame l still to look at
+    unsigned long long pendA = 0ull, pendB = 0ull;
+    // per lane; byte l of the pair: children of frame l this lane's filter lets through
+    unsigned long long wantA = 0ull, wantB = 0ull;
+    auto get8 = [&](unsigned long long a, unsigned long long b, int l) -> unsigned {
+      return (unsigned)((l < 8 ? a : b) >> (8 * (l & 7))) & 0xffu;
+    };
+    auto set8 = [&](unsigned long long &a, unsigned long long &b, int l, unsigned v) {
+      const int sh_ = 8 * (l & 7);
+      if (l < 8) a = (a & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
+      else b = (b & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
+    };
+    const bool leaves_inline = L <= kHsLeafLevels;  // (deeper trees: no LDS left for the short leaf children's lists)
     int node = 0;
     unsigned long long m = __ballot(cur == 0);
     int ret_p = -1;
@@ -2119,9 +2130,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       return (int)((unsigned)__builtin_ctz(t) ^ flip);
     };
     // the node the wave enters after the current one if nothing below it is entered
-    auto next_after = [&](int l, unsigned long long pd) -> int {
+    auto next_after = [&](int l) -> int {
       for (; l >= 0; l--) {
-        const unsigned td = (unsigned)(pd >> (8 * l)) & 0xffu;
+        const unsigned td = get8(pendA, pendB, l);
         if (td != 0u) return __builtin_amdgcn_readlane(lane_fc, l) + pick(td);
       }
       return -1;
@@ -2265,14 +2276,13 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       // Lanes that hold a candidate drop the children that sort behind it: the reference's
       // loop would have stopped before them (they could only be looked at, never taken).
       {
-        const int sh0 = 8 * lev;
-        unsigned rest = (unsigned)(pend >> sh0) & 0xffu;
+        unsigned rest = get8(pendA, pendB, lev);
         if (rest != 0u) {
           const int wp = h_win_p[lev * 64 + lane];
           const int kw = (int)((unsigned)wp >> 28) & 7;
           const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
           const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
-          unsigned my = (unsigned)(wantbits >> sh0) & 0xffu;
+          unsigned my = get8(wantA, wantB, lev);
           unsigned still = 0u;
           while (rest != 0u) {
             const int c2 = __builtin_ctz(rest);
@@ -2283,8 +2293,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
             if (behind) my &= ~(1u << c2);
             if (__ballot(((my >> c2) & 1u) != 0u) != 0ull) still |= 1u << c2;
           }
-          wantbits = (wantbits & ~(0xffull << sh0)) | ((unsigned long long)my << sh0);
-          pend = (pend & ~(0xffull << sh0)) | ((unsigned long long)still << sh0);
+          set8(wantA, wantB, lev, my);
+          set8(pendA, pendB, lev, still);
         }
       }
     };
@@ -2304,7 +2314,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       staged0 = uniform_i32(staged0);
       staged1 = uniform_i32(staged1);
       entering = uniform_i32(entering ? 1 : 0) != 0;
-      pend = ((unsigned long long)(unsigned)uniform_i32((int)(pend >> 32)) << 32) | (unsigned)uniform_i32((int)pend);
+      pendA = uniform_u64(pendA);
+      pendB = uniform_u64(pendB);
       m = ((unsigned long long)(unsigned)uniform_i32((int)(m >> 32)) << 32) | (unsigned)uniform_i32((int)m);
       if (entering) {
         MT_TL(2);  // ENTER
@@ -2392,7 +2403,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         // (all of them at once, while the own list is scanned) and their lists are scanned from this step.
         unsigned inl = 0u;
         int n_leaf_dma = 0;
-        if (any != 0u) {
+        if (any != 0u && leaves_inline) {
           inl = any & ((unsigned)uniform_i32(ri[78]) & 0xffu);
           for (unsigned w = inl; w != 0u; w &= w - 1u) {
             const int c = __builtin_ctz(w);
@@ -2413,7 +2424,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         bool fetched_next = false;
         {
           const unsigned step_kids = any & ~inl;
-          const int nxt = step_kids != 0u ? fc + pick(step_kids) : next_after(lev, pend);
+          const int nxt = step_kids != 0u ? fc + pick(step_kids) : next_after(lev);
           if (nxt >= 0 && MT_KNOCK != 3) {
             hs_fetch(nxt, buf ^ 1);
             fetched_next = true;
@@ -2587,9 +2598,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         lane_node = lane == lev ? node : lane_node;
         lane_fc = lane == lev ? fc : lane_fc;
         if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + 240u))[lane];
-        const int sh = 8 * lev;
-        wantbits = (wantbits & ~(0xffull << sh)) | ((unsigned long long)bits << sh);
-        pend = (pend & ~(0xffull << sh)) | ((unsigned long long)(any & ~inl) << sh);
+        set8(wantA, wantB, lev, bits);
+        set8(pendA, pendB, lev, any & ~inl);
         ret_p = -1;  // nothing comes back yet
         if (inl != 0u) {
           // the short leaf children, near to far: their lists are in LDS by now (only the next node's
@@ -2599,7 +2609,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           while (w != 0u) {
             const int c = pick(w);
             w &= ~(1u << c);
-            const bool wants = ((wantbits >> (sh + c)) & 1ull) != 0ull;
+            const bool wants = ((get8(wantA, wantB, lev) >> c) & 1u) != 0u;
             const int pcc = (int)(((unsigned)uniform_i32(ri[58 + (c >> 2)]) >> (8 * (c & 3))) & 0xffu);
             const int pbc = uniform_i32(ri[80 + c]);
             unsigned long long cand = wants ? list_bits(lstage + (unsigned)c * 384u, pcc) : 0ull;
@@ -2630,8 +2640,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           MT_PROF_COUNT(PROF_HS_N_RETHIT, 1);
           offer(slot, ret_p, ret_t);
         }
-        const int sh = 8 * lev;
-        const unsigned todo = (unsigned)(pend >> sh) & 0xffu;
+        const unsigned todo = get8(pendA, pendB, lev);
         MT_PROF_END(PROF_HS_RET_T, prof_t1);
         if (todo == 0u) {  // close the frame: octtree.cc:248-256
           const int wp = h_win_p[lev * 64 + lane];
@@ -2649,8 +2658,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         }
         MT_TL(9);  // offer done, next child picked
         const int c = pick(todo);
-        pend &= ~(1ull << (sh + c));
-        m = __ballot(((wantbits >> (sh + c)) & 1ull) != 0ull);
+        set8(pendA, pendB, lev, todo & ~(1u << c));
+        m = __ballot(((get8(wantA, wantB, lev) >> c) & 1u) != 0u);
         node = __builtin_amdgcn_readlane(lane_fc, lev) + c;
         entering = true;
       }
