@@ -79,6 +79,7 @@ struct mt_scene {
   size_t rgb_bytes = 0;
   mt_debug_px *d_debug = nullptr;
   size_t debug_bytes = 0;
+  int forecasts_in_a_row = 0;  // launches with this geometry and camera whose work order came from a forecast
   int waves_per_block = 4;
   size_t lds_bytes = 0;
   int grid_blocks = 0;
@@ -301,11 +302,19 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   // Has the camera moved since the costs were measured?  Then forecast_kernel
   // re-projects them (radius 1 block; 2 when the origin moved too: parallax).
   int reproject = 0, radius = 0;
+  float blend = 0.0f;  // see forecast_kernel
   if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {
     reproject = 1;
     radius = memcmp(s->cost_sensor.origin, sensor->origin, sizeof sensor->origin) != 0 ? 2 : 1;
     if (const char *e = getenv("MT_DEBUG_FORECAST_RADIUS")) radius = atoi(e);
   }
+  if (history && !reproject && s->forecasts_in_a_row > 0) {
+    // swept (scripts/blend_sweep.py, state machine, 64 frames): 0 -> every other frame 6 % slower (mean 7.09 ms), 0.5 -> one
+    // in three (7.03), 0.9 -> one in eight (7.01); a frozen forecast (1.0) repeats its frame time to 0.2 % (scripts/alternation.py)
+    blend = 0.9f;
+    if (const char *e = getenv("MT_DEBUG_BLEND")) blend = (float)atof(e);
+  }
+  s->forecasts_in_a_row = (history && !reproject) ? s->forecasts_in_a_row + 1 : 0;
   if (pool_engine) {
     if (!history) {
       hipLaunchKernelGGL(probe_kernel, dim3((4 * P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream,
@@ -321,7 +330,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (const char *e = getenv("MT_DEBUG_CELL_FACTOR")) sp.cell_factor = (float)atof(e);
     hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
                        reproject, radius, (history && s->last_engine == 1) ? 0 : 1,
-                       (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u);
+                       (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u, blend);
     hipLaunchKernelGGL(pool_schedule_kernel, dim3(1), dim3(kPoolSchedThreads), 0, stream, P,
                        s->grid_blocks * s->waves_per_block, sp);
     HIP_TRY(hipGetLastError());
@@ -341,7 +350,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       float quad_work = 1.7f;   // work of a block rendered as quarters / rendered whole
       if (const char *e = getenv("MT_DEBUG_QUAD_WORK")) quad_work = (float)atof(e);
       hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
-                         reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f, 16000u);
+                         reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f, 16000u, blend);
       hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
                          s->grid_blocks * s->waves_per_block, quad_share, quad_keep);
     } else if (s->stats_enabled) {
@@ -363,6 +372,25 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   s->cost_signature = sig;  // the costs now in d_item_cost belong to this geometry and engine
   s->last_engine = engine;
   s->cost_sensor = *sensor;
+  if (const char *e = getenv("MT_DEBUG_PRINT_UNITS")) {  // debug: how many work units did the order have?
+    if (atoi(e) == 2) {  // without synchronising: kept in a ring, printed every 16th launch
+      static unsigned *ring = nullptr;
+      static unsigned long long n = 0;
+      if (!ring) HIP_TRY(hipMalloc((void **)&ring, 16 * sizeof(unsigned)));
+      HIP_TRY(hipMemcpyAsync(ring + (n % 16), s->d_work + 7, sizeof(unsigned), hipMemcpyDeviceToDevice, stream));
+      if (++n % 16 == 0) {
+        unsigned host[16];
+        HIP_TRY(hipMemcpy(host, ring, sizeof host, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[mt units]");
+        for (int i = 0; i < 16; i++) fprintf(stderr, " %u", host[i]);
+        fprintf(stderr, "\n");
+      }
+    } else {  // (synchronises!)
+      unsigned nw = 0;
+      HIP_TRY(hipMemcpy(&nw, s->d_work + 7, sizeof nw, hipMemcpyDeviceToHost));
+      fprintf(stderr, "[mt units] %u units for %u blocks\n", nw, P.n_items);
+    }
+  }
   if (d_item) {  // debug: dump per-item durations (synchronises!)
     std::vector<unsigned long long> host((size_t)P.n_items * 16 * 2 * 3);
     HIP_TRY(hipMemcpy(host.data(), d_item, host.size() * 8, hipMemcpyDeviceToHost));

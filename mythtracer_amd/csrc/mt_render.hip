@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScen
 // the work and picks the blocks handed out in pieces.
 // pool != 0: cost words of the latency engine (granularity in bits 30-31).
 __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, int radius, int pool, float w1,
-                                float w2, unsigned unseen) {
+                                float w2, unsigned unseen, float blend) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_items) return;
   auto cost_of = [&](unsigned word) -> unsigned {
@@ -260,7 +260,12 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
   };
   if (!reproject) {
     // (bit 31, state machine only: the block was rendered as quarters -- schedule_kernel's hysteresis)
-    P.item_forecast[i] = cost_of(P.item_cost[i]) | (pool ? 0u : (P.item_cost[i] & 0x80000000u));
+    // blend > 0 (the camera stands still and the previous launch made a forecast too): the new forecast is a mix
+    // of the old one and the measurement -- a block near a cutting threshold is otherwise measured whole in one
+    // frame and in pieces in the next, and the schedule alternates between two states
+    unsigned f = cost_of(P.item_cost[i]);
+    if (blend > 0.0f) f = (unsigned)(blend * (float)(P.item_forecast[i] & 0x7fffffffu) + (1.0f - blend) * (float)f);
+    P.item_forecast[i] = f | (pool ? 0u : (P.item_cost[i] & 0x80000000u));
     return;
   }
   const int per_tile = P.blocks_x * P.blocks_y;
