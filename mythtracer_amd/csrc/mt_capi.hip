@@ -311,7 +311,9 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   if (history && !reproject && s->forecasts_in_a_row > 0) {
     // swept (scripts/blend_sweep.py, state machine, 64 frames): 0 -> every other frame 6 % slower (mean 7.09 ms), 0.5 -> one
     // in three (7.03), 0.9 -> one in eight (7.01); a frozen forecast (1.0) repeats its frame time to 0.2 % (scripts/alternation.py)
-    blend = 0.9f;
+    // (a running mean of the measurements first -- 1/2, 2/3, ... -- so that the first frames' costs, measured under a
+    // guessed order, do not linger)
+    blend = std::min(0.9f, (float)s->forecasts_in_a_row / (float)(s->forecasts_in_a_row + 1));
     if (const char *e = getenv("MT_DEBUG_BLEND")) blend = (float)atof(e);
   }
   s->forecasts_in_a_row = (history && !reproject) ? s->forecasts_in_a_row + 1 : 0;
