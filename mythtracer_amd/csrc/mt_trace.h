@@ -52,8 +52,8 @@ namespace mt {
 #define MT_CONST __attribute__((address_space(4)))
 #ifndef MT_KNOCK
 // timing experiments of the hit-set walk (scripts/ab_lib.py): 1 = no long-list scans, 7 = no list scans at all (wrong
-// images both), 2 = short lists through the call path, 3 = no record prefetch, 4 / 5 / 6 = child tests / short-list fp32
-// tests / short-list candidates executed twice
+// images both), 2 = short lists through the call path, 4 / 5 / 6 = child tests / short-list fp32
+// tests / short-list candidates executed twice, 8 = no cache-warming loads for the candidates
 #define MT_KNOCK 0
 #endif
 #ifndef MT_DUP
@@ -2130,7 +2130,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       return (int)((unsigned)__builtin_ctz(t) ^ flip);
     };
     // the node the wave enters after the current one if nothing below it is entered
-    auto next_after = [&](int l) -> int {
+    [[maybe_unused]] auto next_after = [&](int l) -> int {
       for (; l >= 0; l--) {
         const unsigned td = get8(pendA, pendB, l);
         if (td != 0u) return __builtin_amdgcn_readlane(lane_fc, l) + pick(td);
@@ -2189,7 +2189,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       unsigned warm = 0u;
       {
         unsigned long long w = cand;
-        for (int guard = 0; guard < 4 && w != 0ull; guard++) {
+        for (int guard = 0; guard < (MT_KNOCK == 8 ? 0 : 4) && w != 0ull; guard++) {
           const int k = __builtin_ctzll(w);
           w &= w - 1ull;
           const char *ep = (const char *)(S.tri_aabb + (size_t)(pb_ + k) * 6);
@@ -2420,17 +2420,21 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           in_list = in && subtree_may_hit(ob, f32, sxl != 0, syl != 0, szl != 0);
         }
         const unsigned long long lm = __ballot(in_list);
-        // stage the record of the node that comes next while this one's list is scanned
+        // -DMT_HS_PREFETCH: stage the record of the node that comes next while this one's list is scanned.
+        // Off by default: measured 2 % SLOWER than fetching a record when its node is entered (the other wave of
+        // the SIMD covers that latency; finding the next node and the second copy in flight are not free).
         bool fetched_next = false;
+#ifdef MT_HS_PREFETCH
         {
           const unsigned step_kids = any & ~inl;
           const int nxt = step_kids != 0u ? fc + pick(step_kids) : next_after(lev);
-          if (nxt >= 0 && MT_KNOCK != 3) {
+          if (nxt >= 0) {
             hs_fetch(nxt, buf ^ 1);
             fetched_next = true;
           }
           buf ^= 1;
         }
+#endif
 #ifdef MT_PROF
         asm volatile("" :: "v"(bits), "s"(any), "s"(lm));
         MT_PROF_END(PROF_HS_KIDS_T, prof_t1);
@@ -2476,7 +2480,14 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           const int n_in = __builtin_popcountll(lm);
           const bool blocks_ok = pc > kHsShortList;
           const int nblk = (pb + pc - 1) / kGroupTris - pb / kGroupTris + 1;
+          // (the triangle-parallel scan of the ordered descent for a handful of lanes: 1.3 % slower here, -DMT_HS_TRANSPOSED)
+#ifdef MT_HS_TRANSPOSED
           const bool transposed = blocks_ok && (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk);
+#else
+          const bool transposed = false;
+          (void)n_in;
+          (void)nblk;
+#endif
           ScanOut o{-1, 0.0, 0u};
           if (transposed) {
             o = scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in_list, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
