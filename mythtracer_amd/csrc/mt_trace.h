@@ -53,7 +53,8 @@ namespace mt {
 #ifndef MT_KNOCK
 // timing experiments of the hit-set walk (scripts/ab_lib.py): 1 = no long-list scans, 7 = no list scans at all (wrong
 // images both), 2 = short lists through the call path, 4 / 5 / 6 = child tests / short-list fp32
-// tests / short-list candidates executed twice, 8 = no cache-warming loads for the candidates
+// tests / short-list candidates executed twice, 8 = no cache-warming loads for the candidates, 10 = short leaf
+// children entered like any node
 #define MT_KNOCK 0
 #endif
 #ifndef MT_DUP
@@ -2100,7 +2101,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       if (l < 8) a = (a & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
       else b = (b & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
     };
-    const bool leaves_inline = L <= kHsLeafLevels;  // (deeper trees: no LDS left for the short leaf children's lists)
+    const bool leaves_inline = MT_KNOCK != 10 && L <= kHsLeafLevels;  // (deeper trees: no LDS left for the short leaf children's lists)
     int node = 0;
     unsigned long long m = __ballot(cur == 0);
     int ret_p = -1;
