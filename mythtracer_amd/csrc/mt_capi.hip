@@ -344,7 +344,10 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     }
   } else {
     if (history) {
-      float quad_share = 0.8f;  // blocks above this share of an even split are cut into quarters
+      // blocks above this share of an even split are cut into quarters; a re-projected forecast (moving camera) is
+      // cut more eagerly -- it is a neighbourhood maximum of stale costs (swept, scripts/quad_sweep.py: repeated frame
+      // 0.6 / 0.8 / 1.0 -> 7.18 / 6.84 / 7.28 ms, moving camera 6.69 / 7.20 / 9.89)
+      float quad_share = reproject ? 0.6f : 0.8f;
       if (const char *e = getenv("MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
       float quad_keep = 1.0f;   // ... and stay so above this fraction of that threshold (1 = no hysteresis: swept, scripts/quad_sweep.py --
                                 // settings that steady the repeated frame cost the moving camera 50 %)

@@ -1,17 +1,28 @@
-"""Sweep of the state machine's cutting constants on the warm 1080p room frame (MT_DEBUG_QUAD_SHARE / _WORK)."""
-import os, sys, numpy as np
+"""Sweep of the state machine's cutting constants on the warm 1080p room frame (MT_DEBUG_QUAD_SHARE / _WORK), work
+counters off, 32 frames per setting after 8 settling frames; and the same for the moving camera (2 degrees per frame)."""
+import os, sys, ctypes, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mythtracer_amd as M
 from mythtracer_amd import scenegen as sg, binding
+torch.cuda.init(); torch.zeros(1, device="cuda")
 W, H = 1920, 1080
-sens = binding.sensor(sg.ROOM_CAMERA, W, H)
 info = sg.write_scene("room", "/tmp/mt_scenes")
 m = M.MythTracer(info["obj"]); m.set_lights(sg.ROOM_LIGHTS)
 abi = M.hip_abi(); h = m.device_scene(); abi.set_lights(h, sg.ROOM_LIGHTS)
-abi.set_engine(h, 1)
-for work, share, keep in [(w, s_, k) for w in (2.0, 2.4) for s_ in (0.9, 1.0, 1.1) for k in (0.5, 0.7, 0.85)]:
-    if True:
-        os.environ["MT_DEBUG_QUAD_SHARE"] = str(share); os.environ["MT_DEBUG_QUAD_WORK"] = str(work); os.environ["MT_DEBUG_QUAD_KEEP"] = str(keep)
-        t = [abi.render_chunk(h, sens, W, H)["stats"]["kernel_ms"] for _ in range(9)]
-        print("quad_work %.1f quad_share %.2f keep %.2f: frames %s -> min %.3f median %.3f" % (work, share, keep, " ".join("%.2f" % x for x in t[1:]), min(t[1:]), float(np.median(t[1:]))), flush=True)
+buf = torch.zeros(W * H * 3, dtype=torch.uint8, device="cuda")
+def frames(cams):
+    for cam in cams:
+        abi.render_chunk_device(h, binding.sensor(cam, W, H), W, H, (0, 0, W, H), 5, ctypes.c_void_p(buf.data_ptr()))
+    torch.cuda.synchronize()
+    a, b = abi.kernel_times(h)
+    return (a + b)[-len(cams):]
+for work in (1.4, 1.7, 2.2):
+    for share in (0.6, 0.8, 1.0, 1.3):
+        os.environ["MT_DEBUG_QUAD_SHARE"] = str(share); os.environ["MT_DEBUG_QUAD_WORK"] = str(work)
+        abi.set_engine(h, 1); abi.set_stats(h, False)
+        frames([sg.ROOM_CAMERA] * 8)
+        t = frames([sg.ROOM_CAMERA] * 32)
+        mv = frames([sg.ROOM_CAMERA[:4] + (2.0 * i,) + sg.ROOM_CAMERA[5:] for i in range(1, 13)])
+        print("quad_work %.1f quad_share %.2f: repeated frame mean %.3f (min %.3f max %.3f) | moving camera mean %.3f max %.3f" % (
+            work, share, t.mean(), t.min(), t.max(), mv.mean(), mv.max()), flush=True)
