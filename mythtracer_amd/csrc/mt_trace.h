@@ -54,7 +54,8 @@ namespace mt {
 // timing experiments of the hit-set walk (scripts/ab_lib.py): 1 = no long-list scans, 7 = no list scans at all (wrong
 // images both), 2 = short lists through the call path, 4 / 5 / 6 = child tests / short-list fp32
 // tests / short-list candidates executed twice, 8 = no cache-warming loads for the candidates, 10 = short leaf
-// children entered like any node
+// children entered like any node, 11 = long lists without per-lane candidates and second-level boxes, 12 = children in index
+// order instead of near to far
 #define MT_KNOCK 0
 #endif
 #ifndef MT_DUP
@@ -2124,6 +2125,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
                         (__builtin_amdgcn_readlane(syl, fl) << 2));
     }
     auto pick = [&](unsigned td) -> int {  // td != 0: the child to look at next
+      if (MT_KNOCK == 12) return __builtin_ctz(td);
       unsigned t = td;
       if (flip & 1u) t = ((t & 0x55u) << 1) | ((t >> 1) & 0x55u);
       if (flip & 2u) t = ((t & 0x33u) << 2) | ((t >> 2) & 0x33u);
@@ -2495,7 +2497,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           }
 #ifndef MT_HS_LDS_LONG  // (default: the long lists go through the scalar-stream scans; the LDS form below is 10 % slower)
           else if (in_list) {
-            o = scan_filtered_dispatch<STATS, true>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
+            o = scan_filtered_dispatch<STATS, (MT_KNOCK != 11)>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
             if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
           }
 #else
