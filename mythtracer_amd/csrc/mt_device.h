@@ -52,7 +52,10 @@ static_assert(sizeof(NodeRec) == 96, "NodeRec must be 96 bytes");
 // (primitive_triangle.cc:73-76) for every member, so the block is skipped.
 constexpr int kBigNode = 32;
 constexpr int kGroupTris = 16;
-constexpr int kSuperBlocks = 8;   // blocks per second-level box
+#ifndef MT_SUPER_BLOCKS
+#define MT_SUPER_BLOCKS 8
+#endif
+constexpr int kSuperBlocks = MT_SUPER_BLOCKS;   // blocks per second-level box
 #ifndef MT_SUPER_MIN
 #define MT_SUPER_MIN 24
 #endif
