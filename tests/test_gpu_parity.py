@@ -362,7 +362,7 @@ def test_ties_degenerates_and_missing_normals():
     assert (g["line"] >= 100).any()  # twins are visible: the later coincident triangle won
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3] + list(range(50, 50 + int(os.environ.get("MT_FUZZ_SEEDS", "0")))))
 def test_random_triangle_soups_all_modes(seed):
     """Random clustered triangle soups (big straddlers + many small triangles, on
     an integer lattice so that coincident planes, shared edges and exact ties are
