@@ -3,6 +3,9 @@
 // can index it without bounds checks), keeps it resident in HBM and launches
 // the kernels of mt_render.hip.
 #include <hip/hip_runtime.h>
+#include <algorithm>
+#include <limits>
+#include <utility>
 
 #include <chrono>
 #include <cmath>
@@ -79,6 +82,14 @@ struct mt_scene {
   size_t rgb_bytes = 0;
   mt_debug_px *d_debug = nullptr;
   size_t debug_bytes = 0;
+  // rays with one zero direction component (DevScene::deg_*): per axis the box planes of all triangles, sorted,
+  // with the triangle each belongs to; the node of every triangle; the parent of every node
+  std::vector<std::pair<double, int32_t>> plane_index[3];
+  std::vector<int32_t> tri_node, node_parent;
+  uint32_t *d_deg_maps = nullptr;  // [3][block words] then [3][node words]
+  size_t deg_blk_words = 0, deg_node_words = 0;
+  double deg_origin[3] = {0, 0, 0};
+  bool deg_valid = false;
   int forecasts_in_a_row = 0;  // launches with this geometry and camera whose work order came from a forecast
   int waves_per_block = 4;
   size_t lds_bytes = 0;
@@ -114,6 +125,38 @@ bool finite3(const double *p, size_t n) {
     if (!std::isfinite(p[i])) return false;
   }
   return true;
+}
+
+// Rays with ONE zero direction component from the camera's origin (a camera that looks along an axis): which
+// blocks / subtrees hold a triangle whose box has a plane exactly at the origin's coordinate on that axis?  Those
+// pass the reference's pre-filter through NaN whatever the other axes say (0 * inf); every other box is decided by
+// its range on that axis and by the other two axes alone, so its unions may be culled (mt_trace.h,
+// degenerate_axis).  Equality is decided on the fp64 boxes the reference caches (primitive_triangle.cc:11-25).
+// Recomputed only when the origin changes (a turning camera keeps it).
+int refresh_degenerate_maps(mt_scene *s, const mt_sensor *sensor, hipStream_t stream) {
+  if (s->deg_valid && memcmp(s->deg_origin, sensor->origin, sizeof s->deg_origin) == 0) return MT_OK;
+  std::vector<uint32_t> maps(3 * (s->deg_blk_words + s->deg_node_words), 0u);
+  for (int a = 0; a < 3; a++) {
+    const double c = sensor->origin[a];
+    uint32_t *db = maps.data() + (size_t)a * s->deg_blk_words;
+    uint32_t *dn = maps.data() + 3 * s->deg_blk_words + (size_t)a * s->deg_node_words;
+    const auto &ix = s->plane_index[a];
+    auto lo = std::lower_bound(ix.begin(), ix.end(), std::make_pair(c, (int32_t)INT32_MIN));
+    for (auto it = lo; it != ix.end() && it->first == c; ++it) {  // (-0.0 == 0.0: both are "at" the plane, as in (p - o) * inf)
+      const int32_t t = it->second;
+      db[(size_t)(t / kGroupTris) >> 5] |= 1u << ((t / kGroupTris) & 31);
+      for (int32_t n = s->tri_node[(size_t)t]; n >= 0; n = s->node_parent[(size_t)n]) {
+        if (dn[(size_t)n >> 5] & (1u << (n & 31))) break;  // the ancestors are marked already
+        dn[(size_t)n >> 5] |= 1u << (n & 31);
+      }
+    }
+    s->dev.deg_c[a] = c;
+  }
+  HIP_TRY(hipMemcpyAsync(s->d_deg_maps, maps.data(), maps.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipStreamSynchronize(stream));  // (maps is a local buffer)
+  memcpy(s->deg_origin, sensor->origin, sizeof s->deg_origin);
+  s->deg_valid = true;
+  return MT_OK;
 }
 
 // Launch geometry: as many 4-wave blocks as the CU's LDS/VGPR budget admits.
@@ -292,6 +335,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   HIP_TRY(hipMemsetAsync(s->d_work, 0, 8 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
+  if (int rc_deg = refresh_degenerate_maps(s, sensor, stream)) return rc_deg;
   HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
   // events: [0] -> [1] forecast / classification + work order; [1] -> [2] the frame kernel
   hipEvent_t *ek = s->ev_k[s->launches_timed % mt_scene::kTimedLaunches];
@@ -770,6 +814,38 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   s->dev.tree_depth = max_depth;
   s->dev.force_mode = 0;
   s->dev.scene_regular = regular ? 1 : 0;
+  // Index for rays with one zero direction component (DevScene::deg_*, refresh_degenerate_maps below).
+  {
+    s->node_parent.assign((size_t)nn, -1);
+    s->tri_node.assign(nt, 0);
+    for (int i = 0; i < nn; i++) {
+      const NodeRec &r = recs[i];
+      if (r.first_child != 0) {
+        for (int c = 0; c < 8; c++) s->node_parent[(size_t)r.first_child + c] = i;
+      }
+      for (int t = r.prim_begin; t < r.prim_begin + r.prim_count; t++) s->tri_node[(size_t)t] = i;
+    }
+    for (int a = 0; a < 3; a++) {
+      auto &ix = s->plane_index[a];
+      ix.clear();
+      ix.reserve(nt * 2);
+      for (size_t t = 0; t < nt; t++) {
+        ix.emplace_back(d->tri_aabb[t * 6 + a], (int32_t)t);
+        ix.emplace_back(d->tri_aabb[t * 6 + 3 + a], (int32_t)t);
+      }
+      std::sort(ix.begin(), ix.end());
+    }
+    s->deg_blk_words = (nt / kGroupTris + 1 + 31) / 32;
+    s->deg_node_words = ((size_t)nn + 31) / 32;
+    HIP_TRY(hipMalloc((void **)&s->d_deg_maps, 3 * (s->deg_blk_words + s->deg_node_words) * sizeof(uint32_t)));
+    s->allocs.push_back(s->d_deg_maps);
+    for (int a = 0; a < 3; a++) {
+      s->dev.deg_dirty_blocks[a] = s->d_deg_maps + (size_t)a * s->deg_blk_words;
+      s->dev.deg_dirty_nodes[a] = s->d_deg_maps + 3 * s->deg_blk_words + (size_t)a * s->deg_node_words;
+      s->dev.deg_c[a] = std::numeric_limits<double>::quiet_NaN();
+    }
+    s->deg_valid = false;
+  }
   {
     // 16-byte traversal stack frames when "first child" and "best triangle + 1"
     // share one word: a quarter less LDS per wave

@@ -98,6 +98,14 @@ struct DevScene {
   const float *sup_aabb32;   // fp32 union box of each run of kSuperBlocks consecutive blocks (long lists)
   const float *sub_aabb32;   // per node: fp32 union box of all triangles in its subtree
   const HsRec *hs_rec;       // per node (hit-set traversal)
+  // Rays with ONE zero direction component whose origin coordinate on that axis is deg_c[axis] (the
+  // camera's origin: a camera that looks along an axis shoots a whole pixel column or row of them): bit b of
+  // deg_dirty_blocks[axis] = block b holds a triangle whose box has a plane EXACTLY at that coordinate, bit n of
+  // deg_dirty_nodes[axis] = node n or a node below it holds one.  Everything else may be culled by the other two
+  // axes for such a ray (mt_trace.h, degenerate_axis).  Refreshed per launch; NaN in deg_c = no maps.
+  const uint32_t *deg_dirty_blocks[3];
+  const uint32_t *deg_dirty_nodes[3];
+  double deg_c[3];
   double bmax[3];            // max |coordinate| of any triangle box, per axis
   const double *tri_vertex;  // 9 per triangle
   const double *tri_normal;  // 9 per triangle

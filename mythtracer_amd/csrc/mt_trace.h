@@ -542,6 +542,19 @@ __device__ __forceinline__ unsigned degenerate_keep_mask(const float *sub, int a
   return keep;
 }
 
+// ... and when o[a] lies INSIDE a box's range: (lo - o) * inf and (hi - o) * inf are -inf and +inf (in one order or
+// the other), the axis constrains nothing and the other two axes decide -- UNLESS a plane of the box equals o[a]
+// exactly (0 * inf = NaN).  A union box (block, subtree) may therefore be culled by the other two axes when none of
+// its members has a plane at o[a]; the host marks the blocks and subtrees that do, for the camera's origin
+// (DevScene::deg_dirty_*, mt_capi.hip refresh_degenerate_maps), and a ray whose coordinate is not the one the maps
+// were made for keeps the range rule only.
+__device__ __forceinline__ bool degenerate_known(const MT_CONST DevScene *G, int axis, double o) {
+  return axis >= 0 && o == G->deg_c[axis];  // (NaN = no maps; -0.0 == 0.0, as the host's comparison)
+}
+__device__ __forceinline__ bool degenerate_dirty(const uint32_t *map, int index) {
+  return ((map[index >> 5] >> (index & 31)) & 1u) != 0u;
+}
+
 // Returns false when the filter must not be used for this ray.
 __device__ __forceinline__ bool make_filter32(const DevScene &S, const RayRegs &r, Filter32 &f) {
   const double o[3] = {r.ox, r.oy, r.oz}, iv[3] = {r.ix, r.iy, r.iz};
@@ -549,6 +562,14 @@ __device__ __forceinline__ bool make_filter32(const DevScene &S, const RayRegs &
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
+    if (__builtin_isinf(iv[k]) && __builtin_fabs(o[k]) <= 0x1p120) {
+      // a zero direction component: this axis never constrains the fp32 interval (the caller applies the
+      // filter to such a ray only where the axis provably does not decide: degenerate_axis below)
+      I[k] = 0.0f;
+      Cn[k] = -3.0e38f;
+      Cf[k] = 3.0e38f;
+      continue;
+    }
     const double M = (S.bmax[k] + __builtin_fabs(o[k])) * __builtin_fabs(iv[k]);
     ok = ok && (M <= 0x1p120);  // false for NaN/inf as well
     const double E = M * 0x1p-21 + 0x1p-100;
@@ -601,6 +622,37 @@ __device__ __forceinline__ bool subtree_may_hit(const float *b, const Filter32 &
   const float lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
   const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
   return !(hi < 0.0f) && !(lo > hi);  // NaN: keep
+}
+
+// keep mask of the eight subtree boxes `sub` (children fc .. fc + 7) for a ray with one zero direction component:
+// the range rule, and -- when the maps were made for this ray's coordinate -- the other two axes for the subtrees
+// that hold no triangle with a plane at that coordinate.
+__device__ __forceinline__ unsigned degenerate_children(const DevScene *self, const float *sub, int fc, double ox,
+                                                        double oy, double oz, double ix, double iy, double iz) {
+  const int axis = degenerate_axis(ox, oy, oz, ix, iy, iz);
+  if (axis < 0) return 0xffu;
+  const double o = axis == 0 ? ox : (axis == 1 ? oy : oz);
+  unsigned keep = degenerate_keep_mask(sub, axis, o);
+  const MT_CONST DevScene *G = as_const(self);
+  if (keep != 0u && degenerate_known(G, axis, o)) {
+    DevScene B;
+    B.bmax[0] = G->bmax[0]; B.bmax[1] = G->bmax[1]; B.bmax[2] = G->bmax[2];
+    RayRegs r;
+    r.ox = ox; r.oy = oy; r.oz = oz;
+    r.dx = 0.0; r.dy = 0.0; r.dz = 0.0;
+    r.ix = ix; r.iy = iy; r.iz = iz;
+    Filter32 f;
+    if (make_filter32(B, r, f)) {
+      const uint32_t *dn = G->deg_dirty_nodes[axis];
+      const bool sx = __builtin_signbit(ix), sy = __builtin_signbit(iy), sz = __builtin_signbit(iz);
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        if (((keep >> c) & 1u) == 0u) continue;
+        if (!degenerate_dirty(dn, fc + c) && !subtree_may_hit(sub + c * 6, f, sx, sy, sz)) keep &= ~(1u << c);
+      }
+    }
+  }
+  return keep;
 }
 
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -916,6 +968,9 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
     const int fx = 3 - nx, fy = 5 - ny, fz = 7 - nz;
     const int deg_axis = EX ? degenerate_axis(u.ox, u.oy, u.oz, u.ix, u.iy, u.iz) : -1;
     const double deg_o = deg_axis == 0 ? u.ox : (deg_axis == 1 ? u.oy : u.oz);
+    const bool deg_known = EX && S.self != nullptr && degenerate_known(as_const(S.self), deg_axis, deg_o) &&
+                           readlane_f32(f.cnx, L) == readlane_f32(f.cnx, L);  // (a usable filter: no NaN constants)
+    const uint32_t *deg_db = deg_known ? as_const(S.self)->deg_dirty_blocks[deg_axis] : nullptr;
     int ubest = -1;
     double ubest_t = 0.0;
     unsigned mt_count = 0;
@@ -934,7 +989,12 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
       // "may pass" unless provably not (NaN compares as may pass, like filter32_pass);
       // EX: an irregular ray -- only the one-zero-component test above applies
       bool may = !(hi < 0.0f) && !(lo > hi);
-      if (EX) may = !(deg_axis >= 0 && outside_on_axis(bp, deg_axis, deg_o));
+      if (EX) {
+        // the range rule; and, where the host's maps cover this ray's coordinate, the other two axes (f's third
+        // axis is neutral, make_filter32) for the blocks that hold no triangle with a plane at it
+        const bool range_ok = !(deg_axis >= 0 && outside_on_axis(bp, deg_axis, deg_o));
+        may = range_ok && (!deg_known || may || degenerate_dirty(deg_db, b0 + (g < nb ? g : nb - 1)));
+      }
       unsigned long long live = __builtin_amdgcn_ballot_w64(may && g < nb);
 #ifdef MT_PROF
       const unsigned long long tt2 = __builtin_amdgcn_s_memtime();
@@ -1395,30 +1455,26 @@ __device__ __forceinline__ unsigned order_children_regular(const NodeRec *N, con
 __device__ __attribute__((noinline)) unsigned order_children_exact_lane_call(const NodeRec *N, double ox,
                                                                              double oy, double oz, double ix,
                                                                              double iy, double iz,
-                                                                             const float *sub) {
+                                                                             const float *sub,
+                                                                             const DevScene *self, int fc) {
   RayRegs r;
   r.ox = ox; r.oy = oy; r.oz = oz;
   r.dx = 0.0; r.dy = 0.0; r.dz = 0.0;
   r.ix = ix; r.iy = iy; r.iz = iz;
   unsigned keep = 0xffu;
-  if (sub != nullptr) {
-    const int axis = degenerate_axis(ox, oy, oz, ix, iy, iz);
-    if (axis >= 0) keep = degenerate_keep_mask(sub, axis, axis == 0 ? ox : (axis == 1 ? oy : oz));
-  }
+  if (sub != nullptr) keep = degenerate_children(self, sub, fc, ox, oy, oz, ix, iy, iz);
   return order_children<0>(as_const(N), r, keep);
 }
 __device__ __attribute__((noinline)) unsigned order_children_exact_call(const NodeRec *N, double ox, double oy,
                                                                         double oz, double ix, double iy,
-                                                                        double iz, const float *sub) {
+                                                                        double iz, const float *sub,
+                                                                        const DevScene *self, int fc) {
   RayRegs r;
   r.ox = ox; r.oy = oy; r.oz = oz;
   r.dx = 0.0; r.dy = 0.0; r.dz = 0.0;
   r.ix = ix; r.iy = iy; r.iz = iz;
   unsigned keep = 0xffu;
-  if (sub != nullptr) {
-    const int axis = degenerate_axis(ox, oy, oz, ix, iy, iz);
-    if (axis >= 0) keep = degenerate_keep_mask(uniform_ptr(sub), axis, axis == 0 ? ox : (axis == 1 ? oy : oz));
-  }
+  if (sub != nullptr) keep = degenerate_children(uniform_ptr(self), uniform_ptr(sub), uniform_i32(fc), ox, oy, oz, ix, iy, iz);
   return order_children<0>(as_const(uniform_ptr(N)), r, keep);
 }
 
@@ -1439,6 +1495,7 @@ __device__ __forceinline__ DevScene scan_ctx_self(const DevScene *self) {
   S.grp_aabb32 = G->grp_aabb32;
   S.sup_aabb32 = G->sup_aabb32;
   S.tri_vertex = G->tri_vertex;
+  S.self = uniform_ptr(self);
   return S;
 }
 
@@ -1447,6 +1504,7 @@ __device__ __forceinline__ DevScene scan_ctx(const float *b32, const double *b64
   S.tri_aabb32 = uniform_ptr(b32);
   S.tri_aabb = uniform_ptr(b64);
   S.tri_vertex = uniform_ptr(vtx);
+  S.self = nullptr;
   return S;
 }
 
@@ -2732,7 +2790,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
           ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, S.force_mode != 9)
                              : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                              irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr);
+                                                              irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr, S.self, fc);
         }
         if (STATS && fc != 0) {  // node planes + record (88 B) and the subtree boxes of the children entered
           MT_CNT_ADD(4, 88u + 24u * (((ordw >> 24) & 15u) + 1u));
@@ -2842,7 +2900,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         const float *sub = cull ? S.sub_aabb32 + (size_t)my_fc * 6 : nullptr;
         ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, S.force_mode != 9)
                            : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                            irr_boxes ? S.sub_aabb32 + (size_t)my_fc * 6 : nullptr);
+                                                            irr_boxes ? S.sub_aabb32 + (size_t)my_fc * 6 : nullptr, S.self, my_fc);
       }
       finish_node(my_fc, ordw, best, best_t);
     }
@@ -2894,7 +2952,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
 #endif
           ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, kSurvivorsFirst)
                              : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                              irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr);
+                                                              irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr, S.self, fc);
         }
         if (STATS && fc != 0) {  // node planes + record (88 B) and the subtree boxes of the children entered
           MT_CNT_ADD(4, 88u + 24u * (((ordw >> 24) & 15u) + 1u));
@@ -3080,7 +3138,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (mode != 0) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, true, kSurvivorsFirst)));
 #endif
         ordw = (mode == 0) ? order_children_exact_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                       irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr)
+                                                       irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr, S.self, fc)
                            : order_children_regular(Np, r, sub, f32, true, kSurvivorsFirst);
       }
       if (STATS && fc != 0) st.bytes_scalar += 96u + 24u * 8u;  // node record + the children's subtree boxes, once for the wave

@@ -499,6 +499,12 @@ def test_random_scenes_render_like_the_oracle(seed):
     cam = (rnd.rng(10, 38), rnd.rng(6, 30), rnd.rng(-30, -4), rnd.rng(-5, 25), rnd.rng(-25, 25), rnd.rng(-10, 10), rnd.rng(50, 100))
     g = _render_both(m, o, cam, 112, 80, lights)
     assert (g["line"] >= 0).mean() > 0.1 and g["counters"]["rays_secondary"] > 0  # (the camera saw something)
+    # Cameras that look straight along z: the centre pixel column and row shoot rays with a zero direction
+    # component.  On a lattice plane (triangle boxes and octree planes AT the origin's coordinate: NaN in the
+    # reference's slab tests) and off it (the other two axes decide: the culling of DevScene::deg_dirty_*).
+    xl = float(round(cam[0] * 2) / 2)
+    for x in (xl, xl + 0.125):
+        _render_both(m, o, (x, float(round(cam[1])), cam[2], 0.0, 0.0, 0.0, 80.0), 64, 48, lights)
 
 
 def test_materialless_occluder_is_opaque():
