@@ -88,6 +88,9 @@ struct mt_scene {
   std::vector<int32_t> tri_node, node_parent;
   uint32_t *d_deg_maps = nullptr;  // [3][block words] then [3][node words]
   size_t deg_blk_words = 0, deg_node_words = 0;
+  uint32_t *deg_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned
+  hipEvent_t deg_stage_done[4] = {};
+  unsigned long long deg_uploads = 0;
   double deg_origin[3] = {0, 0, 0};
   bool deg_valid = false;
   int forecasts_in_a_row = 0;  // launches with this geometry and camera whose work order came from a forecast
@@ -135,11 +138,22 @@ bool finite3(const double *p, size_t n) {
 // Recomputed only when the origin changes (a turning camera keeps it).
 int refresh_degenerate_maps(mt_scene *s, const mt_sensor *sensor, hipStream_t stream) {
   if (s->deg_valid && memcmp(s->deg_origin, sensor->origin, sizeof s->deg_origin) == 0) return MT_OK;
-  std::vector<uint32_t> maps(3 * (s->deg_blk_words + s->deg_node_words), 0u);
+  // staged through one of four pinned buffers, so that a camera that moves every frame does not make the host wait
+  // for the previous frame (a buffer is reused only after the copy that read it has completed)
+  const size_t n_words = 3 * (s->deg_blk_words + s->deg_node_words);
+  const int slot = (int)(s->deg_uploads++ % 4);
+  if (!s->deg_stage[slot]) {
+    HIP_TRY(hipHostMalloc((void **)&s->deg_stage[slot], n_words * sizeof(uint32_t), hipHostMallocDefault));
+    HIP_TRY(hipEventCreateWithFlags(&s->deg_stage_done[slot], hipEventDisableTiming));
+  } else {
+    HIP_TRY(hipEventSynchronize(s->deg_stage_done[slot]));
+  }
+  uint32_t *maps = s->deg_stage[slot];
+  memset(maps, 0, n_words * sizeof(uint32_t));
   for (int a = 0; a < 3; a++) {
     const double c = sensor->origin[a];
-    uint32_t *db = maps.data() + (size_t)a * s->deg_blk_words;
-    uint32_t *dn = maps.data() + 3 * s->deg_blk_words + (size_t)a * s->deg_node_words;
+    uint32_t *db = maps + (size_t)a * s->deg_blk_words;
+    uint32_t *dn = maps + 3 * s->deg_blk_words + (size_t)a * s->deg_node_words;
     const auto &ix = s->plane_index[a];
     auto lo = std::lower_bound(ix.begin(), ix.end(), std::make_pair(c, (int32_t)INT32_MIN));
     for (auto it = lo; it != ix.end() && it->first == c; ++it) {  // (-0.0 == 0.0: both are "at" the plane, as in (p - o) * inf)
@@ -152,8 +166,8 @@ int refresh_degenerate_maps(mt_scene *s, const mt_sensor *sensor, hipStream_t st
     }
     s->dev.deg_c[a] = c;
   }
-  HIP_TRY(hipMemcpyAsync(s->d_deg_maps, maps.data(), maps.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipStreamSynchronize(stream));  // (maps is a local buffer)
+  HIP_TRY(hipMemcpyAsync(s->d_deg_maps, maps, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+  HIP_TRY(hipEventRecord(s->deg_stage_done[slot], stream));
   memcpy(s->deg_origin, sensor->origin, sizeof s->deg_origin);
   s->deg_valid = true;
   return MT_OK;
@@ -335,7 +349,9 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   HIP_TRY(hipMemsetAsync(s->d_work, 0, 8 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
+#ifdef MT_DEG_MAPS
   if (int rc_deg = refresh_degenerate_maps(s, sensor, stream)) return rc_deg;
+#endif
   HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
   // events: [0] -> [1] forecast / classification + work order; [1] -> [2] the frame kernel
   hipEvent_t *ek = s->ev_k[s->launches_timed % mt_scene::kTimedLaunches];
@@ -524,6 +540,10 @@ void mt_scene_destroy(mt_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void *p : s->allocs) (void)hipFree(p);
+  for (int i = 0; i < 4; i++) {
+    if (s->deg_stage[i]) (void)hipHostFree(s->deg_stage[i]);
+    if (s->deg_stage_done[i]) (void)hipEventDestroy(s->deg_stage_done[i]);
+  }
   if (s->d_pool) (void)hipFree(s->d_pool);
   if (s->d_frames) (void)hipFree(s->d_frames);
   if (s->d_hit_prim) (void)hipFree(s->d_hit_prim);
@@ -814,7 +834,9 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   s->dev.tree_depth = max_depth;
   s->dev.force_mode = 0;
   s->dev.scene_regular = regular ? 1 : 0;
-  // Index for rays with one zero direction component (DevScene::deg_*, refresh_degenerate_maps below).
+  // Index for rays with one zero direction component (DevScene::deg_*, refresh_degenerate_maps; -DMT_DEG_MAPS).
+  for (int a = 0; a < 3; a++) s->dev.deg_c[a] = std::numeric_limits<double>::quiet_NaN();
+#ifdef MT_DEG_MAPS
   {
     s->node_parent.assign((size_t)nn, -1);
     s->tri_node.assign(nt, 0);
@@ -846,6 +868,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     }
     s->deg_valid = false;
   }
+#endif
   {
     // 16-byte traversal stack frames when "first child" and "best triangle + 1"
     // share one word: a quarter less LDS per wave

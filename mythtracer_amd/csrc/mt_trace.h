@@ -547,7 +547,9 @@ __device__ __forceinline__ unsigned degenerate_keep_mask(const float *sub, int a
 // exactly (0 * inf = NaN).  A union box (block, subtree) may therefore be culled by the other two axes when none of
 // its members has a plane at o[a]; the host marks the blocks and subtrees that do, for the camera's origin
 // (DevScene::deg_dirty_*, mt_capi.hip refresh_degenerate_maps), and a ray whose coordinate is not the one the maps
-// were made for keeps the range rule only.
+// were made for keeps the range rule only.  -DMT_DEG_MAPS (off by default: on the benchmark's camera, which stands ON a
+// plane full of box planes, everything such a ray meets is marked and the extra tests cost 1.4 % of the frame; a
+// batch of rays in a plane without box planes gains 4 %).
 __device__ __forceinline__ bool degenerate_known(const MT_CONST DevScene *G, int axis, double o) {
   return axis >= 0 && o == G->deg_c[axis];  // (NaN = no maps; -0.0 == 0.0, as the host's comparison)
 }
@@ -562,6 +564,7 @@ __device__ __forceinline__ bool make_filter32(const DevScene &S, const RayRegs &
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
+#ifdef MT_DEG_MAPS
     if (__builtin_isinf(iv[k]) && __builtin_fabs(o[k]) <= 0x1p120) {
       // a zero direction component: this axis never constrains the fp32 interval (the caller applies the
       // filter to such a ray only where the axis provably does not decide: degenerate_axis below)
@@ -570,6 +573,7 @@ __device__ __forceinline__ bool make_filter32(const DevScene &S, const RayRegs &
       Cf[k] = 3.0e38f;
       continue;
     }
+#endif
     const double M = (S.bmax[k] + __builtin_fabs(o[k])) * __builtin_fabs(iv[k]);
     ok = ok && (M <= 0x1p120);  // false for NaN/inf as well
     const double E = M * 0x1p-21 + 0x1p-100;
@@ -633,6 +637,7 @@ __device__ __forceinline__ unsigned degenerate_children(const DevScene *self, co
   if (axis < 0) return 0xffu;
   const double o = axis == 0 ? ox : (axis == 1 ? oy : oz);
   unsigned keep = degenerate_keep_mask(sub, axis, o);
+#ifdef MT_DEG_MAPS
   const MT_CONST DevScene *G = as_const(self);
   if (keep != 0u && degenerate_known(G, axis, o)) {
     DevScene B;
@@ -652,6 +657,10 @@ __device__ __forceinline__ unsigned degenerate_children(const DevScene *self, co
       }
     }
   }
+#else
+  (void)self;
+  (void)fc;
+#endif
   return keep;
 }
 
@@ -968,9 +977,14 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
     const int fx = 3 - nx, fy = 5 - ny, fz = 7 - nz;
     const int deg_axis = EX ? degenerate_axis(u.ox, u.oy, u.oz, u.ix, u.iy, u.iz) : -1;
     const double deg_o = deg_axis == 0 ? u.ox : (deg_axis == 1 ? u.oy : u.oz);
+#ifdef MT_DEG_MAPS
     const bool deg_known = EX && S.self != nullptr && degenerate_known(as_const(S.self), deg_axis, deg_o) &&
                            readlane_f32(f.cnx, L) == readlane_f32(f.cnx, L);  // (a usable filter: no NaN constants)
     const uint32_t *deg_db = deg_known ? as_const(S.self)->deg_dirty_blocks[deg_axis] : nullptr;
+#else
+    constexpr bool deg_known = false;
+    const uint32_t *deg_db = nullptr;
+#endif
     int ubest = -1;
     double ubest_t = 0.0;
     unsigned mt_count = 0;
@@ -994,6 +1008,7 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
         // axis is neutral, make_filter32) for the blocks that hold no triangle with a plane at it
         const bool range_ok = !(deg_axis >= 0 && outside_on_axis(bp, deg_axis, deg_o));
         may = range_ok && (!deg_known || may || degenerate_dirty(deg_db, b0 + (g < nb ? g : nb - 1)));
+        (void)deg_db;
       }
       unsigned long long live = __builtin_amdgcn_ballot_w64(may && g < nb);
 #ifdef MT_PROF
