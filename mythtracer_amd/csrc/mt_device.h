@@ -223,7 +223,9 @@ __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
     // the frame's node (80 bytes); trees of up to kHsLeafLevels frame levels also stage the lists of up to eight
     // short leaf children (384 bytes each) and, with -DMT_HS_LDS_LONG, two blocks of a long list
     size_t hs = (((size_t)(depth - 1) * (64 * 24 + 8) + 15) & ~(size_t)15) + 2 * sizeof(HsRec) + (size_t)(depth - 1) * 80;
+#if defined(MT_HS_INLINE_LEAVES) || defined(MT_HS_LDS_LONG)
     if (depth - 1 <= kHsLeafLevels) hs += 8 * 384 + 2 * 384;
+#endif
     if (hs > n) n = hs;
   }
 #endif

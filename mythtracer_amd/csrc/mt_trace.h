@@ -53,8 +53,7 @@ namespace mt {
 #ifndef MT_KNOCK
 // timing experiments of the hit-set walk (scripts/ab_lib.py): 1 = no long-list scans, 7 = no list scans at all (wrong
 // images both), 2 = short lists through the call path, 4 / 5 / 6 = child tests / short-list fp32
-// tests / short-list candidates executed twice, 8 = no cache-warming loads for the candidates, 10 = short leaf
-// children entered like any node, 11 = long lists without per-lane candidates and second-level boxes, 12 = children in index
+// tests / short-list candidates executed twice, 8 = no cache-warming loads for the candidates, 11 = long lists without per-lane candidates and second-level boxes, 12 = children in index
 // order instead of near to far
 #define MT_KNOCK 0
 #endif
@@ -2175,7 +2174,12 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       if (l < 8) a = (a & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
       else b = (b & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
     };
-    const bool leaves_inline = MT_KNOCK != 10 && L <= kHsLeafLevels;  // (deeper trees: no LDS left for the short leaf children's lists)
+#ifdef MT_HS_INLINE_LEAVES
+    const bool leaves_inline = L <= kHsLeafLevels;
+#else
+    // (scanning the short leaf children from the parent's step saves a seventh of the steps and is 0.5 % SLOWER)
+    const bool leaves_inline = false;
+#endif  // (deeper trees: no LDS left for the short leaf children's lists)
     int node = 0;
     unsigned long long m = __ballot(cur == 0);
     int ret_p = -1;
