@@ -406,13 +406,13 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (history) {
       // blocks above this share of an even split are cut into quarters; a re-projected forecast (moving camera) is
       // cut more eagerly -- it is a neighbourhood maximum of stale costs (swept, scripts/quad_sweep.py: repeated frame
-      // 0.6 / 0.8 / 1.0 -> 7.18 / 6.84 / 7.28 ms, moving camera 6.69 / 7.20 / 9.89)
-      float quad_share = reproject ? 0.6f : 0.8f;
+      // 0.6 / 0.8 / 1.0 -> 7.18 / 6.84 / 7.28 ms, moving camera 6.69 / 7.20 / 9.89; with work 1.5: share 0.7 -> 6.40)
+      float quad_share = reproject ? 0.7f : 0.8f;
       if (const char *e = getenv("MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
       float quad_keep = 1.0f;   // ... and stay so above this fraction of that threshold (1 = no hysteresis: swept, scripts/quad_sweep.py --
                                 // settings that steady the repeated frame cost the moving camera 50 %)
       if (const char *e = getenv("MT_DEBUG_QUAD_KEEP")) quad_keep = (float)atof(e);
-      float quad_work = 1.7f;   // work of a block rendered as quarters / rendered whole
+      float quad_work = reproject ? 1.5f : 1.7f;   // work of a block rendered as quarters / rendered whole (swept with the share)
       if (const char *e = getenv("MT_DEBUG_QUAD_WORK")) quad_work = (float)atof(e);
       hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
                          reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f, 16000u, blend);

@@ -17,8 +17,8 @@ def frames(cams):
     torch.cuda.synchronize()
     a, b = abi.kernel_times(h)
     return (a + b)[-len(cams):]
-for work in (1.4, 1.7, 2.2):
-    for share in (0.6, 0.8, 1.0, 1.3):
+for work in (1.5, 1.7, 1.9):
+    for share in (0.7, 0.8, 0.9):
         os.environ["MT_DEBUG_QUAD_SHARE"] = str(share); os.environ["MT_DEBUG_QUAD_WORK"] = str(work)
         abi.set_engine(h, 1); abi.set_stats(h, False)
         frames([sg.ROOM_CAMERA] * 8)
