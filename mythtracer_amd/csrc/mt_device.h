@@ -53,11 +53,11 @@ static_assert(sizeof(NodeRec) == 96, "NodeRec must be 96 bytes");
 constexpr int kBigNode = 32;
 constexpr int kGroupTris = 16;
 #ifndef MT_SUPER_BLOCKS
-#define MT_SUPER_BLOCKS 8
+#define MT_SUPER_BLOCKS 4
 #endif
 constexpr int kSuperBlocks = MT_SUPER_BLOCKS;   // blocks per second-level box
 #ifndef MT_SUPER_MIN
-#define MT_SUPER_MIN 24
+#define MT_SUPER_MIN 12
 #endif
 constexpr int kSuperMin = MT_SUPER_MIN;  // lists that touch at least this many blocks are scanned through the second level
 
