@@ -93,6 +93,7 @@ struct mt_scene {
   unsigned long long deg_uploads = 0;
   double deg_origin[3] = {0, 0, 0};
   bool deg_valid = false;
+  std::vector<mt_light> lights_host;  // what d_lights holds
   int forecasts_in_a_row = 0;  // launches with this geometry and camera whose work order came from a forecast
   int waves_per_block = 4;
   size_t lds_bytes = 0;
@@ -373,8 +374,9 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     // in three (7.03), 0.9 -> one in eight (7.01); a frozen forecast (1.0) repeats its frame time to 0.2 % (scripts/alternation.py)
     // (a running mean of the measurements first -- 1/2, 2/3, ... -- so that the first frames' costs, measured under a
     // guessed order, do not linger)
-    blend = std::min(0.9f, (float)s->forecasts_in_a_row / (float)(s->forecasts_in_a_row + 1));
-    if (const char *e = getenv("MT_DEBUG_BLEND")) blend = (float)atof(e);
+    float cap = 0.9f;
+    if (const char *e = getenv("MT_DEBUG_BLEND")) cap = (float)atof(e);
+    blend = std::min(cap, (float)s->forecasts_in_a_row / (float)(s->forecasts_in_a_row + 1));
   }
   s->forecasts_in_a_row = (history && !reproject) ? s->forecasts_in_a_row + 1 : 0;
   if (pool_engine) {
@@ -934,6 +936,11 @@ int mt_scene_set_lights(mt_scene *s, const mt_light *lights, int n) {
     s->lights_cap = cap;
   }
   if (n) HIP_TRY(hipMemcpy(s->d_lights, lights, (size_t)n * sizeof(mt_light), hipMemcpyHostToDevice));
+  // other lights, other costs: the damped forecast starts over (the old costs remain its first guess)
+  if ((size_t)n != s->lights_host.size() || (n && memcmp(s->lights_host.data(), lights, (size_t)n * sizeof(mt_light)) != 0)) {
+    s->lights_host.assign(lights, lights + n);
+    s->forecasts_in_a_row = 0;
+  }
   s->dev.lights = s->d_lights;
   s->dev.n_lights = n;
   return MT_OK;
