@@ -1,6 +1,6 @@
 """A/B of library variants (lib/libmythtracer_hip_<name>.so) against the current one on the repeated 1080p room frame,
 work counters OFF (the kernels bench.py times), 40 frames each after 8 settling frames."""
-import ctypes, os, sys, numpy as np, torch
+import ctypes, hashlib, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mythtracer_amd as M
@@ -26,5 +26,6 @@ for rep in range(2):
             for _ in range(40):
                 abi.render_chunk_device(h, sens, W, H, (0, 0, W, H), 5, ctypes.c_void_p(buf.data_ptr()))
             torch.cuda.synchronize(); a, b = abi.kernel_times(h); t = a + b
-            print("%-5s engine %d: mean %.3f median %.3f min %.3f max %.3f ms" % (name, engine, t.mean(), np.median(t), t.min(), t.max()), flush=True)
+            sha = hashlib.sha256(buf.cpu().numpy().tobytes()).hexdigest()[:12]
+            print("%-5s engine %d: mean %.3f median %.3f min %.3f max %.3f ms  frame %s" % (name, engine, t.mean(), np.median(t), t.min(), t.max(), sha), flush=True)
         abi.lib.mt_scene_destroy(h)
