@@ -71,6 +71,8 @@ struct mt_scene {
   size_t item_cost_bytes = 0;
   unsigned int *d_item_forecast = nullptr;  // [n_items]
   size_t item_forecast_bytes = 0;
+  unsigned int *d_item_forms = nullptr;     // [2 n_items] cost of a block as one unit / as four quarters (forecast_kernel)
+  size_t item_forms_bytes = 0;
   mt_sensor cost_sensor{};               // camera of the launch that measured the costs
   unsigned int *d_order_item = nullptr;  // [4 n_items]
   size_t order_item_bytes = 0;
@@ -289,12 +291,16 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   {
     int rc = ensure_bytes((void **)&s->d_item_cost, &s->item_cost_bytes, (size_t)P.n_items * 4);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_item_forecast, &s->item_forecast_bytes, (size_t)P.n_items * 4);
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_item_forms, &s->item_forms_bytes, (size_t)P.n_items * 8);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_item, &s->order_item_bytes, (size_t)P.n_items * 64);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_sub, &s->order_sub_bytes, (size_t)P.n_items * 16);
     if (rc != MT_OK) return rc;
   }
   P.item_cost = s->d_item_cost;
   P.item_forecast = s->d_item_forecast;
+  P.item_whole = s->d_item_forms;
+  P.item_qsum = s->d_item_forms + P.n_items;
+  if (getenv("MT_DEBUG_NO_FORMS")) P.item_whole = P.item_qsum = nullptr;
   P.order_item = s->d_order_item;
   P.order_sub = s->d_order_sub;
   P.n_work = s->d_work + 7;
@@ -378,6 +384,8 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (const char *e = getenv("MT_DEBUG_BLEND")) cap = (float)atof(e);
     blend = std::min(cap, (float)s->forecasts_in_a_row / (float)(s->forecasts_in_a_row + 1));
   }
+  // (the two measurements of a block belong to ONE camera, geometry and set of lights)
+  if (s->forecasts_in_a_row == 0) HIP_TRY(hipMemsetAsync(s->d_item_forms, 0, (size_t)P.n_items * 8, stream));
   s->forecasts_in_a_row = (history && !reproject) ? s->forecasts_in_a_row + 1 : 0;
   if (pool_engine) {
     if (!history) {
@@ -409,8 +417,10 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       // blocks above this share of an even split are cut into quarters; a re-projected forecast (moving camera) is
       // cut more eagerly -- it is a neighbourhood maximum of stale costs (swept, scripts/quad_sweep.py: repeated frame
       // 0.6 / 0.8 / 1.0 -> 7.18 / 6.84 / 7.28 ms, moving camera 6.69 / 7.20 / 9.89; with work 1.5: share 0.7 -> 6.40)
-      float quad_share = reproject ? 0.7f : 0.8f;
-      if (const char *e = getenv("MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
+      // (with the per-block ratio of the two forms' costs -- forecast_kernel -- the repeated frame no longer alternates,
+      // and re-swept: 0.8 / 0.9 / 0.95 / 1.0 / 1.05 / 1.1 -> 6.67 / 6.49 / 6.47 / 6.46 / 6.56 / 6.93 ms)
+      float quad_share = reproject ? 0.7f : 0.95f;
+      if (const char *e = getenv(reproject ? "MT_DEBUG_QUAD_SHARE_MOVING" : "MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
       float quad_keep = 1.0f;   // ... and stay so above this fraction of that threshold (1 = no hysteresis: swept, scripts/quad_sweep.py --
                                 // settings that steady the repeated frame cost the moving camera 50 %)
       if (const char *e = getenv("MT_DEBUG_QUAD_KEEP")) quad_keep = (float)atof(e);
@@ -553,6 +563,7 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_class_list) (void)hipFree(s->d_class_list);
   if (s->d_item_cost) (void)hipFree(s->d_item_cost);
   if (s->d_item_forecast) (void)hipFree(s->d_item_forecast);
+  if (s->d_item_forms) (void)hipFree(s->d_item_forms);
   if (s->d_order_item) (void)hipFree(s->d_order_item);
   if (s->d_order_sub) (void)hipFree(s->d_order_sub);
   if (s->d_rgb) (void)hipFree(s->d_rgb);

@@ -201,6 +201,8 @@ struct RenderParams {
   // (or a forecast), and the work order derived from them.
   unsigned int *item_cost;        // [n_items] ticks (>> 6) of the last frame; pieces of a block add up
   unsigned int *item_forecast;    // [n_items] expected cost of the block as ONE unit in the coming frame
+  unsigned int *item_whole;       // [n_items] the block's last cost measured as ONE unit, 0 none (state machine, camera at rest)
+  unsigned int *item_qsum;        // [n_items] ... and the last sum over its four quarters: their ratio scales the one to the other
   unsigned int *order_item;       // [<= 16 n_items] block id of work unit w
   signed char *order_sub;         // [<= 16 n_items] -1 = whole block, 0..3 = quarter, 4..19 = 2x2 cell (pool only)
   unsigned int *n_work;           // number of work units in order_item/order_sub

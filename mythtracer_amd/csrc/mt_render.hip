@@ -264,6 +264,19 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
     // of the old one and the measurement -- a block near a cutting threshold is otherwise measured whole in one
     // frame and in pieces in the next, and the schedule alternates between two states
     unsigned f = cost_of(P.item_cost[i]);
+    if (!pool && P.item_whole != nullptr) {
+      // A block near the cutting threshold: measured whole it costs c, in four pieces s, and s / w1 is only a guess
+      // of c -- when the guess is below the threshold and c above it, the block changes its form every few frames
+      // and every frame that renders it whole ends late.  Once both have been measured, THEIR ratio scales the one to
+      // the other, and the forecast of the block no longer depends on the form it was rendered in.
+      const unsigned word = P.item_cost[i], c = word & 0x7fffffffu;
+      if (word >> 31) P.item_qsum[i] = c; else P.item_whole[i] = c;
+      const unsigned w = P.item_whole[i], qs = P.item_qsum[i];
+      if ((word >> 31) && w > 0u && qs > 0u) {
+        const float ratio = fminf(fmaxf((float)qs / (float)w, 1.0f), 4.0f);
+        f = (unsigned)((float)c / ratio);
+      }
+    }
     if (blend > 0.0f) f = (unsigned)(blend * (float)(P.item_forecast[i] & 0x7fffffffu) + (1.0f - blend) * (float)f);
     P.item_forecast[i] = f | (pool ? 0u : (P.item_cost[i] & 0x80000000u));
     return;

@@ -17,11 +17,12 @@ def frames(cams):
     torch.cuda.synchronize()
     a, b = abi.kernel_times(h)
     return (a + b)[-len(cams):]
-for work in (1.5, 1.7, 1.9):
-    for share in (0.7, 0.8, 0.9):
+for work in (1.7,) if len(sys.argv) > 1 else (1.5, 1.7, 1.9):
+    for share in ([float(x) for x in sys.argv[1:]] or (0.7, 0.8, 0.9)):
         os.environ["MT_DEBUG_QUAD_SHARE"] = str(share); os.environ["MT_DEBUG_QUAD_WORK"] = str(work)
+        os.environ["MT_DEBUG_QUAD_SHARE_MOVING"] = str(share - 0.4 if len(sys.argv) > 1 else share)  # (argv: the moving camera 0.4 below)
         abi.set_engine(h, 1); abi.set_stats(h, False)
-        frames([sg.ROOM_CAMERA] * 8)
+        frames([sg.ROOM_CAMERA] * 24)
         t = frames([sg.ROOM_CAMERA] * 32)
         mv = frames([sg.ROOM_CAMERA[:4] + (2.0 * i,) + sg.ROOM_CAMERA[5:] for i in range(1, 13)])
         print("quad_work %.1f quad_share %.2f: repeated frame mean %.3f (min %.3f max %.3f) | moving camera mean %.3f max %.3f" % (
