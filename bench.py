@@ -406,6 +406,7 @@ def main():
         out["extras"] = extras
         if not args.no_cpu_baseline:
             chunk = (0, 0, W, H) if args.cpu_sample == "full" else (0, (H * 3) // 8, W, max(H // 4, 1))
+            abi.render_chunk(h, sens, W, H, chunk=chunk, max_depth=args.max_depth)  # (the camera has just jumped back: no usable history)
             g = abi.render_chunk(h, sens, W, H, chunk=chunk, max_depth=args.max_depth)
             rc = sum(g["stats"][k] for k in RAY_KEYS)
             try:
