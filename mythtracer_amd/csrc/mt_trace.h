@@ -75,6 +75,10 @@ namespace mt {
 #define MT_CNT_GET(i) (cnt[(i) * 64 + lane])
 #endif
 
+#ifndef MT_PACK_SMALL
+#define MT_PACK_SMALL 8  // at most this many lanes with exact scans: their small nodes packed over the wave (0: off; 16: a pass of 16 such rays 3.2 -> 4.2 M cycles)
+#endif
+
 // Phase profiling (diagnostic build only: python -m mythtracer_amd.build --prof).
 #ifdef MT_PROF
 #define MT_PROF_DECL unsigned long long prof_acc[PROF_COUNT] = {0}; unsigned long long prof_t0 = 0, prof_t1 = 0
@@ -1490,6 +1494,95 @@ __device__ __attribute__((noinline)) unsigned order_children_exact_call(const No
   unsigned keep = 0xffu;
   if (sub != nullptr) keep = degenerate_children(uniform_ptr(self), uniform_ptr(sub), uniform_i32(fc), ox, oy, oz, ix, iy, iz);
   return order_children<0>(as_const(uniform_ptr(N)), r, keep);
+}
+
+// Small nodes of a FEW lanes, exact tests, triangle-parallel and PACKED: the lists of all lanes in `need` (each
+// lane's own node: pb / pc per lane, pc < kBigNode) are laid end to end over the wave's lanes -- lane = one (ray,
+// triangle) pair, 64 pairs per trip -- every lane fetches its pair's box and tests it against the OWNER's ray
+// (ds_bpermute), Moeller-Trumbore for the boxes that pass, and the hits are folded into their owners in ascending
+// slot order = list order per owner (octtree.cc:177-196: a later hit wins unless it is strictly farther).  What a
+// lane scanning its list by itself does in pc trips of one triangle, sixty lanes idle, takes ONE trip here for six
+// lists of ten triangles.  Must be called by all 64 lanes; the result is the owner lane's.
+template <bool STATS>
+__device__ __attribute__((noinline)) ScanOut scan_small_packed_call(const double *b64, const double *vtx, int pb, int pc,
+                                                                    unsigned need_lo, unsigned need_hi, MT_RAY_PARAMS) {
+  MT_RAY_FROM_PARAMS(r);
+  b64 = uniform_ptr(b64);
+  vtx = uniform_ptr(vtx);
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const unsigned long long need =
+      ((unsigned long long)(unsigned)uniform_i32((int)need_hi) << 32) | (unsigned)uniform_i32((int)need_lo);
+  ScanOut o{-1, 0.0, 0u};
+  int total = 0;
+  for (unsigned long long w = need; w != 0ull; w &= w - 1ull) total += __builtin_amdgcn_readlane(pc, __builtin_ctzll(w));
+  auto from_owner = [&](double v, int owner) -> double {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(owner * 4, (int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(owner * 4, (int)(unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+  };
+  for (int base = 0; base < total; base += 64) {
+    const int slot = base + lane;
+    // whose list does this slot belong to, and which triangle of it?
+    int owner = 0, tri = 0, off = 0;
+    bool valid = false;
+    for (unsigned long long w = need; w != 0ull; w &= w - 1ull) {
+      const int L = __builtin_ctzll(w);
+      const int pcl = __builtin_amdgcn_readlane(pc, L), pbl = __builtin_amdgcn_readlane(pb, L);
+      if (slot >= off && slot < off + pcl) {
+        owner = L;
+        tri = pbl + (slot - off);
+        valid = true;
+      }
+      off += pcl;
+    }
+    RayRegs u;
+    u.ox = from_owner(r.ox, owner); u.oy = from_owner(r.oy, owner); u.oz = from_owner(r.oz, owner);
+    u.dx = from_owner(r.dx, owner); u.dy = from_owner(r.dy, owner); u.dz = from_owner(r.dz, owner);
+    u.ix = from_owner(r.ix, owner); u.iy = from_owner(r.iy, owner); u.iz = from_owner(r.iz, owner);
+    bool pass = false;
+    if (valid) {
+      const double *bp = b64 + (size_t)tri * 6;
+      const double b[6] = {bp[0], bp[1], bp[2], bp[3], bp[4], bp[5]};
+      pass = slab_pass_lane<true>(b, u);
+    }
+    const unsigned long long pm = __ballot(pass);
+    if (STATS) {
+      // (the owner counts what was fetched and tested for its list)
+      unsigned long long mine_slots = 0ull;
+      {
+        int off2 = 0;
+        for (unsigned long long w = need; w != 0ull; w &= w - 1ull) {
+          const int L = __builtin_ctzll(w);
+          const int pcl = __builtin_amdgcn_readlane(pc, L);
+          const int a = off2 - base, e = off2 + pcl - base;  // this owner's slots within the trip: [a, e)
+          if (lane == L && e > 0 && a < 64) {
+            const int a0 = a < 0 ? 0 : a, e0 = e > 64 ? 64 : e;
+            mine_slots = (e0 - a0 >= 64 ? ~0ull : ((1ull << (e0 - a0)) - 1ull)) << a0;
+          }
+          off2 += pcl;
+        }
+      }
+      o.bytes_v += 48u * (unsigned)__builtin_popcountll(mine_slots) + 72u * (unsigned)__builtin_popcountll(mine_slots & pm);
+      o.mt_tests += (unsigned)__builtin_popcountll(mine_slots & pm);
+    }
+    if (pm == 0ull) continue;
+    double t = 0.0;
+    bool hit = false;
+    if (pass) hit = moller_trumbore(vtx + (size_t)tri * 9, u.ox, u.oy, u.oz, u.dx, u.dy, u.dz, &t);
+    unsigned long long hm = __ballot(hit);
+    while (hm != 0ull) {  // ascending slot = list order within every owner's list
+      const int i = __builtin_ctzll(hm);
+      hm &= hm - 1ull;
+      const double ti = readlane_f64(t, i);
+      const int ow = __builtin_amdgcn_readlane(owner, i), tr = __builtin_amdgcn_readlane(tri, i);
+      if (lane == ow && !(o.best >= 0 && ti > o.best_t)) {
+        o.best = tr;
+        o.best_t = ti;
+      }
+    }
+  }
+  return o;
 }
 
 // ---- non-inlined entry points of the node scans ------------------------------
@@ -2936,6 +3029,41 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // ---- phase A: every lane works through its own small nodes
     if (lane_phase) {
       MT_PROF_BEGIN(prof_t1);
+#if MT_PACK_SMALL > 0
+      // A handful of lanes with exact scans (what the hit-set walk leaves behind: rays with a zero direction
+      // component, four to eight lanes of a unit on such a pixel column): their small nodes' lists are scanned
+      // together, packed over the wave's lanes (scan_small_packed_call), instead of every lane by itself.
+      if (!all_regular) {
+        for (int guard = 0;; guard++) {
+          const bool mine = cur >= 0 && cur_pc < kBigNode;
+          const unsigned long long need = __ballot(mine);
+          if (need == 0ull || __builtin_popcountll(need) > MT_PACK_SMALL) break;
+          if (guard > S.n_nodes) {
+            if (mine) cur = -2;
+            break;
+          }
+          const ScanOut o = scan_small_packed_call<STATS>(S.tri_aabb, S.tri_vertex, mine ? cur_pb : 0, mine ? cur_pc : 0,
+                                                          (unsigned)need, (unsigned)(need >> 32), MT_RAY_ARGS(r));
+          if (mine) {
+            if (STATS) {
+              MT_CNT_ADD(1, 1u);
+              MT_CNT_ADD(2, (unsigned)cur_pc);
+              if (o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
+              if (o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
+            }
+            unsigned ordw = 0;
+            const int fc = cur_fc;
+            if (fc != 0) {
+              if (STATS) MT_CNT_ADD(0, 8u);
+              ordw = order_children_exact_lane_call(S.nodes + cur, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
+                                                    irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr, S.self, fc);
+              if (STATS) MT_CNT_ADD(4, 88u + 24u * (((ordw >> 24) & 15u) + 1u));
+            }
+            finish_node(fc, ordw, o.best, o.best_t);
+          }
+        }
+      }
+#endif
       for (int guard = 0; cur >= 0 && cur_pc < kBigNode; guard++) {
         if (guard > S.n_nodes) {
           cur = -2;
