@@ -211,6 +211,47 @@ def test_c_abi_intersect_rays_match_reference(case, scene, scenes):
         abi.scene_destroy(h)
 
 
+@pytest.mark.parametrize("per_wave", [1, 3, 8, 9, 64])
+def test_a_few_rays_with_a_zero_direction_component_per_wave(per_wave, scenes):
+    """Rays IN the plane x = 200 of the room (one zero direction component: the exact path behind the hit-set walk),
+    `per_wave` of them in every wave of 64, the rest missing the scene: up to eight such lanes have the lists of their
+    small nodes scanned together, packed over the wave (scan_small_packed_call); nine and more scan lane by lane.
+    Every hit equals the oracle's, in every traversal mode, with the oracle's counters in the un-pruned one."""
+    rnd = np.random.RandomState(per_wave)
+    n_waves = 6
+    rays = np.zeros((64 * n_waves, 6))
+    rays[:, :3] = 1.0e6
+    rays[:, 3:] = (0.6, 0.64, 0.48)  # away from the scene
+    for w in range(n_waves):
+        k = w * 64 + rnd.permutation(64)[:per_wave]
+        ang = rnd.uniform(-0.7, 0.7, per_wave)
+        rays[k, 0] = 200.0
+        rays[k, 1] = rnd.choice([120.0, 60.0, 200.0], per_wave)
+        rays[k, 2] = rnd.choice([20.0, 200.0], per_wave)
+        d = np.stack([np.zeros(per_wave), np.sin(ang), np.cos(ang)], axis=1)
+        if w % 2:
+            d = d[:, [1, 0, 2]]; rays[k, 0] = rnd.uniform(50.0, 350.0, per_wave); rays[k, 1] = 120.0  # ... or in y = 120
+        rays[k, 3:] = d
+    o = orclib.OracleScene(scenes["room"])
+    want = o.intersect(rays)
+    abi = M.hip_abi()
+    h = abi.scene_create(M.MythTracer(scenes["room"]).flatten())
+    try:
+        for mode in (0, 7, 1, 5):
+            abi.set_traversal_mode(h, mode)
+            r = abi.intersect_rays(h, rays)
+            assert np.array_equal(r["line"], want["line"]), mode
+            hit = want["line"] >= 0
+            assert hit.sum() >= per_wave * n_waves // 2
+            assert np.array_equal(r["t"][hit], want["t"][hit]), mode
+            assert np.array_equal(r["point"][hit], want["point"][hit]), mode
+            if mode == 7:
+                for k in ("box_tests", "node_visits", "tri_tests", "mt_tests"):
+                    assert r["stats"][k] == want["counters"][k], (k, r["stats"][k], want["counters"][k])
+    finally:
+        abi.scene_destroy(h)
+
+
 def test_c_abi_render_direct_and_modes(scenes):
     """mt_render_chunk called directly; all traversal modes give the same image,
     debug buffer, ray counts and Möller–Trumbore counts.  The modes that skip no
