@@ -386,7 +386,9 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   }
   // (the two measurements of a block belong to ONE camera, geometry and set of lights)
   if (s->forecasts_in_a_row == 0) HIP_TRY(hipMemsetAsync(s->d_item_forms, 0, (size_t)P.n_items * 8, stream));
-  s->forecasts_in_a_row = (history && !reproject) ? s->forecasts_in_a_row + 1 : 0;
+  // (a forecast made from the OTHER engine's costs -- the frame after a first frame -- does not count: the next one
+  // starts the running mean with this engine's own measurement)
+  s->forecasts_in_a_row = (history && !reproject && s->last_engine == engine) ? s->forecasts_in_a_row + 1 : 0;
   if (pool_engine) {
     if (!history) {
       hipLaunchKernelGGL(probe_kernel, dim3((4 * P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream,
