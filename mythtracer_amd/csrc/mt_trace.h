@@ -16,7 +16,10 @@
 //   * every lane keeps its own recursion state (the reference's call stack of
 //     PrimitiveIntersectRay) in an LDS-resident per-lane stack;
 //   * small nodes (< kBigNode triangles) are scanned lane-parallel, every lane
-//     its own node; for the big ones the wave repeatedly picks the lowest-
+//     its own node -- unless only a handful of lanes is left (what the hit-set
+//     walk leaves behind: rays with a zero direction component), whose lists are
+//     then scanned together, packed over the wave's lanes, one (ray, triangle)
+//     pair per lane (scan_small_packed_call); for the big ones the wave repeatedly picks the lowest-
 //     numbered node any lane still has to scan (nodes are numbered breadth-first,
 //     so the big top-of-tree lists are scanned once for all lanes that need
 //     them) and scans it for those lanes only.  Its boxes are then WAVE-UNIFORM:
