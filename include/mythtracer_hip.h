@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MT_ABI_VERSION 2
+#define MT_ABI_VERSION 3
 
 enum {
   MT_OK = 0,
@@ -194,6 +194,26 @@ int mt_blit_tiles_device(mt_scene *scene, int image_w, int image_h,
                          int tile_stride, int n_tiles, const void *d_tiles,
                          void *d_image, void *stream);
 
+/* One frame on SEVERAL GPUs of this process -- the master/worker farm of the
+ * reference (main_net_master.cc:195-236: GenerateWork cuts the frame into
+ * WorkChunks, every worker renders chunks with the full-image sensor from its
+ * own copy of the scene, main_net_worker.cc:29-32,148-150, BlitWorkChunk puts
+ * them into the frame) inside one host process: scenes[r] is a replica of the
+ * scene on its own HIP device (mt_scene_desc.device; several replicas may share
+ * a device), tile k of the tile_w x tile_h grid belongs to replica k mod n, all
+ * replicas render at the same time, the tile buffers travel to scenes[0]'s
+ * device (peer copies over xGMI, 3 bytes per pixel in total), are blitted there
+ * and the frame is copied to out_rgb (image_w*image_h*3 bytes, row-major, top
+ * row first -- what RayTrace(int,int,Camera*,vector*) returns).  Lights must
+ * have been set on every replica.  stats (nullable): n_scenes entries, the work
+ * counters, kernel_ms = that replica's frame kernels, total_ms = wall time of
+ * the whole call; stats[0].total_ms - max kernel_ms ~ exchange + blit + D2H.
+ * The result is byte-identical to mt_render_chunk of the whole frame. */
+int mt_render_frame_multi(mt_scene *const *scenes, int n_scenes,
+                          const mt_sensor *sensor, int image_w, int image_h,
+                          int tile_w, int tile_h, int max_depth,
+                          uint8_t *out_rgb, mt_stats *stats);
+
 /* Fetches and clears the accumulated counters (kernel_ms/total_ms = 0). */
 int mt_scene_read_stats(mt_scene *scene, mt_stats *stats);
 
@@ -224,8 +244,42 @@ int mt_scene_set_scheduling(mt_scene *scene, int use_cost_history);
  * side (shortest chain of dependent passes per pixel; wins when a launch has
  * few blocks per wave, e.g. one rank's share of a multi-GPU frame).  0 =
  * automatic (default): 2 for launches with fewer than 9 blocks per resident
- * wave and for launches without measured block costs, else 1.  Also forgets the recorded costs.  (No reference counterpart.) */
+ * wave and for launches without measured block costs, else 1.  Also forgets the
+ * recorded costs.  Limits of engine 2: at most 254 lights (a pool entry holds the
+ * light in 8 bits), and its scratch -- per resident wave `capacity` records of
+ * 160 + 80 n_lights bytes, capacity <= 1024 -- must fit a budget (4 GiB; the
+ * capacity shrinks to fit, down to the ~280 records its depth-first throttle
+ * needs).  The automatic mode never fails on either limit: launches the pool
+ * cannot hold comfortably are rendered by engine 1, which has no such limits;
+ * only an EXPLICIT engine 2 beyond them returns MT_ERR_UNSUPPORTED.
+ * (No reference counterpart.) */
 int mt_scene_set_engine(mt_scene *scene, int engine);
+/* Process-wide default of mt_scene_set_engine for scenes created afterwards
+ * (also those the C++ facade creates); 0 initially. */
+int mt_set_default_engine(int engine);
+
+/* Tuning constants of the work order and of the engine choice (defaults = what
+ * the sweeps in DESIGN.md settled on).  None of them changes a pixel; tests and
+ * experiment scripts use them instead of environment variables.  The call also
+ * forgets the recorded costs. */
+enum {
+  MT_TUNE_POOL_BELOW = 0,     /* automatic engine: ray pool below this many blocks per resident wave (9) */
+  MT_TUNE_POOL_CAP,           /* records per wave of the ray pool, 0 = default (tests: force the throttle) */
+  MT_TUNE_PACKED_STACK,       /* 1 (default): 16-byte traversal stack frames when indices fit; 0: 20-byte */
+  MT_TUNE_BLOCKS_PER_CU,      /* 0 = as many workgroups per CU as fit */
+  MT_TUNE_FORECAST_RADIUS,    /* blocks; < 0 = 1, or 2 when the camera origin moved */
+  MT_TUNE_BLEND,              /* damping of a repeated frame's cost forecast (0.9) */
+  MT_TUNE_FORMS,              /* 1 (default): per-block ratio of the two measured cost forms */
+  MT_TUNE_POOL_CUT_SHARE,     /* < 0 = 1.0 with history, 0.3 without */
+  MT_TUNE_POOL_PIECE_TIME1, MT_TUNE_POOL_PIECE_TIME2,
+  MT_TUNE_POOL_PIECE_WORK1, MT_TUNE_POOL_PIECE_WORK2,
+  MT_TUNE_POOL_CELL_FACTOR,
+  MT_TUNE_QUAD_SHARE, MT_TUNE_QUAD_SHARE_MOVING, MT_TUNE_QUAD_KEEP,
+  MT_TUNE_QUAD_WORK, MT_TUNE_QUAD_WORK_MOVING,
+  MT_TUNE_POOL_SCRATCH_MB,    /* scratch budget of the ray pool (4096) */
+  MT_TUNE_COUNT
+};
+int mt_scene_set_tuning(mt_scene *scene, int knob, double value);
 
 /* Device durations of the launches made since the previous call (at most the
  * last 64, oldest first; at most max_n): primary_ms[i] = the kernels that

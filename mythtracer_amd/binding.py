@@ -11,7 +11,7 @@ HIP_LIB = os.path.join(PKG, "lib", "libmythtracer_hip.so")
 HOST_LIB = os.path.join(PKG, "lib", "libmythtracer_host.so")
 
 MT_OK = 0
-MT_ABI_VERSION = 2
+MT_ABI_VERSION = 3
 MT_TEX_RGB8, MT_TEX_F64 = 0, 1
 
 # every symbol include/mythtracer_hip.h declares
@@ -21,8 +21,16 @@ HIP_SYMBOLS = [
     "mt_render_chunk_device", "mt_render_tiles_device", "mt_blit_tiles_device",
     "mt_scene_read_stats", "mt_intersect_rays", "mt_scene_set_traversal_mode",
     "mt_scene_kernel_times", "mt_scene_set_scheduling", "mt_scene_set_engine",
-    "mt_scene_set_stats",
+    "mt_scene_set_stats", "mt_set_default_engine", "mt_scene_set_tuning",
+    "mt_render_frame_multi",
 ]
+
+# mt_scene_set_tuning knobs, in the order of the enum in include/mythtracer_hip.h
+TUNE = {name: i for i, name in enumerate([
+    "POOL_BELOW", "POOL_CAP", "PACKED_STACK", "BLOCKS_PER_CU", "FORECAST_RADIUS", "BLEND", "FORMS",
+    "POOL_CUT_SHARE", "POOL_PIECE_TIME1", "POOL_PIECE_TIME2", "POOL_PIECE_WORK1", "POOL_PIECE_WORK2",
+    "POOL_CELL_FACTOR", "QUAD_SHARE", "QUAD_SHARE_MOVING", "QUAD_KEEP", "QUAD_WORK", "QUAD_WORK_MOVING",
+    "POOL_SCRATCH_MB"])}
 
 STAT_NAMES = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests",
               "node_visits", "tri_tests", "mt_tests", "shaded_hits"]
@@ -125,9 +133,11 @@ class HipAbi:
         L.mt_scene_set_traversal_mode.argtypes = [vp, ci]
         L.mt_scene_kernel_times.argtypes = [vp, ci, vp, vp]
         L.mt_scene_set_scheduling.argtypes = [vp, ci]
-        if hasattr(L, "mt_scene_set_engine"):  # absent from older builds loaded by the A/B scripts
-            L.mt_scene_set_engine.argtypes = [vp, ci]
-            L.mt_scene_set_stats.argtypes = [vp, ci]
+        L.mt_scene_set_engine.argtypes = [vp, ci]
+        L.mt_scene_set_stats.argtypes = [vp, ci]
+        L.mt_set_default_engine.argtypes = [ci]
+        L.mt_scene_set_tuning.argtypes = [vp, ci, C.c_double]
+        L.mt_render_frame_multi.argtypes = [vp, ci, C.POINTER(mt_sensor)] + [ci] * 5 + [vp, vp]
 
     def last_error(self) -> str:
         return self.lib.mt_last_error().decode(errors="replace")
@@ -262,6 +272,27 @@ class HipAbi:
         """0 = automatic, 1 = throughput engine (state machine), 2 = latency engine (ray pool)."""
         self.check(self.lib.mt_scene_set_engine(h, int(engine)))
 
+    def set_default_engine(self, engine: int):
+        """Engine of the scenes created from now on (also those the C++ facade creates)."""
+        self.check(self.lib.mt_set_default_engine(int(engine)))
+
+    def set_tuning(self, h, knob: str, value: float):
+        """mt_scene_set_tuning; knob = a key of TUNE (e.g. "POOL_CAP")."""
+        self.check(self.lib.mt_scene_set_tuning(h, TUNE[knob], float(value)))
+
+    def render_frame_multi(self, handles, sensor12, image_w, image_h, tile_w=64, tile_h=64, max_depth=5,
+                           want_stats=True):
+        """mt_render_frame_multi: one frame on the replicas `handles` (one per GPU)."""
+        n = len(handles)
+        arr = (C.c_void_p * n)(*handles)
+        rgb = np.zeros((image_h, image_w, 3), dtype=np.uint8)
+        st = (mt_stats * n)()
+        s = self.make_sensor(sensor12)
+        self.check(self.lib.mt_render_frame_multi(C.cast(arr, C.c_void_p), n, C.byref(s), image_w, image_h,
+                                                  tile_w, tile_h, max_depth, _ptr(rgb),
+                                                  C.cast(st, C.c_void_p) if want_stats else None))
+        return dict(rgb=rgb, stats=[st[i].as_dict() for i in range(n)])
+
     def set_scheduling(self, h, use_cost_history: bool):
         self.check(self.lib.mt_scene_set_scheduling(h, 1 if use_cost_history else 0))
 
@@ -309,6 +340,8 @@ def host_lib():
     L.mth_new.argtypes = [ci, ci]
     L.mth_free.argtypes = [vp]
     L.mth_free.restype = None
+    L.mth_set_devices.argtypes = [vp, vp, ci]
+    L.mth_set_devices.restype = None
     L.mth_last_error.restype = cs
     L.mth_last_error.argtypes = [vp]
     L.mth_load_obj.argtypes = [vp, cs]
@@ -387,6 +420,11 @@ class MythTracer:
 
     def last_error(self):
         return self.L.mth_last_error(self.h).decode(errors="replace")
+
+    def set_devices(self, devices):
+        """MythTracer::SetDevices: the W x H overload of RayTrace renders on all of them."""
+        d = _i32(devices)
+        self.L.mth_set_devices(self.h, _ptr(d), len(d))
 
     def load_obj(self, path) -> bool:
         return bool(self.L.mth_load_obj(self.h, os.fsencode(path)))

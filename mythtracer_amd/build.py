@@ -77,6 +77,17 @@ def build_diag(verbose: bool = False) -> str:
     return out
 
 
+def build_knobs(verbose: bool = False) -> str:
+    """-DMT_DEBUG_KNOBS: the dump facilities (MT_DEBUG_ITEM_CYCLES, _PRINT_UNITS, _TIMELINE, _HEARTBEAT), read from
+    the environment once in mt_scene_create.  Replaces lib/libmythtracer_hip.so until the next normal build
+    (experiment scripts only; never what tests or bench.py measure)."""
+    cmd = [HIPCC] + HIP_FLAGS + ["-DMT_DEBUG_KNOBS"] + os.environ.get("MT_EXTRA_FLAGS", "").split() + [
+        "-I", INC, "-I", CSRC, "-o", HIP_LIB, os.path.join(CSRC, "mt_capi.hip")]
+    subprocess.check_call(cmd)
+    os.utime(os.path.join(CSRC, "mt_capi.hip"))  # the next build_hip() rebuilds the shipping library
+    return HIP_LIB
+
+
 def build_host(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIB, exist_ok=True)
     srcs = _files(os.path.join(HOST, "src"), (".cc",))
@@ -100,6 +111,9 @@ def build_all(force: bool = False, verbose: bool = False):
 if __name__ == "__main__":
     if "--diag" in sys.argv:
         print("built:", build_diag())
+        sys.exit(0)
+    if "--knobs" in sys.argv:
+        print("built:", build_knobs())
         sys.exit(0)
     if "--prof" in sys.argv:
         print("built:", build_prof())

@@ -4,6 +4,11 @@
 // the kernels of mt_render.hip.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <limits>
 #include <utility>
 
@@ -43,6 +48,35 @@ int fail(int code, const char *fmt, ...) {
   } while (0)
 
 constexpr size_t kLdsBudget = 160 * 1024;
+
+// Tuning constants of the work order and of the engine choice, with the values the sweeps of DESIGN.md section 5
+// settled on.  Changed through mt_scene_set_tuning only (tests, experiment scripts): the library reads no
+// environment variable on the launch path.  (A -DMT_DEBUG_KNOBS build additionally reads its DUMP facilities --
+// item cycles, unit counts, heartbeat, time line -- from the environment, once, in mt_scene_create.)
+struct Tuning {
+  double v[MT_TUNE_COUNT];
+  Tuning() {
+    for (double &x : v) x = 0.0;
+    v[MT_TUNE_POOL_BELOW] = 9.0;          // blocks per resident wave below which a launch is taken to be tail-bound
+    v[MT_TUNE_POOL_CAP] = 0.0;            // 0 = default capacity of a wave's ray pool
+    v[MT_TUNE_PACKED_STACK] = 1.0;
+    v[MT_TUNE_BLOCKS_PER_CU] = 0.0;       // 0 = as many as fit
+    v[MT_TUNE_FORECAST_RADIUS] = -1.0;    // < 0 = 1 block, 2 when the origin moved
+    v[MT_TUNE_BLEND] = 0.9;
+    v[MT_TUNE_FORMS] = 1.0;
+    v[MT_TUNE_POOL_CUT_SHARE] = -1.0;     // < 0 = 1.0 with history, 0.3 without
+    v[MT_TUNE_POOL_PIECE_TIME1] = 0.35; v[MT_TUNE_POOL_PIECE_TIME2] = 0.12;
+    v[MT_TUNE_POOL_PIECE_WORK1] = 1.1;  v[MT_TUNE_POOL_PIECE_WORK2] = 3.0;
+    v[MT_TUNE_POOL_CELL_FACTOR] = 3.0;
+    v[MT_TUNE_QUAD_SHARE] = 0.95; v[MT_TUNE_QUAD_SHARE_MOVING] = 0.7;
+    v[MT_TUNE_QUAD_KEEP] = 1.0;
+    v[MT_TUNE_QUAD_WORK] = 1.7;   v[MT_TUNE_QUAD_WORK_MOVING] = 1.5;
+    v[MT_TUNE_POOL_SCRATCH_MB] = 4096.0;  // automatic mode: above this the state machine renders (explicit engine 2: the cap shrinks)
+  }
+};
+
+// process-wide default of mt_scene_set_engine for scenes created from now on (mt_set_default_engine)
+std::atomic<int> g_default_engine{0};
 
 }  // namespace
 
@@ -84,17 +118,6 @@ struct mt_scene {
   size_t rgb_bytes = 0;
   mt_debug_px *d_debug = nullptr;
   size_t debug_bytes = 0;
-  // rays with one zero direction component (DevScene::deg_*): per axis the box planes of all triangles, sorted,
-  // with the triangle each belongs to; the node of every triangle; the parent of every node
-  std::vector<std::pair<double, int32_t>> plane_index[3];
-  std::vector<int32_t> tri_node, node_parent;
-  uint32_t *d_deg_maps = nullptr;  // [3][block words] then [3][node words]
-  size_t deg_blk_words = 0, deg_node_words = 0;
-  uint32_t *deg_stage[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned
-  hipEvent_t deg_stage_done[4] = {};
-  unsigned long long deg_uploads = 0;
-  double deg_origin[3] = {0, 0, 0};
-  bool deg_valid = false;
   std::vector<mt_light> lights_host;  // what d_lights holds
   int forecasts_in_a_row = 0;  // launches with this geometry and camera whose work order came from a forecast
   int waves_per_block = 4;
@@ -111,6 +134,20 @@ struct mt_scene {
   unsigned long long *hb_host = nullptr;  // MT_DEBUG_HEARTBEAT: pinned, device-visible
   unsigned long long *d_prof = nullptr;   // -DMT_PROF build: phase cycle sums
   DevScene *d_dev = nullptr;              // device copy of `dev` (DevScene::self)
+  Tuning tune;
+  int tree_depth_levels = 0, n_tris_total = 0, n_nodes_total = 0;  // for MT_TUNE_PACKED_STACK
+  // -DMT_DEBUG_KNOBS builds only (read from the environment once, in mt_scene_create)
+  std::string dbg_item_cycles, dbg_timeline;
+  int dbg_print_units = 0;
+  // mt_render_frame_multi: this scene's tile buffer and stream, the frame + gathered tiles on the first scene's GPU
+  uint8_t *d_multi_tiles = nullptr;
+  size_t multi_tiles_bytes = 0;
+  uint8_t *d_multi_gather = nullptr;
+  size_t multi_gather_bytes = 0;
+  uint8_t *d_multi_frame = nullptr;
+  size_t multi_frame_bytes = 0;
+  hipStream_t multi_stream = nullptr;
+  hipEvent_t multi_done = nullptr;
 };
 
 namespace {
@@ -133,49 +170,6 @@ bool finite3(const double *p, size_t n) {
   return true;
 }
 
-// Rays with ONE zero direction component from the camera's origin (a camera that looks along an axis): which
-// blocks / subtrees hold a triangle whose box has a plane exactly at the origin's coordinate on that axis?  Those
-// pass the reference's pre-filter through NaN whatever the other axes say (0 * inf); every other box is decided by
-// its range on that axis and by the other two axes alone, so its unions may be culled (mt_trace.h,
-// degenerate_axis).  Equality is decided on the fp64 boxes the reference caches (primitive_triangle.cc:11-25).
-// Recomputed only when the origin changes (a turning camera keeps it).
-int refresh_degenerate_maps(mt_scene *s, const mt_sensor *sensor, hipStream_t stream) {
-  if (s->deg_valid && memcmp(s->deg_origin, sensor->origin, sizeof s->deg_origin) == 0) return MT_OK;
-  // staged through one of four pinned buffers, so that a camera that moves every frame does not make the host wait
-  // for the previous frame (a buffer is reused only after the copy that read it has completed)
-  const size_t n_words = 3 * (s->deg_blk_words + s->deg_node_words);
-  const int slot = (int)(s->deg_uploads++ % 4);
-  if (!s->deg_stage[slot]) {
-    HIP_TRY(hipHostMalloc((void **)&s->deg_stage[slot], n_words * sizeof(uint32_t), hipHostMallocDefault));
-    HIP_TRY(hipEventCreateWithFlags(&s->deg_stage_done[slot], hipEventDisableTiming));
-  } else {
-    HIP_TRY(hipEventSynchronize(s->deg_stage_done[slot]));
-  }
-  uint32_t *maps = s->deg_stage[slot];
-  memset(maps, 0, n_words * sizeof(uint32_t));
-  for (int a = 0; a < 3; a++) {
-    const double c = sensor->origin[a];
-    uint32_t *db = maps + (size_t)a * s->deg_blk_words;
-    uint32_t *dn = maps + 3 * s->deg_blk_words + (size_t)a * s->deg_node_words;
-    const auto &ix = s->plane_index[a];
-    auto lo = std::lower_bound(ix.begin(), ix.end(), std::make_pair(c, (int32_t)INT32_MIN));
-    for (auto it = lo; it != ix.end() && it->first == c; ++it) {  // (-0.0 == 0.0: both are "at" the plane, as in (p - o) * inf)
-      const int32_t t = it->second;
-      db[(size_t)(t / kGroupTris) >> 5] |= 1u << ((t / kGroupTris) & 31);
-      for (int32_t n = s->tri_node[(size_t)t]; n >= 0; n = s->node_parent[(size_t)n]) {
-        if (dn[(size_t)n >> 5] & (1u << (n & 31))) break;  // the ancestors are marked already
-        dn[(size_t)n >> 5] |= 1u << (n & 31);
-      }
-    }
-    s->dev.deg_c[a] = c;
-  }
-  HIP_TRY(hipMemcpyAsync(s->d_deg_maps, maps, n_words * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-  HIP_TRY(hipEventRecord(s->deg_stage_done[slot], stream));
-  memcpy(s->deg_origin, sensor->origin, sizeof s->deg_origin);
-  s->deg_valid = true;
-  return MT_OK;
-}
-
 // Launch geometry: as many 4-wave blocks as the CU's LDS/VGPR budget admits.
 int configure_launch(mt_scene *s) {
   const size_t per_wave = wave_stack_bytes(s->dev.tree_depth, s->dev.pack_shift != 0);
@@ -187,26 +181,31 @@ int configure_launch(mt_scene *s) {
   }
   s->waves_per_block = wpb;
   s->lds_bytes = per_wave * wpb;
-  // The attribute is per-function process state: keep it at the largest size
-  // any scene of this process needs (a shallower scene must not lower it).
-  static size_t lds_attr = 0;
-  if (s->lds_bytes > lds_attr) {
-    const void *kernels[] = {(const void *)render_kernel<true>, (const void *)render_kernel<false>,
-                             (const void *)primary_kernel<true>, (const void *)primary_kernel<false>,
-                             (const void *)pool_kernel<true>, (const void *)pool_kernel<false>,
-                             (const void *)probe_kernel, (const void *)intersect_kernel};
-    for (const void *k : kernels) {
-      HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+  // The attribute is per function AND per device: keep it, for every device, at the largest size any scene
+  // of this process needs there (a shallower scene must not lower it; scenes may be created from several threads).
+  {
+    static std::mutex mu;
+    static std::map<int, size_t> lds_attr;  // device -> bytes set
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &have = lds_attr[s->device];
+    if (s->lds_bytes > have) {
+      const void *kernels[] = {(const void *)render_kernel<true>, (const void *)render_kernel<false>,
+                               (const void *)primary_kernel<true>, (const void *)primary_kernel<false>,
+                               (const void *)pool_kernel<true>, (const void *)pool_kernel<false>,
+                               (const void *)probe_kernel, (const void *)intersect_kernel};
+      for (const void *k : kernels) {
+        HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+      }
+      have = s->lds_bytes;
     }
-    lds_attr = s->lds_bytes;
   }
   int per_cu = 0;
   HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_kernel<true>,
                                                        wpb * 64, s->lds_bytes));
   if (per_cu < 1) per_cu = 1;
   if (per_cu * wpb > 16) per_cu = 16 / wpb;  // more waves only add divergence state
-  if (const char *e = getenv("MT_DEBUG_BLOCKS_PER_CU")) {  // occupancy experiments
-    const int v = atoi(e);
+  {  // occupancy experiments
+    const int v = (int)s->tune.v[MT_TUNE_BLOCKS_PER_CU];
     if (v >= 1 && v < per_cu) per_cu = v;
   }
   s->grid_blocks = s->n_cu * per_cu;
@@ -274,16 +273,49 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   // by its amount of work, i.e. when there are few blocks per wave (a rank's
   // share of a multi-GPU frame, a small chunk).
   int engine = s->engine;
-  if (const char *e = getenv("MT_ENGINE")) engine = atoi(e);
-  if (engine != 1 && engine != 2) {
+  const bool engine_auto = engine != 1 && engine != 2;
+  // Ray pool: records per wave.  64 * (2^(max_depth+1) - 1) is every call of every pixel's recursion tree at once;
+  // beyond kPoolCapMax the kernel's throttle keeps the pool within the capacity (depth first).  A record grows with
+  // the number of lights (160 + 80 n bytes), so the capacity shrinks with it -- down to the floor the throttle needs
+  // -- to keep the scratch of all resident waves within MT_TUNE_POOL_SCRATCH_MB.
+  const int n_l = s->dev.n_lights;
+  constexpr int kPoolMaxLights = 254;  // a pool entry has 8 bits for (light + 1)
+  long long pool_cap = 0;
+  size_t pool_stride = 0;
+  bool pool_fits = n_l <= kPoolMaxLights, pool_roomy = pool_fits;
+  if (pool_fits) {
+    constexpr long long kPoolCapMax = 1024;
+    const long long all = 64ll * ((2ll << max_depth) - 1);
+    const long long floor_cap = 64 + 128 + 4ll * (max_depth + 1) + 64;
+    pool_cap = all < kPoolCapMax ? all : kPoolCapMax;
+    const size_t rec_bytes = (size_t)(kRecFixed + kLightSlot * n_l) * sizeof(double);
+    const size_t per_rec = rec_bytes + (size_t)(n_l > 0 ? n_l : 1) * 4 + 4;
+    const double budget = s->tune.v[MT_TUNE_POOL_SCRATCH_MB] * 1048576.0;
+    const long long fit = (long long)(budget / ((double)per_rec * (double)(waves ? waves : 1)));
+    if (pool_cap > fit) {  // automatic mode: such a launch goes to the state machine; engine 2 by request: a smaller pool
+      pool_roomy = false;
+      pool_cap = fit;
+    }
+    if ((long long)s->tune.v[MT_TUNE_POOL_CAP] > 0) pool_cap = (long long)s->tune.v[MT_TUNE_POOL_CAP];  // tests: force the depth-first throttle
+    if (pool_cap < floor_cap) {
+      pool_fits = (double)floor_cap * (double)per_rec * (double)(waves ? waves : 1) <= 4.0 * budget;
+      pool_cap = floor_cap;
+    }
+    pool_stride = ((size_t)pool_cap * per_rec + 255) & ~(size_t)255;
+  }
+  if (engine_auto) {
     // blocks per wave below which a launch is taken to be tail-bound (one rank's share of the 4K frame
     // at N = 8 has 7.9 per wave: ray pool 4.4 ms, state machine 4.7; at N = 4, 15.8: 7.3 against 6.6)
-    float per_wave = 9.0f;
-    if (const char *e = getenv("MT_DEBUG_POOL_BELOW")) per_wave = (float)atof(e);
+    const float per_wave = (float)s->tune.v[MT_TUNE_POOL_BELOW];
     // ... and the first frame of a geometry: without measured costs the order
     // of the work is a guess, and the pool's short pixel chains forgive a bad
-    // guess (12 ms against the state machine's 14.5 on the 1080p frame)
-    engine = (!have_costs || (float)P.n_items < per_wave * (float)waves) ? 2 : 1;
+    // guess (12 ms against the state machine's 14.5 on the 1080p frame).
+    // The state machine has no limit on lights or scratch: it takes what the pool cannot hold.
+    engine = (pool_fits && pool_roomy && (!have_costs || (float)P.n_items < per_wave * (float)waves)) ? 2 : 1;
+  }
+  if (engine == 2 && !pool_fits) {
+    return fail(MT_ERR_UNSUPPORTED, "the ray pool (engine 2) holds at most %d lights within its scratch budget; "
+                "%d were set -- engine 0 (automatic) or 1 renders such scenes", kPoolMaxLights, n_l);
   }
   const bool pool_engine = engine == 2;
   const bool history = have_costs && (pool_engine || d_debug == nullptr);
@@ -300,36 +332,19 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   P.item_forecast = s->d_item_forecast;
   P.item_whole = s->d_item_forms;
   P.item_qsum = s->d_item_forms + P.n_items;
-  if (getenv("MT_DEBUG_NO_FORMS")) P.item_whole = P.item_qsum = nullptr;
+  if (s->tune.v[MT_TUNE_FORMS] == 0.0) P.item_whole = P.item_qsum = nullptr;
   P.order_item = s->d_order_item;
   P.order_sub = s->d_order_sub;
   P.n_work = s->d_work + 7;
   if (pool_engine) {
-    // Ray pool: records per wave.  64 * (2^(max_depth+1) - 1) is every call of
-    // every pixel's recursion tree at once; beyond kPoolCapMax the kernel's
-    // throttle keeps the pool within the capacity (depth first).
-    const int n_l = s->dev.n_lights;
-    if (n_l > 254) return fail(MT_ERR_UNSUPPORTED, "%d lights: the ray pool addresses at most 254", n_l);
-    constexpr long long kPoolCapMax = 1024;
-    const long long all = 64ll * ((2ll << max_depth) - 1);
-    const long long floor_cap = 64 + 128 + 4ll * (max_depth + 1) + 64;
-    long long cap = all < kPoolCapMax ? all : kPoolCapMax;
-    if (const char *e = getenv("MT_DEBUG_POOL_CAP")) cap = atoll(e);  // tests: force the depth-first throttle
-    if (cap < floor_cap) cap = floor_cap;
-    const size_t rec_bytes = (size_t)(kRecFixed + kLightSlot * n_l) * sizeof(double);
-    size_t stride = (size_t)cap * rec_bytes + (size_t)cap * (size_t)(n_l > 0 ? n_l : 1) * 4 + (size_t)cap * 4;
-    stride = (stride + 255) & ~(size_t)255;
-    int rc = ensure_bytes((void **)&s->d_pool, &s->pool_bytes, stride * waves);
+    int rc = ensure_bytes((void **)&s->d_pool, &s->pool_bytes, pool_stride * waves);
     if (rc != MT_OK) return rc;
     P.pool_scratch = s->d_pool;
-    P.pool_stride = stride;
-    P.pool_cap = (int)cap;
+    P.pool_stride = pool_stride;
+    P.pool_cap = (int)pool_cap;
     P.prio_units = (unsigned)(s->n_cu * 4);  // one per SIMD
   } else {
     size_t fbytes = waves * ((size_t)(max_depth > 0 ? max_depth : 1) * kFrameSlots + kParkSlots) * 64 * sizeof(double);
-#if MT_DUP == 7
-    fbytes += waves * 100 * 64 * sizeof(unsigned);  // the spill-traffic experiment's buffer, behind the frames
-#endif
     const size_t slots_px = (size_t)n_tiles * (size_t)tile_w * (size_t)tile_h;
     int rc = ensure_bytes((void **)&s->d_frames, &s->frames_bytes, fbytes);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_hit_prim, &s->hit_prim_bytes, slots_px * sizeof(int32_t));
@@ -347,7 +362,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   }
   P.item_cycles = nullptr;
   unsigned long long *d_item = nullptr;
-  const char *item_dump = getenv("MT_DEBUG_ITEM_CYCLES");
+  const char *item_dump = s->dbg_item_cycles.empty() ? nullptr : s->dbg_item_cycles.c_str();
   if (item_dump && P.n_items > 0) {
     HIP_TRY(hipMalloc((void **)&d_item, (size_t)P.n_items * 16 * 16 * 3));
     HIP_TRY(hipMemset(d_item, 0, (size_t)P.n_items * 16 * 16 * 3));
@@ -356,9 +371,6 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   HIP_TRY(hipMemsetAsync(s->d_work, 0, 8 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
-#ifdef MT_DEG_MAPS
-  if (int rc_deg = refresh_degenerate_maps(s, sensor, stream)) return rc_deg;
-#endif
   HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
   // events: [0] -> [1] forecast / classification + work order; [1] -> [2] the frame kernel
   hipEvent_t *ek = s->ev_k[s->launches_timed % mt_scene::kTimedLaunches];
@@ -373,15 +385,14 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {
     reproject = 1;
     radius = memcmp(s->cost_sensor.origin, sensor->origin, sizeof sensor->origin) != 0 ? 2 : 1;
-    if (const char *e = getenv("MT_DEBUG_FORECAST_RADIUS")) radius = atoi(e);
+    if (s->tune.v[MT_TUNE_FORECAST_RADIUS] >= 0.0) radius = (int)s->tune.v[MT_TUNE_FORECAST_RADIUS];
   }
   if (history && !reproject && s->forecasts_in_a_row > 0) {
     // swept (scripts/blend_sweep.py, state machine, 64 frames): 0 -> every other frame 6 % slower (mean 7.09 ms), 0.5 -> one
     // in three (7.03), 0.9 -> one in eight (7.01); a frozen forecast (1.0) repeats its frame time to 0.2 % (scripts/alternation.py)
     // (a running mean of the measurements first -- 1/2, 2/3, ... -- so that the first frames' costs, measured under a
     // guessed order, do not linger)
-    float cap = 0.9f;
-    if (const char *e = getenv("MT_DEBUG_BLEND")) cap = (float)atof(e);
+    const float cap = (float)s->tune.v[MT_TUNE_BLEND];
     blend = std::min(cap, (float)s->forecasts_in_a_row / (float)(s->forecasts_in_a_row + 1));
   }
   // (the two measurements of a block belong to ONE camera, geometry and set of lights)
@@ -396,12 +407,12 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       HIP_TRY(hipGetLastError());
     }
     // blocks above cut_share of an even split of the frame are handed out in pieces
-    SchedParams sp{history ? 1.0f : 0.3f, {1.0f, 0.35f, 0.12f}, {1.0f, 1.1f, 3.0f}, 3.0f,
+    const double *tv = s->tune.v;
+    SchedParams sp{history ? 1.0f : 0.3f, {1.0f, (float)tv[MT_TUNE_POOL_PIECE_TIME1], (float)tv[MT_TUNE_POOL_PIECE_TIME2]},
+                   {1.0f, (float)tv[MT_TUNE_POOL_PIECE_WORK1], (float)tv[MT_TUNE_POOL_PIECE_WORK2]},
+                   (float)tv[MT_TUNE_POOL_CELL_FACTOR],
                    (!history || s->last_engine == 2) ? 1 : 0};  // a forecast is cut more eagerly
-    if (const char *e = getenv("MT_DEBUG_CUT_SHARE")) sp.cut_share = (float)atof(e);
-    if (const char *e = getenv("MT_DEBUG_PIECE_TIME")) sscanf(e, "%f,%f", &sp.piece_time[1], &sp.piece_time[2]);
-    if (const char *e = getenv("MT_DEBUG_PIECE_WORK")) sscanf(e, "%f,%f", &sp.piece_work[1], &sp.piece_work[2]);
-    if (const char *e = getenv("MT_DEBUG_CELL_FACTOR")) sp.cell_factor = (float)atof(e);
+    if (tv[MT_TUNE_POOL_CUT_SHARE] >= 0.0) sp.cut_share = (float)tv[MT_TUNE_POOL_CUT_SHARE];
     hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
                        reproject, radius, (history && s->last_engine == 1) ? 0 : 1,
                        (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u, blend);
@@ -421,13 +432,12 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       // 0.6 / 0.8 / 1.0 -> 7.18 / 6.84 / 7.28 ms, moving camera 6.69 / 7.20 / 9.89; with work 1.5: share 0.7 -> 6.40)
       // (with the per-block ratio of the two forms' costs -- forecast_kernel -- the repeated frame no longer alternates,
       // and re-swept: 0.8 / 0.9 / 0.95 / 1.0 / 1.05 / 1.1 -> 6.67 / 6.49 / 6.47 / 6.46 / 6.56 / 6.93 ms)
-      float quad_share = reproject ? 0.7f : 0.95f;
-      if (const char *e = getenv(reproject ? "MT_DEBUG_QUAD_SHARE_MOVING" : "MT_DEBUG_QUAD_SHARE")) quad_share = (float)atof(e);
-      float quad_keep = 1.0f;   // ... and stay so above this fraction of that threshold (1 = no hysteresis: swept, scripts/quad_sweep.py --
-                                // settings that steady the repeated frame cost the moving camera 50 %)
-      if (const char *e = getenv("MT_DEBUG_QUAD_KEEP")) quad_keep = (float)atof(e);
-      float quad_work = reproject ? 1.5f : 1.7f;   // work of a block rendered as quarters / rendered whole (swept with the share)
-      if (const char *e = getenv("MT_DEBUG_QUAD_WORK")) quad_work = (float)atof(e);
+      const float quad_share = (float)s->tune.v[reproject ? MT_TUNE_QUAD_SHARE_MOVING : MT_TUNE_QUAD_SHARE];  // 0.7 / 0.95
+      // ... and stay so above this fraction of that threshold (1 = no hysteresis: swept, scripts/quad_sweep.py --
+      // settings that steady the repeated frame cost the moving camera 50 %)
+      const float quad_keep = (float)s->tune.v[MT_TUNE_QUAD_KEEP];
+      // work of a block rendered as quarters / rendered whole (swept with the share): 1.5 / 1.7
+      const float quad_work = (float)s->tune.v[reproject ? MT_TUNE_QUAD_WORK_MOVING : MT_TUNE_QUAD_WORK];
       hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
                          reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f, 16000u, blend);
       hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
@@ -451,8 +461,8 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   s->cost_signature = sig;  // the costs now in d_item_cost belong to this geometry and engine
   s->last_engine = engine;
   s->cost_sensor = *sensor;
-  if (const char *e = getenv("MT_DEBUG_PRINT_UNITS")) {  // debug: how many work units did the order have?
-    if (atoi(e) == 2) {  // without synchronising: kept in a ring, printed every 16th launch
+  if (s->dbg_print_units) {  // -DMT_DEBUG_KNOBS: how many work units did the order have?
+    if (s->dbg_print_units == 2) {  // without synchronising: kept in a ring, printed every 16th launch
       static unsigned *ring = nullptr;
       static unsigned long long n = 0;
       if (!ring) HIP_TRY(hipMalloc((void **)&ring, 16 * sizeof(unsigned)));
@@ -554,10 +564,6 @@ void mt_scene_destroy(mt_scene *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   for (void *p : s->allocs) (void)hipFree(p);
-  for (int i = 0; i < 4; i++) {
-    if (s->deg_stage[i]) (void)hipHostFree(s->deg_stage[i]);
-    if (s->deg_stage_done[i]) (void)hipEventDestroy(s->deg_stage_done[i]);
-  }
   if (s->d_pool) (void)hipFree(s->d_pool);
   if (s->d_frames) (void)hipFree(s->d_frames);
   if (s->d_hit_prim) (void)hipFree(s->d_hit_prim);
@@ -571,6 +577,11 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_rgb) (void)hipFree(s->d_rgb);
   if (s->d_debug) (void)hipFree(s->d_debug);
   if (s->d_lights) (void)hipFree(s->d_lights);
+  if (s->d_multi_tiles) (void)hipFree(s->d_multi_tiles);
+  if (s->d_multi_gather) (void)hipFree(s->d_multi_gather);
+  if (s->d_multi_frame) (void)hipFree(s->d_multi_frame);
+  if (s->multi_stream) (void)hipStreamDestroy(s->multi_stream);
+  if (s->multi_done) (void)hipEventDestroy(s->multi_done);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   for (auto &tri : s->ev_k) {
@@ -849,41 +860,6 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   s->dev.tree_depth = max_depth;
   s->dev.force_mode = 0;
   s->dev.scene_regular = regular ? 1 : 0;
-  // Index for rays with one zero direction component (DevScene::deg_*, refresh_degenerate_maps; -DMT_DEG_MAPS).
-  for (int a = 0; a < 3; a++) s->dev.deg_c[a] = std::numeric_limits<double>::quiet_NaN();
-#ifdef MT_DEG_MAPS
-  {
-    s->node_parent.assign((size_t)nn, -1);
-    s->tri_node.assign(nt, 0);
-    for (int i = 0; i < nn; i++) {
-      const NodeRec &r = recs[i];
-      if (r.first_child != 0) {
-        for (int c = 0; c < 8; c++) s->node_parent[(size_t)r.first_child + c] = i;
-      }
-      for (int t = r.prim_begin; t < r.prim_begin + r.prim_count; t++) s->tri_node[(size_t)t] = i;
-    }
-    for (int a = 0; a < 3; a++) {
-      auto &ix = s->plane_index[a];
-      ix.clear();
-      ix.reserve(nt * 2);
-      for (size_t t = 0; t < nt; t++) {
-        ix.emplace_back(d->tri_aabb[t * 6 + a], (int32_t)t);
-        ix.emplace_back(d->tri_aabb[t * 6 + 3 + a], (int32_t)t);
-      }
-      std::sort(ix.begin(), ix.end());
-    }
-    s->deg_blk_words = (nt / kGroupTris + 1 + 31) / 32;
-    s->deg_node_words = ((size_t)nn + 31) / 32;
-    HIP_TRY(hipMalloc((void **)&s->d_deg_maps, 3 * (s->deg_blk_words + s->deg_node_words) * sizeof(uint32_t)));
-    s->allocs.push_back(s->d_deg_maps);
-    for (int a = 0; a < 3; a++) {
-      s->dev.deg_dirty_blocks[a] = s->d_deg_maps + (size_t)a * s->deg_blk_words;
-      s->dev.deg_dirty_nodes[a] = s->d_deg_maps + 3 * s->deg_blk_words + (size_t)a * s->deg_node_words;
-      s->dev.deg_c[a] = std::numeric_limits<double>::quiet_NaN();
-    }
-    s->deg_valid = false;
-  }
-#endif
   {
     // 16-byte traversal stack frames when "first child" and "best triangle + 1"
     // share one word: a quarter less LDS per wave
@@ -891,7 +867,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     while (tri_bits < 31 && ((long long)d->n_tris + 1) > (1ll << tri_bits)) tri_bits++;
     int node_bits = 1;
     while (node_bits < 31 && (long long)nn > (1ll << node_bits)) node_bits++;
-    s->dev.pack_shift = (tri_bits + node_bits <= 32 && !getenv("MT_DEBUG_NO_PACKED_STACK")) ? tri_bits : 0;
+    s->dev.pack_shift = (tri_bits + node_bits <= 32) ? tri_bits : 0;  // (MT_TUNE_PACKED_STACK = 0 switches it off)
   }
   s->dev.n_lights = 0;
   s->dev.lights = nullptr;
@@ -915,7 +891,15 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   HIP_TRY(hipMemset(s->d_prof, 0, (PROF_COUNT + 1 + kProfTimeline) * sizeof(unsigned long long)));
   s->dev.prof = s->d_prof;
 #endif
-  if (getenv("MT_DEBUG_HEARTBEAT")) {
+#ifdef MT_DEBUG_KNOBS
+  if (const char *e = getenv("MT_DEBUG_ITEM_CYCLES")) s->dbg_item_cycles = e;
+  if (const char *e = getenv("MT_DEBUG_TIMELINE")) s->dbg_timeline = e;
+  if (const char *e = getenv("MT_DEBUG_PRINT_UNITS")) s->dbg_print_units = atoi(e);
+  const bool heartbeat = getenv("MT_DEBUG_HEARTBEAT") != nullptr;
+#else
+  const bool heartbeat = false;
+#endif
+  if (heartbeat) {
     HIP_TRY(hipHostMalloc((void **)&s->hb_host, 65536 * sizeof(unsigned long long), hipHostMallocMapped));
     memset(s->hb_host, 0, 65536 * sizeof(unsigned long long));
     void *dp = nullptr;
@@ -931,6 +915,7 @@ mt_scene *mt_scene_create(const mt_scene_desc *d) {
     return nullptr;
   }
   mt_scene *s = new mt_scene();
+  s->engine = g_default_engine.load();
   if (scene_create_impl(s, d) != MT_OK) {
     mt_scene_destroy(s);
     return nullptr;
@@ -985,6 +970,30 @@ int mt_scene_set_engine(mt_scene *s, int engine) {
   return MT_OK;
 }
 
+int mt_set_default_engine(int engine) {
+  if (engine < 0 || engine > 2) return fail(MT_ERR_ARG, "engine must be 0 (automatic), 1 or 2");
+  g_default_engine.store(engine);
+  return MT_OK;
+}
+
+int mt_scene_set_tuning(mt_scene *s, int knob, double value) {
+  if (!s || knob < 0 || knob >= MT_TUNE_COUNT || !(value == value)) return fail(MT_ERR_ARG, "bad tuning argument");
+  s->tune.v[knob] = value;
+  s->cost_signature = 0;  // other constants, other order: start from a first frame
+  if (knob == MT_TUNE_PACKED_STACK || knob == MT_TUNE_BLOCKS_PER_CU) {
+    if (knob == MT_TUNE_PACKED_STACK) {
+      int tri_bits = 1;
+      while (tri_bits < 31 && ((long long)s->dev.n_tris + 1) > (1ll << tri_bits)) tri_bits++;
+      int node_bits = 1;
+      while (node_bits < 31 && (long long)s->dev.n_nodes > (1ll << node_bits)) node_bits++;
+      s->dev.pack_shift = (value != 0.0 && tri_bits + node_bits <= 32) ? tri_bits : 0;
+    }
+    HIP_TRY(hipSetDevice(s->device));
+    return configure_launch(s);
+  }
+  return MT_OK;
+}
+
 int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
   if (!s || !st) return fail(MT_ERR_ARG, "NULL argument");
   HIP_TRY(hipSetDevice(s->device));
@@ -998,7 +1007,7 @@ int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
     unsigned long long pr[PROF_COUNT];
     HIP_TRY(hipMemcpy(pr, s->d_prof, sizeof pr, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemset(s->d_prof, 0, sizeof pr));
-    if (const char *tl = getenv("MT_DEBUG_TIMELINE")) {  // dump and reset the time line
+    if (const char *tl = s->dbg_timeline.empty() ? nullptr : s->dbg_timeline.c_str()) {  // dump and reset the time line
       std::vector<unsigned long long> host(1 + kProfTimeline);
       HIP_TRY(hipMemcpy(host.data(), s->d_prof + PROF_COUNT, host.size() * 8, hipMemcpyDeviceToHost));
       HIP_TRY(hipMemset(s->d_prof + PROF_COUNT, 0, host.size() * 8));
@@ -1142,6 +1151,135 @@ int mt_render_chunk(mt_scene *s, const mt_sensor *sensor, int image_w, int image
     stats->kernel_ms = ms;
     stats->total_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+  }
+  return MT_OK;
+}
+
+// ---- one frame on several GPUs of this process (main_net_master.cc:195-236) --------------------------
+// Replica r renders tiles r, r + n, ... into its own tile buffer on its own device and stream (the launches are
+// made from one host thread per replica, so that no device waits for another's launch calls); the first replica's
+// stream then waits for each replica's event, pulls its buffer over xGMI (hipMemcpyPeerAsync; the buffers of
+// replicas on the SAME device are read in place) and blits it into the frame; one D2H copy ends the call.
+int mt_render_frame_multi(mt_scene *const *scenes, int n, const mt_sensor *sensor, int image_w, int image_h,
+                          int tile_w, int tile_h, int max_depth, uint8_t *out_rgb, mt_stats *stats) {
+  if (!scenes || n < 1 || n > 1024) return fail(MT_ERR_ARG, "bad scene list");
+  for (int r = 0; r < n; r++) {
+    if (!scenes[r]) return fail(MT_ERR_ARG, "scenes[%d] is NULL", r);
+    for (int q = 0; q < r; q++) {
+      if (scenes[q] == scenes[r]) return fail(MT_ERR_ARG, "scenes[%d] and scenes[%d] are the same replica", q, r);
+    }
+  }
+  if (!out_rgb) return fail(MT_ERR_ARG, "out_rgb is NULL");
+  int rc = check_image_args(scenes[0], sensor, image_w, image_h);
+  if (rc != MT_OK) return rc;
+  if (tile_w <= 0 || tile_h <= 0) return fail(MT_ERR_ARG, "bad tile size");
+  const auto w0 = std::chrono::steady_clock::now();
+  const long long tiles_total = (long long)((image_w + tile_w - 1) / tile_w) * ((image_h + tile_h - 1) / tile_h);
+  const size_t slot = (size_t)tile_w * tile_h * 3;
+  const long long n_max = (tiles_total + n - 1) / n;
+  auto tiles_of = [&](int r) -> int { return r >= tiles_total ? 0 : (int)((tiles_total - r + n - 1) / n); };
+  mt_scene *root = scenes[0];
+
+  // ---- phase 1: every replica renders its tiles
+  std::vector<int> rcs((size_t)n, MT_OK);
+  std::vector<std::string> errs((size_t)n);
+  auto launch_one = [&](int r) {
+    mt_scene *s = scenes[r];
+    auto body = [&]() -> int {
+      HIP_TRY(hipSetDevice(s->device));
+      if (!s->multi_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&s->multi_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&s->multi_done, hipEventDisableTiming));
+      }
+      int rc2 = ensure_bytes((void **)&s->d_multi_tiles, &s->multi_tiles_bytes, (size_t)n_max * slot);
+      if (rc2 != MT_OK) return rc2;
+      if (stats) HIP_TRY(hipMemsetAsync(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long), s->multi_stream));
+      const bool counters_were = s->stats_enabled;
+      if (stats) s->stats_enabled = true;
+      rc2 = launch_render(s, sensor, image_w, image_h, 0, 0, image_w, image_h, tile_w, tile_h, r, n, tiles_of(r),
+                          max_depth, s->d_multi_tiles, nullptr, s->multi_stream);
+      s->stats_enabled = counters_were;
+      if (rc2 != MT_OK) return rc2;
+      HIP_TRY(hipEventRecord(s->multi_done, s->multi_stream));
+      return MT_OK;
+    };
+    rcs[(size_t)r] = body();
+    if (rcs[(size_t)r] != MT_OK) errs[(size_t)r] = g_err;  // (thread-local text: hand it to the caller's thread)
+  };
+  if (n == 1) {
+    launch_one(0);
+  } else {
+    std::vector<std::thread> th;
+    th.reserve((size_t)n);
+    for (int r = 0; r < n; r++) th.emplace_back(launch_one, r);
+    for (auto &t : th) t.join();
+  }
+  for (int r = 0; r < n; r++) {
+    if (rcs[(size_t)r] != MT_OK) {
+      for (int q = 0; q < n; q++) {  // let whatever was launched finish before the buffers are touched again
+        if (scenes[q]->multi_stream) {
+          (void)hipSetDevice(scenes[q]->device);
+          (void)hipStreamSynchronize(scenes[q]->multi_stream);
+        }
+      }
+      return fail(rcs[(size_t)r], "replica %d: %s", r, errs[(size_t)r].c_str());
+    }
+  }
+
+  // ---- phase 2: gather on the first replica's device, blit, one copy to the host
+  HIP_TRY(hipSetDevice(root->device));
+  if ((rc = ensure_bytes((void **)&root->d_multi_frame, &root->multi_frame_bytes, (size_t)image_w * image_h * 3)) != MT_OK) return rc;
+  if ((rc = ensure_bytes((void **)&root->d_multi_gather, &root->multi_gather_bytes, (size_t)n * (size_t)n_max * slot)) != MT_OK) return rc;
+  for (int r = 0; r < n; r++) {
+    mt_scene *s = scenes[r];
+    const int n_r = tiles_of(r);
+    if (n_r == 0) continue;
+    if (r != 0) HIP_TRY(hipStreamWaitEvent(root->multi_stream, s->multi_done, 0));
+    const uint8_t *src = s->d_multi_tiles;
+    if (s->device != root->device) {
+      {  // direct xGMI reads where the platform offers them (once per pair; the copy works without, staged)
+        static std::mutex mu;
+        static std::map<std::pair<int, int>, bool> tried;
+        std::lock_guard<std::mutex> lock(mu);
+        bool &done = tried[std::make_pair(root->device, s->device)];
+        if (!done) {
+          done = true;
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, root->device, s->device) == hipSuccess && can) {
+            if (hipDeviceEnablePeerAccess(s->device, 0) != hipSuccess) (void)hipGetLastError();  // (already enabled)
+          } else {
+            (void)hipGetLastError();
+          }
+        }
+      }
+      uint8_t *dst = root->d_multi_gather + (size_t)r * (size_t)n_max * slot;
+      HIP_TRY(hipMemcpyPeerAsync(dst, root->device, s->d_multi_tiles, s->device, (size_t)n_r * slot, root->multi_stream));
+      src = dst;
+    }
+    if ((rc = mt_blit_tiles_device(root, image_w, image_h, tile_w, tile_h, r, n, n_r, src, root->d_multi_frame,
+                                   root->multi_stream)) != MT_OK) {
+      return rc;
+    }
+  }
+  HIP_TRY(hipMemcpyAsync(out_rgb, root->d_multi_frame, (size_t)image_w * image_h * 3, hipMemcpyDeviceToHost, root->multi_stream));
+  HIP_TRY(hipStreamSynchronize(root->multi_stream));
+  const double total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+  // every replica's launch has completed (the root's stream waited for their events); its device status and counters
+  for (int r = 0; r < n; r++) {
+    mt_scene *s = scenes[r];
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->multi_stream));
+    unsigned long long c[ST_COUNT];
+    HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    if ((rc = check_status(c)) != MT_OK) return rc;
+    if (stats) {
+      HIP_TRY(hipMemset(s->d_counters, 0, sizeof c));
+      memset(&stats[r], 0, sizeof(mt_stats));
+      fill_stats(c, &stats[r]);
+      double a = 0.0, b = 0.0;
+      if (tiles_of(r) > 0 && mt_scene_kernel_times(s, 1, &a, &b) == 1) stats[r].kernel_ms = a + b;
+      stats[r].total_ms = total_ms;
+    }
   }
   return MT_OK;
 }

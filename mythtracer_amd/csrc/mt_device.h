@@ -98,14 +98,6 @@ struct DevScene {
   const float *sup_aabb32;   // fp32 union box of each run of kSuperBlocks consecutive blocks (long lists)
   const float *sub_aabb32;   // per node: fp32 union box of all triangles in its subtree
   const HsRec *hs_rec;       // per node (hit-set traversal)
-  // Rays with ONE zero direction component whose origin coordinate on that axis is deg_c[axis] (the
-  // camera's origin: a camera that looks along an axis shoots a whole pixel column or row of them): bit b of
-  // deg_dirty_blocks[axis] = block b holds a triangle whose box has a plane EXACTLY at that coordinate, bit n of
-  // deg_dirty_nodes[axis] = node n or a node below it holds one.  Everything else may be culled by the other two
-  // axes for such a ray (mt_trace.h, degenerate_axis).  Refreshed per launch; NaN in deg_c = no maps.
-  const uint32_t *deg_dirty_blocks[3];
-  const uint32_t *deg_dirty_nodes[3];
-  double deg_c[3];
   double bmax[3];            // max |coordinate| of any triangle box, per axis
   const double *tri_vertex;  // 9 per triangle
   const double *tri_normal;  // 9 per triangle
@@ -216,18 +208,13 @@ struct RenderParams {
 // frames for the levels that can hold a node with children, plus two
 // wave-uniform words per level; the old frames share the same bytes.
 constexpr int kHsMaxDepth = 12;    // levels of an octree the hit-set walk takes (LDS: 24-byte frames for all but the leaf level)
-constexpr int kHsLeafLevels = 8;  // ... and up to this many frame levels the short leaf children are staged as well
 __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
   size_t n = (size_t)depth * 64 * (packed ? 16 : 20);
 #ifdef MT_HS
   if (depth <= kHsMaxDepth && depth > 1) {
-    // frames, (node, first child) per level, two staged records (16-byte aligned), per level the nine planes of
-    // the frame's node (80 bytes); trees of up to kHsLeafLevels frame levels also stage the lists of up to eight
-    // short leaf children (384 bytes each) and, with -DMT_HS_LDS_LONG, two blocks of a long list
+    // frames, (node, first child) per level, room for two staged records (16-byte aligned), per level the nine
+    // planes of the frame's node (80 bytes)
     size_t hs = (((size_t)(depth - 1) * (64 * 24 + 8) + 15) & ~(size_t)15) + 2 * sizeof(HsRec) + (size_t)(depth - 1) * 80;
-#if defined(MT_HS_INLINE_LEAVES) || defined(MT_HS_LDS_LONG)
-    if (depth - 1 <= kHsLeafLevels) hs += 8 * 384 + 2 * 384;
-#endif
     if (hs > n) n = hs;
   }
 #endif
@@ -238,9 +225,6 @@ __host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
   size_t n = wave_frames_bytes(depth, packed) + 64 * 24;  // the fp32 boxes of a short list (the counters are in registers)
 #else
   size_t n = wave_frames_bytes(depth, packed) + 5 * 64 * 4;
-#endif
-#ifdef MT_VEC_SCAN
-  n += 64 * 32;  // staging area of the vector-load scan: 64 boxes of 8 floats
 #endif
   return n;
 }

@@ -538,21 +538,6 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
         prim = tracing ? P.hit_prim[px_index] : -1;
         t = tracing ? P.hit_t[px_index] : 0.0;
       } else {
-#if MT_DUP == 6
-        {
-          const TraceOut td = trace_wave<false>(S.self, stk.base, lane, tracing, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
-          asm volatile("" :: "v"(td.prim), "v"(td.t));
-        }
-#endif
-#if MT_DUP == 7
-        // Experiment: doubles the register-spill traffic around the
-        // traversal -- 100 more dwords per lane written before the call and read back
-        // after it, coalesced like the compiler's own spills -- to see what that traffic costs.
-        unsigned *dup_buf = (unsigned *)(P.frames + (size_t)gridDim.x * (blockDim.x >> 6) *
-                                         ((size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots + kParkSlots) * 64) +
-                            (size_t)wave_id * 100 * 64 + lane;
-        for (int q = 0; q < 100; q++) dup_buf[q * 64] = (unsigned)(q + lane) ^ (unsigned)passes;
-#endif
 #ifdef MT_DIAG
         const unsigned long long diag_tt0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -560,13 +545,6 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
 #ifdef MT_DIAG
         asm volatile("" :: "v"(to.prim));
         diag_trace_ticks += __builtin_amdgcn_s_memtime() - diag_tt0;
-#endif
-#if MT_DUP == 7
-        {
-          unsigned acc = 0;
-          for (int q = 0; q < 100; q++) acc += dup_buf[q * 64];
-          asm volatile("" :: "v"(acc));
-        }
 #endif
         add_trace_stats<STATS>(st, to);
         prim = to.prim;

@@ -53,17 +53,6 @@
 namespace mt {
 
 #define MT_CONST __attribute__((address_space(4)))
-#ifndef MT_KNOCK
-// timing experiments of the hit-set walk (scripts/ab_lib.py): 1 = no long-list scans, 7 = no list scans at all (wrong
-// images both), 2 = short lists through the call path, 4 / 5 / 6 = child tests / short-list fp32
-// tests / short-list candidates executed twice, 8 = no cache-warming loads for the candidates, 11 = long lists without per-lane candidates and second-level boxes, 12 = children in index
-// order instead of near to far
-#define MT_KNOCK 0
-#endif
-#ifndef MT_DUP
-#define MT_DUP 0  // diagnostic: execute one section of the traversal twice (timing experiments only)
-#endif
-
 // Per-lane work counters of one traversal (STATS instantiations only).  Default:
 // in LDS behind the stack -- four ds_add per node step instead of live VGPRs.
 // -DMT_HS: in registers (the LDS behind the frames stages node records there;
@@ -548,21 +537,6 @@ __device__ __forceinline__ unsigned degenerate_keep_mask(const float *sub, int a
   return keep;
 }
 
-// ... and when o[a] lies INSIDE a box's range: (lo - o) * inf and (hi - o) * inf are -inf and +inf (in one order or
-// the other), the axis constrains nothing and the other two axes decide -- UNLESS a plane of the box equals o[a]
-// exactly (0 * inf = NaN).  A union box (block, subtree) may therefore be culled by the other two axes when none of
-// its members has a plane at o[a]; the host marks the blocks and subtrees that do, for the camera's origin
-// (DevScene::deg_dirty_*, mt_capi.hip refresh_degenerate_maps), and a ray whose coordinate is not the one the maps
-// were made for keeps the range rule only.  -DMT_DEG_MAPS (off by default: on the benchmark's camera, which stands ON a
-// plane full of box planes, everything such a ray meets is marked and the extra tests cost 1.4 % of the frame; a
-// batch of rays in a plane without box planes gains 4 %).
-__device__ __forceinline__ bool degenerate_known(const MT_CONST DevScene *G, int axis, double o) {
-  return axis >= 0 && o == G->deg_c[axis];  // (NaN = no maps; -0.0 == 0.0, as the host's comparison)
-}
-__device__ __forceinline__ bool degenerate_dirty(const uint32_t *map, int index) {
-  return ((map[index >> 5] >> (index & 31)) & 1u) != 0u;
-}
-
 // Returns false when the filter must not be used for this ray.
 __device__ __forceinline__ bool make_filter32(const DevScene &S, const RayRegs &r, Filter32 &f) {
   const double o[3] = {r.ox, r.oy, r.oz}, iv[3] = {r.ix, r.iy, r.iz};
@@ -570,16 +544,6 @@ __device__ __forceinline__ bool make_filter32(const DevScene &S, const RayRegs &
   bool ok = true;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-#ifdef MT_DEG_MAPS
-    if (__builtin_isinf(iv[k]) && __builtin_fabs(o[k]) <= 0x1p120) {
-      // a zero direction component: this axis never constrains the fp32 interval (the caller applies the
-      // filter to such a ray only where the axis provably does not decide: degenerate_axis below)
-      I[k] = 0.0f;
-      Cn[k] = -3.0e38f;
-      Cf[k] = 3.0e38f;
-      continue;
-    }
-#endif
     const double M = (S.bmax[k] + __builtin_fabs(o[k])) * __builtin_fabs(iv[k]);
     ok = ok && (M <= 0x1p120);  // false for NaN/inf as well
     const double E = M * 0x1p-21 + 0x1p-100;
@@ -635,39 +599,15 @@ __device__ __forceinline__ bool subtree_may_hit(const float *b, const Filter32 &
 }
 
 // keep mask of the eight subtree boxes `sub` (children fc .. fc + 7) for a ray with one zero direction component:
-// the range rule, and -- when the maps were made for this ray's coordinate -- the other two axes for the subtrees
-// that hold no triangle with a plane at that coordinate.
+// the range rule.
 __device__ __forceinline__ unsigned degenerate_children(const DevScene *self, const float *sub, int fc, double ox,
                                                         double oy, double oz, double ix, double iy, double iz) {
   const int axis = degenerate_axis(ox, oy, oz, ix, iy, iz);
   if (axis < 0) return 0xffu;
   const double o = axis == 0 ? ox : (axis == 1 ? oy : oz);
-  unsigned keep = degenerate_keep_mask(sub, axis, o);
-#ifdef MT_DEG_MAPS
-  const MT_CONST DevScene *G = as_const(self);
-  if (keep != 0u && degenerate_known(G, axis, o)) {
-    DevScene B;
-    B.bmax[0] = G->bmax[0]; B.bmax[1] = G->bmax[1]; B.bmax[2] = G->bmax[2];
-    RayRegs r;
-    r.ox = ox; r.oy = oy; r.oz = oz;
-    r.dx = 0.0; r.dy = 0.0; r.dz = 0.0;
-    r.ix = ix; r.iy = iy; r.iz = iz;
-    Filter32 f;
-    if (make_filter32(B, r, f)) {
-      const uint32_t *dn = G->deg_dirty_nodes[axis];
-      const bool sx = __builtin_signbit(ix), sy = __builtin_signbit(iy), sz = __builtin_signbit(iz);
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        if (((keep >> c) & 1u) == 0u) continue;
-        if (!degenerate_dirty(dn, fc + c) && !subtree_may_hit(sub + c * 6, f, sx, sy, sz)) keep &= ~(1u << c);
-      }
-    }
-  }
-#else
   (void)self;
   (void)fc;
-#endif
-  return keep;
+  return degenerate_keep_mask(sub, axis, o);
 }
 
 typedef float f16v __attribute__((ext_vector_type(16)));
@@ -983,14 +923,6 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
     const int fx = 3 - nx, fy = 5 - ny, fz = 7 - nz;
     const int deg_axis = EX ? degenerate_axis(u.ox, u.oy, u.oz, u.ix, u.iy, u.iz) : -1;
     const double deg_o = deg_axis == 0 ? u.ox : (deg_axis == 1 ? u.oy : u.oz);
-#ifdef MT_DEG_MAPS
-    const bool deg_known = EX && S.self != nullptr && degenerate_known(as_const(S.self), deg_axis, deg_o) &&
-                           readlane_f32(f.cnx, L) == readlane_f32(f.cnx, L);  // (a usable filter: no NaN constants)
-    const uint32_t *deg_db = deg_known ? as_const(S.self)->deg_dirty_blocks[deg_axis] : nullptr;
-#else
-    constexpr bool deg_known = false;
-    const uint32_t *deg_db = nullptr;
-#endif
     int ubest = -1;
     double ubest_t = 0.0;
     unsigned mt_count = 0;
@@ -1010,11 +942,9 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
       // EX: an irregular ray -- only the one-zero-component test above applies
       bool may = !(hi < 0.0f) && !(lo > hi);
       if (EX) {
-        // the range rule; and, where the host's maps cover this ray's coordinate, the other two axes (f's third
-        // axis is neutral, make_filter32) for the blocks that hold no triangle with a plane at it
+        // the range rule
         const bool range_ok = !(deg_axis >= 0 && outside_on_axis(bp, deg_axis, deg_o));
-        may = range_ok && (!deg_known || may || degenerate_dirty(deg_db, b0 + (g < nb ? g : nb - 1)));
-        (void)deg_db;
+        may = range_ok;
       }
       unsigned long long live = __builtin_amdgcn_ballot_w64(may && g < nb);
 #ifdef MT_PROF
@@ -1079,11 +1009,6 @@ __device__ __forceinline__ void scan_node_transposed_blocks(const DevScene &S, c
 }
 
 
-#ifdef MT_SORT_ALL_PAIRS
-constexpr bool kSortAnyOnly = false;
-#else
-constexpr bool kSortAnyOnly = true;
-#endif
 // Child slab tests + ordering of the hit children, octtree.cc:204-216.
 // Returns ord (3 bits per entry) | count << 24.
 // keep: bit c clear = child c's subtree provably holds no triangle this ray's
@@ -1098,19 +1023,8 @@ template <int MODE>
 // for the children some lane enters.
 __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, const RayRegs &r,
                                                    unsigned keep = 0xffu, unsigned um = 0xffu,
-                                                   const float *sub = nullptr, const Filter32 *f = nullptr,
-                                                   bool preload = false) {
+                                                   const float *sub = nullptr, const Filter32 *f = nullptr) {
   constexpr bool EX = (MODE == 0);
-  // preload (wave-uniform node, MT_PRELOAD_SUB): the eight subtree boxes are
-  // fetched together up front -- one round trip instead of one per entered child
-  float sbox[48];
-  if constexpr (!EX) {
-    if (preload && sub != nullptr) {
-      const MT_CONST float *sp = as_const(sub);
-#pragma unroll
-      for (int i = 0; i < 48; i++) sbox[i] = sp[i];
-    }
-  }
   double xmin[2], xmax[2], ymin[2], ymax[2], zmin[2], zmax[2];
   {
     const double t0 = (N->lo[0] - r.ox) * r.ix, tc = (N->c[0] - r.ox) * r.ix,
@@ -1150,7 +1064,7 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
     if constexpr (!EX) {
       if (sub != nullptr) {
         if (__ballot(valid[c]) != 0ull) {
-          valid[c] = valid[c] && subtree_may_hit(preload ? sbox + c * 6 : sub + c * 6, *f, __builtin_signbit(r.ix),
+          valid[c] = valid[c] && subtree_may_hit(sub + c * 6, *f, __builtin_signbit(r.ix),
                                                  __builtin_signbit(r.iy), __builtin_signbit(r.iz));
         }
       }
@@ -1181,10 +1095,10 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
     for (int c = 0; c < 8; c++) rank[c] = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-      if (kSortAnyOnly && ((any >> i) & 1u) == 0u) continue;  // wave-uniform
+      if (((any >> i) & 1u) == 0u) continue;  // wave-uniform
 #pragma unroll
       for (int j = i + 1; j < 8; j++) {
-        if (kSortAnyOnly && ((any >> j) & 1u) == 0u) continue;  // wave-uniform
+        if (((any >> j) & 1u) == 0u) continue;  // wave-uniform
         const bool both = valid[i] && valid[j];
         const bool j_first = tm[j] < tm[i];
         rank[i] += (both && j_first) ? 1u : 0u;
@@ -1193,7 +1107,7 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
     }
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-      if (kSortAnyOnly && ((any >> c) & 1u) == 0u) continue;  // wave-uniform
+      if (((any >> c) & 1u) == 0u) continue;  // wave-uniform
       if (valid[c]) {
         ord |= (unsigned)c << (3 * rank[c]);
         cnt++;
@@ -1328,123 +1242,10 @@ __device__ __attribute__((noinline)) ScanOut scan_small_lane_call(const double *
 // (subtree_may_hit, applied inside order_children to the children some lane
 // enters).
 
-// Regular-mode ordering WITH subtree boxes, survivors first.  order_children
-// evaluates all eight children (slab test, subtree test, 28-pair rank sort:
-// ~490 vector instructions), although a ray enters at most four octants and
-// most of those hold nothing it can hit.  Here the cheap conservative test
-// comes first -- the fp32 subtree boxes of the non-empty children -- and the
-// reference's slab arithmetic, validity test and sort (octtree.cc:204-216) run
-// only for the children that survive it, lane by lane: typically one or two.
-// The result is the same list: a child is on it iff its slab test passes
-// (identical products and comparisons as order_children<1>) and its subtree
-// may be hit; the order is by (tmin, child index), which is what the stable
-// sort of a NaN-free key gives.
-__device__ __forceinline__ unsigned order_children_culled(const NodeRec *N, const RayRegs &r, const float *sub,
-                                                          const Filter32 &f, bool uniform_node) {
-  const bool sx = __builtin_signbit(r.ix), sy = __builtin_signbit(r.iy), sz = __builtin_signbit(r.iz);
-  const unsigned cm = (unsigned)(uniform_node ? as_const(uniform_ptr(N))->child_mask : N->child_mask) & 0xffu;
-  // 1. survivors of the subtree test (near / far planes picked by the lane's direction signs)
-  const float *bn_x = sub + (sx ? 3 : 0), *bf_x = sub + (sx ? 0 : 3);
-  const float *bn_y = sub + (sy ? 4 : 1), *bf_y = sub + (sy ? 1 : 4);
-  const float *bn_z = sub + (sz ? 5 : 2), *bf_z = sub + (sz ? 2 : 5);
-  unsigned km = 0u;
-#pragma unroll
-  for (int c = 0; c < 8; c++) {
-    const bool nonempty = ((cm >> c) & 1u) != 0u;
-    if (__ballot(nonempty) == 0ull) continue;  // wave-uniform
-    const float tnx = __builtin_fmaf(bn_x[c * 6], f.ix, f.cnx), tfx = __builtin_fmaf(bf_x[c * 6], f.ix, f.cfx);
-    const float tny = __builtin_fmaf(bn_y[c * 6], f.iy, f.cny), tfy = __builtin_fmaf(bf_y[c * 6], f.iy, f.cfy);
-    const float tnz = __builtin_fmaf(bn_z[c * 6], f.iz, f.cnz), tfz = __builtin_fmaf(bf_z[c * 6], f.iz, f.cfz);
-    const float lo = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
-    const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
-    const bool may = !(hi < 0.0f) && !(lo > hi);  // NaN: keep
-    km |= (nonempty && may) ? (1u << c) : 0u;
-  }
-  if (__ballot(km != 0u) == 0ull) return 0u;
-  // 2. the nine plane distances of NodeIntersectRay, shared by the children (as in order_children)
-  const MT_CONST NodeRec *Nc = as_const(uniform_node ? uniform_ptr(N) : N);
-  double xmin[2], xmax[2], ymin[2], ymax[2], zmin[2], zmax[2];
-  {
-    const double t0 = (Nc->lo[0] - r.ox) * r.ix, tc = (Nc->c[0] - r.ox) * r.ix, t1 = (Nc->hi[0] - r.ox) * r.ix;
-    xmax[0] = __builtin_fmax(t0, tc); xmin[0] = __builtin_fmin(t0, tc);
-    xmax[1] = __builtin_fmax(tc, t1); xmin[1] = __builtin_fmin(tc, t1);
-  }
-  {
-    const double t0 = (Nc->lo[1] - r.oy) * r.iy, tc = (Nc->c[1] - r.oy) * r.iy, t1 = (Nc->hi[1] - r.oy) * r.iy;
-    ymax[0] = __builtin_fmax(t0, tc); ymin[0] = __builtin_fmin(t0, tc);
-    ymax[1] = __builtin_fmax(tc, t1); ymin[1] = __builtin_fmin(tc, t1);
-  }
-  {
-    const double t0 = (Nc->lo[2] - r.oz) * r.iz, tc = (Nc->c[2] - r.oz) * r.iz, t1 = (Nc->hi[2] - r.oz) * r.iz;
-    zmax[0] = __builtin_fmax(t0, tc); zmin[0] = __builtin_fmin(t0, tc);
-    zmax[1] = __builtin_fmax(tc, t1); zmin[1] = __builtin_fmin(tc, t1);
-  }
-  // 3. slab test of each lane's k-th survivor (ascending child index)
-  double st[8];
-  unsigned sc[8];
-  bool sv[8];
-  unsigned work = km;
-  int K = 0;  // wave-uniform: slots in use
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    st[k] = 0.0; sc[k] = 0u; sv[k] = false;
-  }
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    if (__ballot(work != 0u) == 0ull) break;
-    K = k + 1;
-    const bool has = work != 0u;
-    const unsigned c = has ? (unsigned)__builtin_ctz(work) : 0u;
-    work &= work - 1u;
-    const bool xh = (c & 1u) != 0u, zh = (c & 2u) != 0u, yh = (c & 4u) != 0u;  // octtree.cc:61-100
-    const double tmax = __builtin_fmin(__builtin_fmin(xh ? xmax[1] : xmax[0], yh ? ymax[1] : ymax[0]),
-                                       zh ? zmax[1] : zmax[0]);
-    const double tmin = __builtin_fmax(__builtin_fmax(xh ? xmin[1] : xmin[0], yh ? ymin[1] : ymin[0]),
-                                       zh ? zmin[1] : zmin[0]);
-    st[k] = tmin;
-    sc[k] = c;
-    sv[k] = has && (tmax >= 0.0) && (tmin <= tmax);
-  }
-  // 4. rank by (tmin, child index) among the valid slots; slots are in ascending child index
-  unsigned rank[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) rank[k] = 0u;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-#pragma unroll
-    for (int j = i + 1; j < 8; j++) {
-      if (j >= K) continue;  // wave-uniform
-      const bool both = sv[i] && sv[j];
-      const bool j_first = st[j] < st[i];
-      rank[i] += (both && j_first) ? 1u : 0u;
-      rank[j] += (both && !j_first) ? 1u : 0u;
-    }
-  }
-  unsigned ord = 0u, cnt = 0u;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    if (k >= K) continue;  // wave-uniform
-    if (sv[k]) {
-      ord |= sc[k] << (3u * rank[k]);
-      cnt++;
-    }
-  }
-  return (ord & 0x00ffffffu) | (cnt << 24);
-}
-
-#ifdef MT_SURVIVORS_FIRST
-constexpr bool kSurvivorsFirst = true;
-#else
-constexpr bool kSurvivorsFirst = false;  // experimental: slower on whole frames
-#endif
 // Regular-mode ordering, inlined into the traversal; the exact-mode variant
 // below stays a function of its own.
 __device__ __forceinline__ unsigned order_children_regular(const NodeRec *N, const RayRegs &r, const float *sub,
-                                                           const Filter32 &f, bool uniform_node,
-                                                           bool survivors_first) {
-  if (sub != nullptr && survivors_first) {
-    return order_children_culled(N, r, uniform_node ? uniform_ptr(sub) : sub, f, uniform_node);
-  }
+                                                           const Filter32 &f, bool uniform_node) {
   unsigned keep = 0xffu, um = 0xffu;
   if (sub != nullptr) {
     // children with an empty subtree (NodeRec::child_mask) are dropped by the
@@ -1460,11 +1261,6 @@ __device__ __forceinline__ unsigned order_children_regular(const NodeRec *N, con
       }
     }
   }
-#ifdef MT_PRELOAD_SUB
-  if (uniform_node) {
-    return order_children<1>(as_const(uniform_ptr(N)), r, keep, um, sub == nullptr ? nullptr : uniform_ptr(sub), &f, true);
-  }
-#endif
   return order_children<1>(as_const(uniform_node ? uniform_ptr(N) : N), r, keep, um,
                            sub == nullptr ? nullptr : (uniform_node ? uniform_ptr(sub) : sub), &f);
 }
@@ -1768,126 +1564,6 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
 }
 
 
-#ifdef MT_VEC_SCAN
-constexpr bool kVecScan = true;
-#else
-constexpr bool kVecScan = false;  // experimental: slower than the scalar-load scans on whole frames
-#endif
-// ---- big node, ray-parallel, boxes through vector loads -----------------------
-// The scalar-load scans above fetch four boxes per round trip to the scalar
-// cache; a node step was a chain of ~9 dependent round trips and the wave spent
-// most of its time waiting for them.  Here every LANE fetches one box -- lane j
-// the j-th block box of the node, later lane k the k-th triangle box of the live
-// blocks -- so that 64 boxes cost ONE round trip, and the loop then hands box
-// after box to all rays with v_readlane (six per box; the box becomes a scalar
-// operand of the same ten fp32 filter instructions as before).  When the lanes
-// that want the node share a sign octant, every lane swaps its box's planes to
-// (near, far) ONCE, before the loop, so one loop serves all eight octants.
-// Same tests on the same boxes in the same order as scan_grouped_call: block box
-// (may reject all 16 members), fp32 triangle box (conservative), exact fp64 box
-// test, Möller–Trumbore for the survivors in stream order.
-// Must be called by ALL 64 lanes (`in` = lanes that want this node).
-template <bool STATS>
-__device__ __forceinline__ ScanOut scan_big_vec(const DevScene &S, unsigned stage_off, int lane, int pb, int pc, bool in,
-                                                const RayRegs &r, const Filter32 &f, bool one_octant,
-                                                int sx, int sy, int sz) {
-  // The 64 boxes a step works on are STAGED IN LDS (8 floats per box) and read
-  // back with two wave-uniform ds_read_b128 per box: every lane gets the same
-  // box as vector operands -- no v_readlane, no scalar registers.
-  typedef float f4v __attribute__((ext_vector_type(4)));
-  MT_LDS f4v *const stage = (MT_LDS f4v *)(uintptr_t)stage_off;
-  ScanOut o{-1, 0.0, 0u};
-  LaneStats st;
-  st.clear();
-  int pend = -1;
-  unsigned long long pmask = 0ull;  // lanes holding a parked candidate
-  const unsigned long long inmask = __builtin_amdgcn_ballot_w64(in);
-  const unsigned long long me = 1ull << lane;
-  const int b0 = pb / kGroupTris, nb = (pb + pc - 1) / kGroupTris - b0 + 1;
-  const float *gp = S.grp_aabb32 + (size_t)b0 * 6;
-  // fp32 verdict of all rays for the box held by lane j of (n0..f2): planes as
-  // (near xyz, far xyz) when one_octant, else (min xyz, max xyz)
-  auto put = [&](float n0, float n1, float n2, float f0, float f1, float f2) {
-    stage[lane * 2 + 0] = f4v{n0, n1, n2, f0};
-    stage[lane * 2 + 1] = f4v{f1, f2, 0.0f, 0.0f};
-  };
-  auto verdict = [&](int j) -> unsigned long long {
-    const f4v a = stage[j * 2 + 0], c = stage[j * 2 + 1];
-    const float b[6] = {a.x, a.y, a.z, a.w, c.x, c.y};
-    return (one_octant ? filter32_pass<0>(b, f) : filter32_pass<8>(b, f)) & inmask;
-  };
-  for (int g0 = 0; g0 < nb; g0 += 64) {
-    const int n = (nb - g0) < 64 ? (nb - g0) : 64;
-    unsigned long long live = 0ull;
-    {
-      const float *bp = gp + (size_t)(g0 + (lane < n ? lane : n - 1)) * 6;
-      const float x0 = bp[0], y0 = bp[1], z0 = bp[2], x1 = bp[3], y1 = bp[4], z1 = bp[5];
-      const float n0 = (one_octant && sx) ? x1 : x0, f0 = (one_octant && sx) ? x0 : x1;
-      const float n1 = (one_octant && sy) ? y1 : y0, f1 = (one_octant && sy) ? y0 : y1;
-      const float n2 = (one_octant && sz) ? z1 : z0, f2 = (one_octant && sz) ? z0 : z1;
-      put(n0, n1, n2, f0, f1, f2);
-      for (int j = 0; j < n; j++) {
-        if (verdict(j) != 0ull) live |= 1ull << j;
-      }
-    }
-#ifdef MT_PROF
-    o.n_groups += (unsigned)n;
-    o.n_live += (unsigned)__builtin_popcountll(live);
-#endif
-    // the triangles of the live blocks, four blocks (64 triangles) per step
-    while (live != 0ull) {
-      constexpr int kSlices = 64 / kGroupTris;
-      const int slice = lane / kGroupTris;
-      int myq = -1;
-#pragma unroll
-      for (int q = 0; q < kSlices; q++) {
-        if (live != 0ull) {
-          const int blk = g0 + __builtin_ctzll(live);
-          live &= live - 1;
-          if (slice == q) myq = blk;
-        }
-      }
-      const int tri = (b0 + myq) * kGroupTris + (lane % kGroupTris);  // stream position
-      const bool ok = myq >= 0 && tri >= pb && tri < pb + pc;
-      const int tri_c = ok ? tri : pb;
-      const float *bp = S.tri_aabb32 + (size_t)tri_c * 6;
-      const float x0 = bp[0], y0 = bp[1], z0 = bp[2], x1 = bp[3], y1 = bp[4], z1 = bp[5];
-      const float n0 = (one_octant && sx) ? x1 : x0, f0 = (one_octant && sx) ? x0 : x1;
-      const float n1 = (one_octant && sy) ? y1 : y0, f1 = (one_octant && sy) ? y0 : y1;
-      const float n2 = (one_octant && sz) ? z1 : z0, f2 = (one_octant && sz) ? z0 : z1;
-      put(n0, n1, n2, f0, f1, f2);
-      unsigned long long todo = __builtin_amdgcn_ballot_w64(ok);  // ascending lane = ascending stream position
-#ifdef MT_PROF
-      o.n_ranges++;
-      o.n_range_tris += (unsigned)__builtin_popcountll(todo);
-#endif
-      while (todo != 0ull) {
-        const int j = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const unsigned long long m = verdict(j);
-        if (m == 0ull) continue;
-        // exact fp64 test (primitive_triangle.cc:83-108) for the rays the filter let through
-        const int tj = __builtin_amdgcn_readlane(tri_c, j);
-        const MT_CONST double *a = as_const(S.tri_aabb) + (size_t)tj * 6;
-        const double bx[6] = {a[0], a[1], a[2], a[3], a[4], a[5]};
-        const unsigned long long pm = slab_pass<1, 0>(bx, r) & m;
-        if (pm == 0ull) continue;
-        if (pm & pmask) {  // some lane would need a second slot: resolve first
-          flush_candidates<STATS>(S, r, pend, o.best, o.best_t, st);
-          pmask = 0ull;
-        }
-        if ((pm & me) != 0ull) pend = tj;
-        pmask |= pm;
-      }
-    }
-  }
-  if (pmask) flush_candidates<STATS>(S, r, pend, o.best, o.best_t, st);
-  o.mt_tests = st.v[ST_MT_TESTS];
-  o.bytes_v = st.v[ST_BYTES_VECTOR];
-  o.bytes_s = st.bytes_scalar;
-  return o;
-}
-
 template <int MODE, int OCT, bool STATS>
 __device__ __attribute__((noinline)) ScanOut scan_exact_call(const double *b64, const double *vtx, int pb,
                                                              int pc, MT_RAY_PARAMS) {
@@ -1991,10 +1667,11 @@ __device__ __forceinline__ ScanOut scan_octant_dispatch(const DevScene &S, int o
 // (wave-uniform base in M0).  Written as asm because hipcc 7.2 handles the builtin inconsistently: it
 // either waits vmcnt(0) before the NEXT LDS read of any address (which serialises the copy with the
 // work it was meant to overlap) or, across a loop back-edge, not at all.  The waits are explicit at the
-// readers (s_waitcnt vmcnt); M0 is a reserved register the compiler sets anew before each of its own uses.
+// readers (s_waitcnt vmcnt).  M0 is declared clobbered: LLVM uses it for its own LDS-DMA / indirect-index / lane-select
+// sequences and merges or hoists its initialisations across blocks -- an undeclared write could be miscompiled.
 __device__ __forceinline__ void lds_dma16(const char *src, unsigned lds_base) {
   const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(base), "v"(src) : "memory");
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(base), "v"(src) : "memory", "m0");
 }
 
 // One closest-hit query per lane.  Must be called by all 64 lanes of the wave
@@ -2060,8 +1737,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   unsigned cntr[5] = {0u, 0u, 0u, 0u, 0u};
   (void)cntr;
   const int pack_shift = stk.pack_shift;  // wave-uniform
-  const unsigned stage_off = frames_end + 5u * 64u * 4u;  // MT_VEC_SCAN only
-  (void)stage_off;
   if (STATS) {
     MT_CNT_SET(0, 0u); MT_CNT_SET(1, 0u); MT_CNT_SET(2, 0u); MT_CNT_SET(3, 0u);
     MT_CNT_SET(4, 0u);
@@ -2125,15 +1800,13 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   const int szl = __builtin_signbit(r.iz) ? 1 : 0;
 
   // Record of the node a lane has to process next (valid while cur >= 0).
-  int cur_fc = 0, cur_pb = 0, cur_pc = 0, cur_level = 0;
+  int cur_fc = 0, cur_pb = 0, cur_pc = 0;
   auto load_record = [&](int node) {
     const int *q = (const int *)(S.nodes + node) + 18;  // NodeRec: first_child, prim_begin, prim_count, (mask), level
     cur_fc = q[0];
     cur_pb = q[1];
     cur_pc = q[2];
-    cur_level = q[4];  // used by the -DMT_LEVEL_LOOP variant only
   };
-  (void)cur_level;
   if (cur >= 0) load_record(cur);
 
   // The tail of PrimitiveIntersectRay for one node (octtree.cc:199-256): order
@@ -2210,7 +1883,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   const long long step_bound = 64ll * (long long)S.n_nodes + 64;
   long long steps = 0;
 #ifdef MT_DIAG
-  unsigned diag_a_trips = 0, diag_transposed = 0, diag_vec = 0;
+  unsigned diag_a_trips = 0, diag_transposed = 0;
 #endif
 #ifdef MT_HS
   // ---- hit-set traversal (regular rays, automatic mode) ---------------------
@@ -2243,12 +1916,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // wave-uniform per level: the frame's node and its first child, level l in LANE l of a register pair
     // (v_readlane / v_writelane with the level as lane select: no LDS round trip in the walk's bookkeeping)
     int lane_node = 0, lane_fc = 0;
-    const unsigned stage = ((unsigned)(uintptr_t)(h_node + L * 2) + 15u) & ~15u;  // two staged HsRec
+    const unsigned stage = ((unsigned)(uintptr_t)(h_node + L * 2) + 15u) & ~15u;  // the staged HsRec (room for two)
     MT_LDS double *const h_planes = (MT_LDS double *)(uintptr_t)(stage + 2u * (unsigned)sizeof(HsRec));  // [L][10] wave-uniform
     const unsigned tstage = frames_end;                                    // 32 staged fp32 triangle boxes (768 B)
-    const unsigned lstage = (unsigned)(uintptr_t)(h_planes + L * 10);      // the lists of up to 8 short leaf children, 384 B each
-    const unsigned bstage = lstage + 8u * 384u;                            // two blocks (16 boxes each) of a long list (-DMT_HS_LDS_LONG)
-    (void)bstage;
     const char *const hs_bytes = (const char *)S.hs_rec;
 #ifdef MT_PROF
     const bool tl_on = S.prof != nullptr && lane == 0 && stk.base == 0u && __builtin_amdgcn_workgroup_id_x() == 0;
@@ -2270,23 +1940,16 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       if (l < 8) a = (a & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
       else b = (b & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
     };
-#ifdef MT_HS_INLINE_LEAVES
-    const bool leaves_inline = L <= kHsLeafLevels;
-#else
-    // (scanning the short leaf children from the parent's step saves a seventh of the steps and is 0.5 % SLOWER)
-    const bool leaves_inline = false;
-#endif  // (deeper trees: no LDS left for the short leaf children's lists)
     int node = 0;
     unsigned long long m = __ballot(cur == 0);
     int ret_p = -1;
     double ret_t = 0.0;
     int slot = 0;  // child slot the result in ret_* comes from
     bool entering = true;
-    // Records are staged one node ahead: `staged[b]` = node whose record is (being) copied to buffer b.
-    int buf = 0, staged0 = -1, staged1 = -1;
-    auto hs_fetch = [&](int nd, int b) {
-      if (lane < kHsRecLanes) lds_dma16(hs_bytes + (size_t)nd * sizeof(HsRec) + (size_t)lane * 16, stage + (unsigned)b * (unsigned)sizeof(HsRec));
-      if (b == 0) staged0 = nd; else staged1 = nd;
+    // A node's record is copied to LDS when the node is entered (fetching it one node ahead was measured 2 %
+    // slower: the other wave of the SIMD covers the latency, and finding the next node is not free).
+    auto hs_fetch = [&](int nd) {
+      if (lane < kHsRecLanes) lds_dma16(hs_bytes + (size_t)nd * sizeof(HsRec) + (size_t)lane * 16, stage);
     };
     // Children are looked at near to far for the octant of the wave's first ray (child index
     // bits: 0 = x high, 1 = z high, 2 = y high): a candidate found early lets the lanes drop the
@@ -2299,23 +1962,14 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
                         (__builtin_amdgcn_readlane(syl, fl) << 2));
     }
     auto pick = [&](unsigned td) -> int {  // td != 0: the child to look at next
-      if (MT_KNOCK == 12) return __builtin_ctz(td);
       unsigned t = td;
       if (flip & 1u) t = ((t & 0x55u) << 1) | ((t >> 1) & 0x55u);
       if (flip & 2u) t = ((t & 0x33u) << 2) | ((t >> 2) & 0x33u);
       if (flip & 4u) t = ((t & 0x0fu) << 4) | ((t >> 4) & 0x0fu);
       return (int)((unsigned)__builtin_ctz(t) ^ flip);
     };
-    // the node the wave enters after the current one if nothing below it is entered
-    [[maybe_unused]] auto next_after = [&](int l) -> int {
-      for (; l >= 0; l--) {
-        const unsigned td = get8(pendA, pendB, l);
-        if (td != 0u) return __builtin_amdgcn_readlane(lane_fc, l) + pick(td);
-      }
-      return -1;
-    };
     // copies `bytes` (<= 2048, wave-uniform) from src to LDS: one or two LDS-DMA instructions; returns how many
-    [[maybe_unused]] auto dma_range = [&](const char *src, unsigned lds, int bytes) -> int {
+    auto dma_range = [&](const char *src, unsigned lds, int bytes) -> int {
       if (lane * 16 < bytes) lds_dma16(src + (size_t)lane * 16, lds);
       if (bytes > 1024) {
         if (lane * 16 < bytes - 1024) lds_dma16(src + 1024 + (size_t)lane * 16, lds + 1024u);
@@ -2366,7 +2020,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       unsigned warm = 0u;
       {
         unsigned long long w = cand;
-        for (int guard = 0; guard < (MT_KNOCK == 8 ? 0 : 4) && w != 0ull; guard++) {
+        for (int guard = 0; guard < 4 && w != 0ull; guard++) {
           const int k = __builtin_ctzll(w);
           w &= w - 1ull;
           const char *ep = (const char *)(S.tri_aabb + (size_t)(pb_ + k) * 6);
@@ -2476,7 +2130,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       }
     };
     if (m != 0ull) {
-      hs_fetch(0, 0);
+      hs_fetch(0);
       for (;;) {
       if (++steps > step_bound) {
         status = DEV_ERR_TRAVERSAL_BOUND;
@@ -2487,9 +2141,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       lev = uniform_i32(lev);
       node = uniform_i32(node);
       slot = uniform_i32(slot);
-      buf = uniform_i32(buf);
-      staged0 = uniform_i32(staged0);
-      staged1 = uniform_i32(staged1);
       entering = uniform_i32(entering ? 1 : 0) != 0;
       pendA = uniform_u64(pendA);
       pendB = uniform_u64(pendB);
@@ -2498,7 +2149,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         MT_TL(2);  // ENTER
         const bool in = ((m >> lane) & 1ull) != 0ull;
         MT_PROF_BEGIN(prof_t1);
-        if ((buf == 0 ? staged0 : staged1) != node) hs_fetch(node, buf);  // not the node that was foreseen
+        if (node != 0) hs_fetch(node);  // (the root's record was requested before the loop)
         // hipcc 7.2 does not wait for an LDS-DMA before LDS reads through a pointer it cannot
         // trace back to the DMA's destination: the wait is explicit
 #ifdef MT_PROF
@@ -2509,7 +2160,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         MT_PROF_COUNT(PROF_HS_CLOSE_T, __builtin_amdgcn_s_memtime() - tw0);
 #endif
         MT_TL(3);  // record landed
-        const unsigned rec = stage + (unsigned)buf * (unsigned)sizeof(HsRec);
+        const unsigned rec = stage;
         const MT_LDS int *ri = (const MT_LDS int *)(uintptr_t)rec;
         const int fc = uniform_i32(ri[0]), pb = uniform_i32(ri[1]), pc = uniform_i32(ri[2]);
         const unsigned cm = (unsigned)uniform_i32(ri[3]);
@@ -2526,11 +2177,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         // ... and the block boxes of a long list (48 at a time: the counters' bytes hold 53)
         const bool long_list = pc > kHsShortList;
         const int lb0 = pb / kGroupTris, lnb = long_list ? (pb + pc - 1) / kGroupTris - lb0 + 1 : 0;
-#ifdef MT_HS_LDS_LONG
-        if (long_list) dma_range((const char *)S.grp_aabb32 + (size_t)lb0 * 24, tstage, (lnb < 48 ? lnb : 48) * 24);
-#else
         (void)lnb;
-#endif
         if (STATS) {
           st.wave_node_steps++;
           st.wave_tri_steps += (unsigned)pc;
@@ -2558,17 +2205,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
             const bool pass = subtree_may_hit(bxs + c * 6, f32, sxl != 0, syl != 0, szl != 0);
             if (pass) bits |= 1u << c;
           }
-#if MT_KNOCK == 4  // timing experiment: the child tests twice
-          {
-            unsigned bits2 = 0u;
-            asm volatile("" : "+v"(bxs[0]), "+v"(bxs[7]), "+v"(bxs[14]), "+v"(bxs[21]), "+v"(bxs[28]), "+v"(bxs[35]), "+v"(bxs[42]), "+v"(bxs[47]));
-#pragma unroll
-            for (int c = 0; c < 8; c++) {
-              if (subtree_may_hit(bxs + c * 6, f32, sxl != 0, syl != 0, szl != 0)) bits2 |= 1u << c;
-            }
-            asm volatile("" :: "v"(bits2));
-          }
-#endif
           bits = in ? (bits & cm) : 0u;  // (cm: children with an empty subtree hold an inverted box anyway)
 #pragma unroll
           for (int c = 0; c < 8; c++) {
@@ -2576,19 +2212,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           }
         }
         MT_TL(4);  // child tests done
-        // Children that are leaves with a short list are not entered: their boxes are copied to LDS now
-        // (all of them at once, while the own list is scanned) and their lists are scanned from this step.
-        unsigned inl = 0u;
-        int n_leaf_dma = 0;
-        if (any != 0u && leaves_inline) {
-          inl = any & ((unsigned)uniform_i32(ri[78]) & 0xffu);
-          for (unsigned w = inl; w != 0u; w &= w - 1u) {
-            const int c = __builtin_ctz(w);
-            const int kb = uniform_i32(ri[80 + c]);
-            if (lane < 24) lds_dma16((const char *)S.tri_aabb32 + (size_t)kb * 24 + (size_t)lane * 16, lstage + (unsigned)c * 384u);
-            n_leaf_dma++;
-          }
-        }
         // the own list's union box decides who scans it
         bool in_list = false;
         if (pc > 0) {
@@ -2597,49 +2220,19 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           in_list = in && subtree_may_hit(ob, f32, sxl != 0, syl != 0, szl != 0);
         }
         const unsigned long long lm = __ballot(in_list);
-        // -DMT_HS_PREFETCH: stage the record of the node that comes next while this one's list is scanned.
-        // Off by default: measured 2 % SLOWER than fetching a record when its node is entered (the other wave of
-        // the SIMD covers that latency; finding the next node and the second copy in flight are not free).
-        bool fetched_next = false;
-#ifdef MT_HS_PREFETCH
-        {
-          const unsigned step_kids = any & ~inl;
-          const int nxt = step_kids != 0u ? fc + pick(step_kids) : next_after(lev);
-          if (nxt >= 0) {
-            hs_fetch(nxt, buf ^ 1);
-            fetched_next = true;
-          }
-          buf ^= 1;
-        }
-#endif
 #ifdef MT_PROF
         asm volatile("" :: "v"(bits), "s"(any), "s"(lm));
         MT_PROF_END(PROF_HS_KIDS_T, prof_t1);
         MT_PROF_BEGIN(prof_t1);
 #endif
-        MT_TL(5);  // copies issued, next node known
+        MT_TL(5);  // copies issued
         int best = -1;
         double best_t = 0.0;
-        if (small_list && lm != 0ull && MT_KNOCK != 2 && MT_KNOCK != 7) {
-          // the boxes were requested before the next node's record: all but that last copy must have landed
-          wait_vm(n_leaf_dma + (fetched_next ? 1 : 0));
+        if (small_list && lm != 0ull) {
+          wait_vm(0);  // the list's boxes have landed
           unsigned long long cand = in_list ? list_bits(tstage, pc) : 0ull;  // per lane: list positions whose fp32 box the ray may hit
-#if MT_KNOCK == 5  // timing experiment: the fp32 tests of a short list twice
-          {
-            asm volatile("" ::: "memory");
-            const unsigned long long c2 = in_list ? list_bits(tstage, pc) : 0ull;
-            asm volatile("" :: "v"(c2));
-          }
-#endif
           if (STATS) st.bytes_scalar += 24u * (unsigned)pc;
           unsigned mt = 0u, bv = 0u;
-#if MT_KNOCK == 6  // timing experiment: candidates of a short list resolved twice
-          {
-            int b2 = -1; double t2 = 0.0; unsigned m2 = 0u, v2 = 0u;
-            resolve_list(pb, cand, b2, t2, m2, v2);
-            asm volatile("" :: "v"(b2), "v"(t2));
-          }
-#endif
           resolve_list(pb, cand, best, best_t, mt, bv);
           if (status != DEV_OK) break;
           if (STATS) {
@@ -2650,107 +2243,17 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           asm volatile("" :: "v"(best), "v"(best_t));
           MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc);
 #endif
-        } else if (lm != 0ull && MT_KNOCK != 1 && MT_KNOCK != 7) {
+        } else if (lm != 0ull) {
           const unsigned long long mxs = __ballot(in_list && sxl), mys = __ballot(in_list && syl), mzs = __ballot(in_list && szl);
           const bool one_octant = (mxs == 0 || mxs == lm) && (mys == 0 || mys == lm) && (mzs == 0 || mzs == lm);
           const int oct = one_octant ? ((mxs != 0 ? 1 : 0) | (mys != 0 ? 2 : 0) | (mzs != 0 ? 4 : 0)) : 8;
-          const int n_in = __builtin_popcountll(lm);
           const bool blocks_ok = pc > kHsShortList;
-          const int nblk = (pb + pc - 1) / kGroupTris - pb / kGroupTris + 1;
-          // (the triangle-parallel scan of the ordered descent for a handful of lanes: 1.3 % slower here, -DMT_HS_TRANSPOSED)
-#ifdef MT_HS_TRANSPOSED
-          const bool transposed = blocks_ok && (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk);
-#else
-          const bool transposed = false;
-          (void)n_in;
-          (void)nblk;
-#endif
+          // (the triangle-parallel scan of the ordered descent for a handful of lanes was 1.3 % slower here)
           ScanOut o{-1, 0.0, 0u};
-          if (transposed) {
-            o = scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in_list, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
-          }
-#ifndef MT_HS_LDS_LONG  // (default: the long lists go through the scalar-stream scans; the LDS form below is 10 % slower)
-          else if (in_list) {
-            o = scan_filtered_dispatch<STATS, (MT_KNOCK != 11)>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
+          if (in_list) {
+            o = scan_filtered_dispatch<STATS, true>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
             if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
           }
-#else
-          else if (!blocks_ok) {
-            if (in_list) {  // (a short list that took this path: timing experiments only)
-              o = scan_filtered_dispatch<STATS, true>(S, oct, nullptr, pb, pc, r, f32);
-              if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
-            }
-          } else {
-            // Long list from LDS, no call: block boxes (copied while the children were tested) -> per-lane
-            // live bits; every block that is live for some lane: its 16 triangle boxes copied (the next live
-            // block's copy is issued before the current one is looked at), fp32 verdicts, candidates resolved
-            // in list order.  Same tests on the same boxes as scan_grouped_call.
-            (void)oct;
-            unsigned mt = 0u, bv = 0u;
-            for (int c0 = 0; c0 < lnb; c0 += 48) {
-              const int n = lnb - c0 < 48 ? lnb - c0 : 48;
-              if (c0 > 0) {
-                dma_range((const char *)S.grp_aabb32 + (size_t)(lb0 + c0) * 24, tstage, n * 24);
-                wait_vm(0);
-              } else {
-                wait_vm(n_leaf_dma + (fetched_next ? 1 : 0));
-              }
-              if (STATS) st.bytes_scalar += 24u * (unsigned)n;
-              unsigned long long live = 0ull, anyb = 0ull;
-              {
-                typedef float f4v_ __attribute__((ext_vector_type(4)));
-                const MT_LDS f4v_ *t4 = (const MT_LDS f4v_ *)(uintptr_t)tstage;
-                for (int k = 0; k < n; k += 4) {
-                  float tb[24];
-#pragma unroll
-                  for (int i = 0; i < 6; i++) {
-                    const f4v_ q = t4[(k >> 2) * 6 + i];
-                    tb[i * 4 + 0] = q.x; tb[i * 4 + 1] = q.y; tb[i * 4 + 2] = q.z; tb[i * 4 + 3] = q.w;
-                  }
-#pragma unroll
-                  for (int j = 0; j < 4; j++) {
-                    const bool pass = in_list && (k + j < n) && subtree_may_hit(tb + j * 6, f32, sxl != 0, syl != 0, szl != 0);
-                    if (pass) live |= 1ull << (k + j);
-                    if (__ballot(pass) != 0ull) anyb |= 1ull << (k + j);
-                  }
-                }
-              }
-              anyb = uniform_u64(anyb);
-              int nextj = anyb != 0ull ? __builtin_ctzll(anyb) : -1;
-              int bb = 0;
-              auto block_range = [&](int j, int &first, int &cnt) {
-                const int blk = lb0 + c0 + j;
-                first = blk * kGroupTris < pb ? pb : blk * kGroupTris;
-                const int last = blk * kGroupTris + kGroupTris > pb + pc ? pb + pc : blk * kGroupTris + kGroupTris;
-                cnt = last - first;
-              };
-              if (nextj >= 0) {
-                int f0, n0;
-                block_range(nextj, f0, n0);
-                dma_range((const char *)S.tri_aabb32 + (size_t)f0 * 24, bstage, n0 * 24);
-              }
-              for (int guard = 0; nextj >= 0 && guard < 64; guard++) {
-                const int j = nextj;
-                anyb &= anyb - 1ull;
-                nextj = anyb != 0ull ? __builtin_ctzll(anyb) : -1;
-                if (nextj >= 0) {
-                  int f1, n1;
-                  block_range(nextj, f1, n1);
-                  dma_range((const char *)S.tri_aabb32 + (size_t)f1 * 24, bstage + (unsigned)(bb ^ 1) * 384u, n1 * 24);
-                }
-                wait_vm(nextj >= 0 ? 1 : 0);
-                int first, cnt;
-                block_range(j, first, cnt);
-                const unsigned long long cand = ((live >> j) & 1ull) != 0ull ? list_bits(bstage + (unsigned)bb * 384u, cnt) : 0ull;
-                if (STATS) st.bytes_scalar += 24u * (unsigned)cnt;
-                resolve_list(first, cand, o.best, o.best_t, mt, bv);
-                bb ^= 1;
-              }
-            }
-            o.mt_tests = mt;
-            o.bytes_v = bv;
-          }
-#endif
           if (in_list) {
             best = o.best;
             best_t = o.best_t;
@@ -2759,8 +2262,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           }
 #ifdef MT_PROF
           asm volatile("" :: "v"(best), "v"(best_t));
-          if (transposed) { MT_PROF_END(PROF_HS_TRANS_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_TRANS, 1); }
-          else if (blocks_ok) { MT_PROF_END(PROF_HS_BIG_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_BIG, 1); MT_PROF_COUNT(PROF_HS_BIG_TRIS, pc); }
+          if (blocks_ok) { MT_PROF_END(PROF_HS_BIG_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_BIG, 1); MT_PROF_COUNT(PROF_HS_BIG_TRIS, pc); }
           else { MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc); }
 #endif
         } else {
@@ -2787,38 +2289,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         lane_fc = lane == lev ? fc : lane_fc;
         if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + 240u))[lane];
         set8(wantA, wantB, lev, bits);
-        set8(pendA, pendB, lev, any & ~inl);
+        set8(pendA, pendB, lev, any);
         ret_p = -1;  // nothing comes back yet
-        if (inl != 0u) {
-          // the short leaf children, near to far: their lists are in LDS by now (only the next node's
-          // record may still be on its way); each result is offered to the frame as if the wave came back
-          wait_vm(fetched_next ? 1 : 0);
-          unsigned w = inl;
-          while (w != 0u) {
-            const int c = pick(w);
-            w &= ~(1u << c);
-            const bool wants = ((get8(wantA, wantB, lev) >> c) & 1u) != 0u;
-            const int pcc = (int)(((unsigned)uniform_i32(ri[58 + (c >> 2)]) >> (8 * (c & 3))) & 0xffu);
-            const int pbc = uniform_i32(ri[80 + c]);
-            unsigned long long cand = wants ? list_bits(lstage + (unsigned)c * 384u, pcc) : 0ull;
-            int lb = -1;
-            double lt = 0.0;
-            unsigned mt = 0u, bv = 0u;
-            resolve_list(pbc, cand, lb, lt, mt, bv);
-            if (STATS) {
-              st.wave_tri_steps += (unsigned)pcc;  // (wave_node_steps counts the walk's steps: none is taken for this leaf)
-              st.bytes_scalar += 24u * (unsigned)pcc;
-              if (wants) {
-                MT_CNT_ADD(1, 1u);
-                MT_CNT_ADD(2, (unsigned)pcc);
-              }
-              if (mt) MT_CNT_ADD(3, mt);
-              if (bv) MT_CNT_ADD(4, bv);
-            }
-            if (__ballot(lb >= 0) != 0ull) offer(c, lb, lt);
-          }
-        }
-        MT_TL(7);  // frame open, short leaf children done
+        MT_TL(7);  // frame open
       } else {
         MT_TL(8);  // back at a frame
         if (lev < 0) break;  // ret_* is the root's result
@@ -2861,172 +2334,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   }
   if (!hs_done)
 #endif
-  // Main loop.  (A) every lane works through the small nodes on its path by
-  // itself.  (B) When all lanes wait at big nodes, the wave takes the
-  // SHALLOWEST tree level at which some lane waits and scans every distinct
-  // node of that level, each for the lanes that wait at it; then the children
-  // of all those nodes are ordered and all those lanes step on (finish_node)
-  // TOGETHER.  Nodes of one level are disjoint subtrees, so a lane that leaves
-  // one of them can never arrive at another one of the same batch: taking the
-  // whole level at once loses none of the sharing that "lowest-numbered node
-  // first" gives (lanes above still catch up with lanes waiting deeper), but
-  // the ordering/unwind code runs once per level instead of once per node --
-  // with incoherent rays (20..50 distinct big nodes per traversal) that is a
-  // large part of the time.  EXPERIMENTAL (-DMT_LEVEL_LOOP): measured slower
-  // than the node-at-a-time loop below on whole frames.
-#ifdef MT_LEVEL_LOOP
-  {
-  for (;;) {
-    // ---- phase A: every lane works through its own small nodes
-    if (lane_phase) {
-      for (int guard = 0; cur >= 0 && cur_pc < kBigNode; guard++) {
-        if (guard > S.n_nodes) {
-          cur = -2;
-          break;
-        }
-#ifdef MT_DIAG
-        diag_a_trips++;
-#endif
-        const ScanOut o = (use_filter && S.force_mode != 4)
-            ? scan_small_lane_f32_call<STATS>(S.self, cur_pb, cur_pc, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
-            : all_regular
-            ? scan_small_lane_call<false, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz)
-            : scan_small_lane_call<true, STATS>(S.tri_aabb, S.tri_vertex, cur_pb, cur_pc, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, r.ix, r.iy, r.iz);
-        if (STATS) {
-          MT_CNT_ADD(1, 1u);
-          MT_CNT_ADD(2, (unsigned)cur_pc);
-          if (o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
-          if (o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
-        }
-        unsigned ordw = 0;
-        const int fc = cur_fc;
-        if (fc != 0) {
-          if (STATS) MT_CNT_ADD(0, 8u);
-          const NodeRec *Np = S.nodes + cur;
-          const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
-          ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, S.force_mode != 9)
-                             : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                              irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr, S.self, fc);
-        }
-        if (STATS && fc != 0) {  // node planes + record (88 B) and the subtree boxes of the children entered
-          MT_CNT_ADD(4, 88u + 24u * (((ordw >> 24) & 15u) + 1u));
-        }
-        finish_node(fc, ordw, o.best, o.best_t);
-      }
-      if (__ballot(cur == -2) != 0ull) {
-        status = DEV_ERR_UNWIND_BOUND;
-        break;
-      }
-    }
-    // ---- phase B: the big nodes of the shallowest level some lane waits at
-    const int lvl = wave_min_i32(cur >= 0 ? cur_level : 0x7fffffff);
-    if (lvl == 0x7fffffff) break;
-    const bool at = cur >= 0 && cur_level == lvl;
-    int best = -1;
-    double best_t = 0.0;
-    const int my_node = cur, my_fc = cur_fc, my_pb = cur_pb, my_pc = cur_pc;
-    bool pend = at;
-    for (;;) {
-      const int n = wave_min_i32(pend ? my_node : 0x7fffffff);
-      if (n == 0x7fffffff) break;
-      if (++steps > step_bound || n < 0 || n >= S.n_nodes) {
-        status = DEV_ERR_TRAVERSAL_BOUND;
-        break;
-      }
-      const bool in = pend && (my_node == n);
-      pend = pend && !in;
-      const unsigned long long inmask = __ballot(in);
-      const int src = __builtin_ctzll(inmask);
-      const int pb = __builtin_amdgcn_readlane(my_pb, src);
-      const int pc = __builtin_amdgcn_readlane(my_pc, src);
-      if (STATS) {
-        st.wave_node_steps++;
-        st.wave_tri_steps += (unsigned)pc;
-      }
-      // wave-uniform mode choice for this node
-      int mode = 0;
-      int sx = 0, sy = 0, sz = 0;
-      if (all_regular) {
-        mode = 1;
-        if (S.force_mode != 2) {
-          const unsigned long long mxs = __ballot(in && sxl), mys = __ballot(in && syl), mzs = __ballot(in && szl);
-          if ((mxs == 0 || mxs == inmask) && (mys == 0 || mys == inmask) && (mzs == 0 || mzs == inmask)) {
-            mode = 2;
-            sx = mxs != 0; sy = mys != 0; sz = mzs != 0;
-          }
-        }
-      }
-      const int n_in = __builtin_popcountll(inmask);
-      const int chunks = (pc + 63) >> 6;
-      const bool blocks_ok = all_regular && use_filter && pc >= kBigNode && S.force_mode != 6;
-      const int nblk = (pb + pc - 1) / kGroupTris - pb / kGroupTris + 1;
-      const bool blocks_irr = irr_boxes && pc >= kBigNode && n_in <= 16;
-      const bool transposed =
-          (S.force_mode != 3) && pc > 0 &&
-          (blocks_irr ? true
-           : blocks_ok ? (n_in * (160 + 40 * ((nblk + 63) >> 6)) < 200 + 14 * nblk)
-                       : (n_in * (30 + 45 * chunks) < 20 * pc));
-      const bool vec_scan = !transposed && blocks_ok && (mode == 1 || mode == 2) && kVecScan;
-#ifdef MT_DIAG
-      if (transposed) diag_transposed++;
-      if (vec_scan) diag_vec++;
-#endif
-      ScanOut o{-1, 0.0, 0u};
-      if constexpr (kVecScan) {
-        if (vec_scan) o = scan_big_vec<STATS>(S, stage_off, lane, pb, pc, in, r, f32, mode == 2, sx, sy, sz);
-      }
-      if (vec_scan) {
-      } else if (transposed) {
-        if (STATS) st.wave_tri_steps += (unsigned)(n_in * chunks) - (unsigned)pc;  // replaces the pc counted above
-        o = blocks_ok
-            ? scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
-            : blocks_irr
-            ? scan_transposed_blocks_call<true, STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
-            : (mode == 0)
-            ? scan_transposed_call<true, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), MT_RAY_ARGS(r))
-            : scan_transposed_call<false, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, lane, (unsigned)inmask, (unsigned)(inmask >> 32), MT_RAY_ARGS(r));
-      } else if (in) {
-        const int oct = sx | (sy << 1) | (sz << 2);
-        const float *g32 = nullptr;
-        if (pc >= kBigNode && S.force_mode != 6) g32 = S.grp_aabb32;
-        if (mode == 2 && use_filter) o = scan_filtered_dispatch<STATS>(S, oct, g32, pb, pc, r, f32);
-        else if (mode == 1 && use_filter && g32 != nullptr) o = scan_filtered_dispatch<STATS>(S, 8, g32, pb, pc, r, f32);
-        else if (mode == 2) o = scan_octant_dispatch<STATS>(S, oct, pb, pc, r);
-        else if (mode == 1) o = scan_exact_call<1, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
-        else o = scan_exact_call<0, 0, STATS>(S.tri_aabb, S.tri_vertex, pb, pc, MT_RAY_ARGS(r));
-      }
-      if (in) {
-        best = o.best;
-        best_t = o.best_t;
-        if (STATS) {
-          MT_CNT_ADD(1, 1u);
-          MT_CNT_ADD(2, (unsigned)pc);
-          if (o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
-          if (o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
-        }
-      }
-    }
-    if (status != DEV_OK) break;
-    // ---- the children of every node of the batch, then all its lanes step on
-    if (at) {
-      unsigned ordw = 0;
-      if (my_fc != 0) {
-        if (STATS) MT_CNT_ADD(0, 8u);
-        const NodeRec *Np = S.nodes + my_node;
-        const float *sub = cull ? S.sub_aabb32 + (size_t)my_fc * 6 : nullptr;
-        ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, S.force_mode != 9)
-                           : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
-                                                            irr_boxes ? S.sub_aabb32 + (size_t)my_fc * 6 : nullptr, S.self, my_fc);
-      }
-      finish_node(my_fc, ordw, best, best_t);
-    }
-    if (__ballot(cur == -2) != 0ull) {
-      status = DEV_ERR_UNWIND_BOUND;
-      break;
-    }
-  }
-  }
-#else
+  // Main loop of the ordered descent.  (A) every lane works through the small nodes on its path by itself.
+  // (B) When all lanes wait at big nodes, the wave takes the LOWEST-NUMBERED one (breadth-first numbering: the top
+  // of the tree first, so that lanes above catch up with lanes waiting deeper) and scans it for the lanes that wait
+  // at it; its children are ordered and those lanes step on (finish_node).
   {
   for (;;) {
     // ---- phase A: every lane works through its own small nodes
@@ -3075,12 +2386,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
 #ifdef MT_DIAG
         diag_a_trips++;
 #endif
-#if MT_DUP == 2
-        if (use_filter && S.force_mode != 4) {
-          const ScanOut od = scan_small_lane_f32_call<STATS>(S.self, cur_pb, cur_pc, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
-          asm volatile("" :: "v"(od.best), "v"(od.best_t));
-        }
-#endif
         const ScanOut o = (use_filter && S.force_mode != 4)
             ? scan_small_lane_f32_call<STATS>(S.self, cur_pb, cur_pc, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
             : all_regular
@@ -3098,10 +2403,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           if (STATS) MT_CNT_ADD(0, 8u);
           const NodeRec *Np = S.nodes + cur;
           const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
-#if MT_DUP == 1
-          if (all_regular) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, false, kSurvivorsFirst)));
-#endif
-          ordw = all_regular ? order_children_regular(Np, r, sub, f32, false, kSurvivorsFirst)
+          ordw = all_regular ? order_children_regular(Np, r, sub, f32, false)
                              : order_children_exact_lane_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                               irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr, S.self, fc);
         }
@@ -3172,34 +2474,13 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     int best = -1;
     double best_t = 0.0;
     MT_PROF_BEGIN(prof_t1);
-    // regular rays + block boxes: boxes by vector load, one per lane (scan_big_vec)
-    const bool vec_scan = !transposed && blocks_ok && (mode == 1 || mode == 2) && kVecScan;
 #ifdef MT_DIAG
     if (transposed) diag_transposed++;
-    if (vec_scan) diag_vec++;
 #endif
-    if constexpr (kVecScan) if (vec_scan) {
-      const ScanOut o = scan_big_vec<STATS>(S, stage_off, lane, pb, pc, in, r, f32, mode == 2, sx, sy, sz);
-      best = o.best;
-      best_t = o.best_t;
-      if (STATS && in && o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
-#ifdef MT_PROF
-      MT_PROF_COUNT(PROF_G_GROUPS, __builtin_amdgcn_readfirstlane(o.n_groups));
-      MT_PROF_COUNT(PROF_G_LIVE, __builtin_amdgcn_readfirstlane(o.n_live));
-      MT_PROF_COUNT(PROF_G_RANGES, __builtin_amdgcn_readfirstlane(o.n_ranges));
-      MT_PROF_COUNT(PROF_G_RANGE_TRIS, __builtin_amdgcn_readfirstlane(o.n_range_tris));
-#endif
-    }
     if (transposed) {
       MT_PROF_COUNT(PROF_N_TRANSPOSED, 1);
       MT_PROF_COUNT(PROF_N_CHUNKS, n_in * chunks);
       if (STATS) st.wave_tri_steps += (unsigned)(n_in * chunks) - (unsigned)pc;  // replaces the pc counted above
-#if MT_DUP == 4
-      if (blocks_ok) {
-        const ScanOut od = scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32));
-        asm volatile("" :: "v"(od.best), "v"(od.best_t));
-      }
-#endif
       const ScanOut o = blocks_ok
           ? scan_transposed_blocks_call<false, STATS>(S.self, pb, pc, in, MT_RAY_ARGS(r), MT_F32_ARGS(f32))
           : blocks_irr
@@ -3227,7 +2508,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         MT_CNT_ADD(1, 1u);
         MT_CNT_ADD(2, (unsigned)pc);
       }
-      if (!transposed && !vec_scan) {
+      if (!transposed) {
         const int oct = sx | (sy << 1) | (sz << 2);
         ScanOut o;
         const float *g32 = nullptr;
@@ -3235,12 +2516,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (mode == 2 && use_filter) {
 #ifdef MT_PROF
           const unsigned long long tc0 = __builtin_amdgcn_s_memtime();
-#endif
-#if MT_DUP == 3
-          {
-            const ScanOut od = scan_filtered_dispatch<STATS>(S, oct, g32, pb, pc, r, f32);
-            asm volatile("" :: "v"(od.best), "v"(od.best_t));
-          }
 #endif
           o = scan_filtered_dispatch<STATS>(S, oct, g32, pb, pc, r, f32);
 #ifdef MT_PROF
@@ -3285,12 +2560,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (STATS) MT_CNT_ADD(0, 8u);
         const NodeRec *Np = S.nodes + n;
         const float *sub = cull ? S.sub_aabb32 + (size_t)fc * 6 : nullptr;
-#if MT_DUP == 1
-        if (mode != 0) asm volatile("" :: "v"(order_children_regular(Np, r, sub, f32, true, kSurvivorsFirst)));
-#endif
         ordw = (mode == 0) ? order_children_exact_call(Np, r.ox, r.oy, r.oz, r.ix, r.iy, r.iz,
                                                        irr_boxes ? S.sub_aabb32 + (size_t)fc * 6 : nullptr, S.self, fc)
-                           : order_children_regular(Np, r, sub, f32, true, kSurvivorsFirst);
+                           : order_children_regular(Np, r, sub, f32, true);
       }
       if (STATS && fc != 0) st.bytes_scalar += 96u + 24u * 8u;  // node record + the children's subtree boxes, once for the wave
       finish_node(fc, ordw, best, best_t);
@@ -3302,12 +2574,11 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     }
   }
   }
-#endif
 #ifdef MT_DIAG
-  {  // wave-uniform diagnostics packed into wave_tri_steps: A-phase trips (max over lanes) | transposed << 12 | vec << 22
+  {  // wave-uniform diagnostics packed into wave_tri_steps: A-phase trips (max over lanes) | transposed << 12
     unsigned mx = diag_a_trips;
     for (int off = 32; off > 0; off >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
-    st.wave_tri_steps = (mx & 0xfffu) | ((diag_transposed & 0x3ffu) << 12) | ((diag_vec & 0x3ffu) << 22);
+    st.wave_tri_steps = (mx & 0xfffu) | ((diag_transposed & 0x3ffu) << 12);
   }
 #endif
   if (status != DEV_OK) break;

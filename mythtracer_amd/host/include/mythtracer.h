@@ -70,6 +70,11 @@ class MythTracer {
     device_ = hip_device;
     scene.tree.SetDevice(hip_device);
   }
+  // Several GPUs of this process for the W x H overload of RayTrace: a scene replica per listed HIP device
+  // (a device may be listed more than once), tiles k = r (mod N) of the frame rendered side by side, gathered
+  // and blitted on the first device -- mt_render_frame_multi; the master/worker farm of main_net_master.cc:195-236
+  // in one process.  RayTrace(WorkChunk*) -- the unit a worker renders -- stays on the first device.
+  void SetDevices(const std::vector<int>& hip_devices);
   void SetMaxRecursionLevel(int level) { max_level_ = level; }  // default MAX_RECURSION_LEVEL
   void SetQuiet(bool quiet) {                                   // no progress text on stdout
     quiet_ = quiet;
@@ -85,8 +90,11 @@ class MythTracer {
  private:
   Scene scene;
   bool was_scene_finalized = false;
-  mt_scene* dev_ = nullptr;
+  mt_scene* dev_ = nullptr;            // replica on devices_[0] (= device_)
+  std::vector<mt_scene*> replicas_;    // replicas on devices_[1..]
+  std::vector<int> devices_;           // empty = {device_}
   int device_ = 0;
+  void DropDeviceScenes();
   int max_level_ = MAX_RECURSION_LEVEL;
   bool quiet_ = false;
   RenderStats stats_;

@@ -47,6 +47,10 @@ void* mth_new(int device, int quiet) {
 
 void mth_free(void* p) { delete static_cast<Handle*>(p); }
 
+void mth_set_devices(void* p, const int* devices, int n) {
+  static_cast<Handle*>(p)->mt.SetDevices(std::vector<int>(devices, devices + n));
+}
+
 const char* mth_last_error(void* p) {
   Handle* h = static_cast<Handle*>(p);
   h->error = h->mt.LastError();

@@ -17,8 +17,19 @@ namespace raytracer {
 
 MythTracer::MythTracer() {}
 
-MythTracer::~MythTracer() {
+MythTracer::~MythTracer() { DropDeviceScenes(); }
+
+void MythTracer::DropDeviceScenes() {
   if (dev_) mt_scene_destroy(dev_);
+  dev_ = nullptr;
+  for (mt_scene* r : replicas_) mt_scene_destroy(r);
+  replicas_.clear();
+}
+
+void MythTracer::SetDevices(const std::vector<int>& hip_devices) {
+  DropDeviceScenes();  // uploaded again, where they are wanted, by the next Prepare
+  devices_ = hip_devices;
+  if (!devices_.empty()) SetDevice(devices_[0]);
 }
 
 Scene* MythTracer::GetScene() { return &scene; }
@@ -168,10 +179,7 @@ bool MythTracer::Prepare() {
     if (!quiet_) puts("Finalizing tree.");
     scene.tree.Finalize();
     was_scene_finalized = true;
-    if (dev_) {  // geometry changed (LoadObj after a render): upload again
-      mt_scene_destroy(dev_);
-      dev_ = nullptr;
-    }
+    DropDeviceScenes();  // geometry changed (LoadObj after a render): upload again
   }
   if (dev_) return true;
   FlatScene flat;
@@ -179,18 +187,70 @@ bool MythTracer::Prepare() {
     error_ = flat.error;
     return false;
   }
-  const mt_scene_desc d = flat.Describe(scene, device_);
-  dev_ = mt_scene_create(&d);
-  if (dev_ == nullptr) {
-    error_ = mt_last_error();
-    fprintf(stderr, "error: cannot create the device scene: %s\n", error_.c_str());
-    return false;
+  // one replica per listed device: every worker of the reference loads its own copy of the scene
+  // (main_net_worker.cc:29-32)
+  const size_t n = devices_.empty() ? 1 : devices_.size();
+  for (size_t r = 0; r < n; r++) {
+    const mt_scene_desc d = flat.Describe(scene, devices_.empty() ? device_ : devices_[r]);
+    mt_scene* s = mt_scene_create(&d);
+    if (s == nullptr) {
+      error_ = mt_last_error();
+      fprintf(stderr, "error: cannot create the device scene: %s\n", error_.c_str());
+      DropDeviceScenes();
+      return false;
+    }
+    if (r == 0) dev_ = s;
+    else replicas_.push_back(s);
   }
   return true;
 }
 
 bool MythTracer::RayTrace(int image_width, int image_height, Camera* camera,
                           std::vector<uint8_t>* output_bitmap) {
+  if (devices_.size() > 1) {
+    // the whole frame on all listed GPUs (mt_render_frame_multi); 64x64 tiles, finer than the master's 128x128
+    // chunks (main_net_master.cc:24-25): a pixel's cost varies 60-fold across the frame
+    if (!Prepare()) return false;
+    if (!quiet_) puts("Rendering.");
+    const auto t0 = std::chrono::steady_clock::now();
+    std::vector<mt_scene*> all{dev_};
+    all.insert(all.end(), replicas_.begin(), replicas_.end());
+    for (mt_scene* s : all) {
+      if (mt_scene_set_lights(s, reinterpret_cast<const mt_light*>(scene.lights.data()), (int)scene.lights.size()) != MT_OK) {
+        error_ = mt_last_error();
+        return false;
+      }
+    }
+    const Camera::Sensor sensor = camera->GetSensor(image_width, image_height);
+    mt_sensor ms;
+    memcpy(ms.origin, camera->origin.v, 24);
+    memcpy(ms.start_point, sensor.StartPoint().v, 24);
+    memcpy(ms.delta_scanline, sensor.DeltaScanline().v, 24);
+    memcpy(ms.delta_pixel, sensor.DeltaPixel().v, 24);
+    output_bitmap->resize((size_t)image_width * image_height * 3);
+    std::vector<mt_stats> st(all.size());
+    if (mt_render_frame_multi(all.data(), (int)all.size(), &ms, image_width, image_height, 64, 64, max_level_,
+                              output_bitmap->data(), st.data()) != MT_OK) {
+      error_ = mt_last_error();
+      fprintf(stderr, "error: render failed: %s\n", error_.c_str());
+      return false;
+    }
+    stats_ = RenderStats{};
+    for (const mt_stats& q : st) {
+      stats_.rays_primary += q.rays_primary;
+      stats_.rays_secondary += q.rays_secondary;
+      stats_.rays_shadow += q.rays_shadow;
+      stats_.box_tests += q.box_tests;
+      stats_.node_visits += q.node_visits;
+      stats_.tri_tests += q.tri_tests;
+      stats_.mt_tests += q.mt_tests;
+      stats_.shaded_hits += q.shaded_hits;
+      if (q.kernel_ms > stats_.kernel_ms) stats_.kernel_ms = q.kernel_ms;  // the slowest replica
+      stats_.total_ms = q.total_ms;
+    }
+    if (!quiet_) printf("%.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    return true;
+  }
   WorkChunk chunk{image_width, image_height, 0, 0, image_width, image_height, *camera, {}, {}};
   chunk.output_bitmap.resize((size_t)image_width * image_height * 3);
   if (!RayTrace(&chunk)) return false;

@@ -1,6 +1,7 @@
 import os, sys, ctypes, numpy as np, torch
 sys.path.insert(0, "/root/repo")
 import mythtracer_amd as M
+sys.path.insert(0, os.path.join(ROOT, "scripts")); import knobs
 from mythtracer_amd import scenegen as sg, binding
 torch.cuda.init(); torch.zeros(1, device="cuda")
 W, H = 1920, 1080
@@ -18,5 +19,5 @@ def run(tag, n=16):
 run("warm-up"); run("history on")
 abi.set_scheduling(h, False); run("history off (classified)"); run("history off (classified)")
 abi.set_scheduling(h, True); run("history on again"); 
-os.environ["MT_DEBUG_BLEND"] = "1.0"   # forecast frozen after the first two frames
+os.environ["MT_DEBUG_BLEND"] = "1.0"; knobs.from_env(abi, h)   # forecast frozen after the first two frames
 run("forecast frozen (blend 1)"); run("forecast frozen (blend 1)")

@@ -3,6 +3,7 @@ import os, sys, ctypes, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mythtracer_amd as M
+sys.path.insert(0, os.path.join(ROOT, "scripts")); import knobs
 from mythtracer_amd import scenegen as sg, binding
 torch.cuda.init(); torch.zeros(1, device="cuda")
 W, H = 1920, 1080
@@ -13,7 +14,7 @@ abi = M.hip_abi(); h = m.device_scene(); abi.set_lights(h, sg.ROOM_LIGHTS)
 buf = torch.zeros(W * H * 3, dtype=torch.uint8, device="cuda")
 for engine in (1,):
     for blend in (0.8, 0.9, 0.95, 0.98, 1.0):
-        os.environ["MT_DEBUG_BLEND"] = str(blend)
+        os.environ["MT_DEBUG_BLEND"] = str(blend); knobs.from_env(abi, h)
         abi.set_engine(h, engine)  # (forgets the recorded costs)
         abi.set_stats(h, False)
         for _ in range(12):

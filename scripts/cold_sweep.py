@@ -12,7 +12,7 @@ info = sg.write_scene("room", "/tmp/mt_scenes")
 m = M.MythTracer(info["obj"]); abi = M.hip_abi()
 cold = []
 for rep in range(3):
-    h = abi.scene_create(m.flatten()); abi.set_lights(h, sg.ROOM_LIGHTS)
+    h = abi.scene_create(m.flatten()); abi.set_lights(h, sg.ROOM_LIGHTS); sys.path.insert(0, "%s/scripts"); import knobs; knobs.from_env(abi, h)
     cold.append(abi.render_chunk(h, sens, W, H)["stats"]["kernel_ms"])
     abi.scene_destroy(h)
 print("%%s: cold frames %%s" %% (os.environ.get("TAG"), " ".join("%%.2f" %% c for c in cold)), flush=True)

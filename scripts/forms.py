@@ -5,6 +5,7 @@ import os, sys, ctypes, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mythtracer_amd as M
+sys.path.insert(0, os.path.join(ROOT, "scripts")); import knobs
 from mythtracer_amd import scenegen as sg, binding
 torch.cuda.init(); torch.zeros(1, device="cuda")
 W, H = 1920, 1080
@@ -26,6 +27,7 @@ for rep in range(2):
     for off in ("1", ""):
         if off: os.environ["MT_DEBUG_NO_FORMS"] = "1"
         else: os.environ.pop("MT_DEBUG_NO_FORMS", None)
+        knobs.from_env(abi, h)
         t = run(lambda k: sg.ROOM_CAMERA, 32, 64)
         bad = np.nonzero(t > t.min() * 1.03)[0]
         print("ratio %-3s at rest: mean %.3f median %.3f min %.3f max %.3f; frames above min + 3 %%: %d" % ("off" if off else "on", t.mean(), np.median(t), t.min(), t.max(), len(bad)), flush=True)

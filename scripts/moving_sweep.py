@@ -4,6 +4,7 @@ import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mythtracer_amd as M
+sys.path.insert(0, os.path.join(ROOT, "scripts")); import knobs
 from mythtracer_amd import scenegen as sg, binding
 torch.cuda.init(); torch.zeros(1, device="cuda")
 W, H = 1920, 1080
@@ -20,7 +21,7 @@ def frames(cams):
 for rep in range(2):
     for work in ("1.5",):
         for share in sys.argv[1:] or ("0.55", "0.6", "0.65", "0.7", "0.75", "0.8"):
-            os.environ["MT_DEBUG_QUAD_SHARE_MOVING"] = share; os.environ["MT_DEBUG_QUAD_WORK"] = work
+            os.environ["MT_DEBUG_QUAD_SHARE_MOVING"] = share; os.environ["MT_DEBUG_QUAD_WORK"] = work; knobs.from_env(abi, h)
             abi.set_engine(h, 1); abi.set_stats(h, False)
             frames([sg.ROOM_CAMERA] * 6)
             mv = frames([sg.ROOM_CAMERA[:4] + (2.0 * i,) + sg.ROOM_CAMERA[5:] for i in range(1, 37)])

@@ -8,7 +8,7 @@ from mythtracer_amd import scenegen as sg, binding
 W, H = 1920, 1080
 sens = binding.sensor(sg.ROOM_CAMERA, W, H)
 info = sg.write_scene("room", "/tmp/mt_scenes")
-m = M.MythTracer(info["obj"]); abi = M.hip_abi(); h = abi.scene_create(m.flatten()); abi.set_lights(h, sg.ROOM_LIGHTS)
+m = M.MythTracer(info["obj"]); abi = M.hip_abi(); h = abi.scene_create(m.flatten()); abi.set_lights(h, sg.ROOM_LIGHTS); sys.path.insert(0, "%s/scripts"); import knobs; knobs.from_env(abi, h)
 t = [abi.render_chunk(h, sens, W, H)["stats"]["kernel_ms"] for _ in range(8)]
 print("%%s: cold %%.2f warm min %%.3f median %%.3f" %% (os.environ.get("TAG"), t[0], min(t[2:]), float(np.median(t[2:]))))
 ''' % ROOT

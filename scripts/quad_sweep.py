@@ -4,6 +4,7 @@ import os, sys, ctypes, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mythtracer_amd as M
+sys.path.insert(0, os.path.join(ROOT, "scripts")); import knobs
 from mythtracer_amd import scenegen as sg, binding
 torch.cuda.init(); torch.zeros(1, device="cuda")
 W, H = 1920, 1080
@@ -21,6 +22,7 @@ for work in (1.7,) if len(sys.argv) > 1 else (1.5, 1.7, 1.9):
     for share in ([float(x) for x in sys.argv[1:]] or (0.7, 0.8, 0.9)):
         os.environ["MT_DEBUG_QUAD_SHARE"] = str(share); os.environ["MT_DEBUG_QUAD_WORK"] = str(work)
         os.environ["MT_DEBUG_QUAD_SHARE_MOVING"] = str(share - 0.4 if len(sys.argv) > 1 else share)  # (argv: the moving camera 0.4 below)
+        knobs.from_env(abi, h)
         abi.set_engine(h, 1); abi.set_stats(h, False)
         frames([sg.ROOM_CAMERA] * 24)
         t = frames([sg.ROOM_CAMERA] * 32)

@@ -24,3 +24,19 @@ def test_tiles_gather_to_the_single_process_frame(world, size, tile, tmp_path):
     o.set_lights([(50, 90, 50, .3, .3, .3, 1, 1, 1, 1, 1, 1)])
     want = o.render((50, 50, -120, 0, 0, 0, 60), W, H)["rgb"]
     assert np.array_equal(got, want)
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher in the environment (how a
+    driver may start the N-GPU run): the parent -- before it imports torch or
+    touches HIP -- starts torch.distributed.run with 2 ranks as a child process
+    and relays their output and exit code.  There is no GPU here, so every rank
+    ends with "no GPU visible" (exit 3): what is checked is that two ranks were
+    started and that their failure reaches the caller -- not rc 2 from the parent."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 2" in r.stderr
+    assert r.stderr.count("no GPU visible") == 2, r.stderr[-2000:]
+    assert r.returncode not in (0, 2)

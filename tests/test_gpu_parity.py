@@ -34,13 +34,19 @@ def _libs(native_libs):
     assert M.hip_abi().device_count() >= 1, "no GPU visible: the HIP path cannot run"
 
 
-@pytest.fixture(params=["state_machine", "ray_pool"], autouse=True)
-def engine(request, monkeypatch):
+@pytest.fixture(params=["state_machine", "ray_pool", "auto"], autouse=True)
+def engine(request):
     """Every test runs through both frame engines (include/mythtracer_hip.h,
-    mt_scene_set_engine): the per-lane state machine and the per-wave ray pool
-    must give the same pixels, debug buffers and counters."""
-    monkeypatch.setenv("MT_ENGINE", "1" if request.param == "state_machine" else "2")
-    return request.param
+    mt_scene_set_engine) and through the shipping default, the AUTOMATIC choice
+    (probe_kernel first frame, the blocks-per-wave switch, cost words handed from
+    one engine to the other): the per-lane state machine and the per-wave ray
+    pool must give the same pixels, debug buffers and counters.  Selected through
+    the API (mt_set_default_engine: scenes created from now on), not through the
+    environment."""
+    abi = M.hip_abi()
+    abi.set_default_engine({"state_machine": 1, "ray_pool": 2, "auto": 0}[request.param])
+    yield request.param
+    abi.set_default_engine(0)
 
 
 PRUNED = ("box_tests", "node_visits", "tri_tests", "mt_tests")
@@ -675,16 +681,15 @@ def test_filters_stay_conservative_at_extreme_coordinates(scale, offset, scenes,
         assert np.array_equal(g2["rgb"], g["rgb"]) and np.array_equal(g2["line"], g["line"]), mode
 
 
-def test_unpacked_stack_frames(scenes, monkeypatch):
+def test_unpacked_stack_frames(scenes):
     """Scenes whose node and triangle indices do not fit one word together use
     20-byte traversal stack frames instead of 16-byte ones; forced here for a
-    small scene (MT_DEBUG_NO_PACKED_STACK is read when the scene is created)."""
+    small scene (mt_scene_set_tuning, MT_TUNE_PACKED_STACK = 0)."""
     g = load("mini_320x180")
-    monkeypatch.setenv("MT_DEBUG_NO_PACKED_STACK", "1")
     m = M.MythTracer(scenes["mini"])
+    M.hip_abi().set_tuning(m.device_scene(), "PACKED_STACK", 0)
     m.set_lights(scenegen.ROOM_LIGHTS)
     a = m.render(scenegen.ROOM_CAMERA, 320, 180, debug=True)
-    monkeypatch.delenv("MT_DEBUG_NO_PACKED_STACK")
     assert_rgb_close(a["rgb"], g["rgb"], "unpacked frames")
     assert np.array_equal(a["line"], g["line"])
     b = m.render(scenegen.ROOM_CAMERA, 320, 180)  # and through the cost-history path
@@ -868,17 +873,15 @@ def test_seam_driver_like_main_local(scenes, tmp_path):
 
 
 @pytest.mark.parametrize("pool_cap", [None, 1])
-def test_binary_recursion_trees_fill_the_ray_pool(pool_cap, monkeypatch):
+def test_binary_recursion_trees_fill_the_ray_pool(pool_cap):
     """A material that is reflective AND transparent makes every hit spawn two
     child calls (mythtracer.cc:181-189 and :192-225): at depth 7 a pixel's
     recursion tree has up to 255 calls, a block's 16 320 -- far beyond the ray
     pool's 1 024 records per wave, so its depth-first throttle has to work; the
     state machine walks the same trees with its frame stack.  Pixels, debug
     buffer and every ray count must equal the oracle's.  pool_cap = 1: the pool
-    is cut down to its minimum (MT_DEBUG_POOL_CAP), so that it throttles all
+    is cut down to its minimum (MT_TUNE_POOL_CAP), so that it throttles all
     the time."""
-    if pool_cap is not None:
-        monkeypatch.setenv("MT_DEBUG_POOL_CAP", str(pool_cap))
     m, o = _both()
     for s in (m, o):
         s.add_material("both", (.1, .1, .1), (.3, .3, .3), (.4, .4, .4), ns=20, refl=0.8, tr=0.7, tf=(.9, .8, .7), ni=1.3)
@@ -896,6 +899,8 @@ def test_binary_recursion_trees_fill_the_ray_pool(pool_cap, monkeypatch):
         s.add_triangle([[-40, -40, -20], [40, -40, -20], [-40, 40, -20]], n, mtl=1, line_no=k); k += 1
         s.add_triangle([[40, 40, -20], [-40, 40, -20], [40, -40, -20]], n, mtl=1, line_no=k); k += 1
     lights = [(0, 30, -10, .1, .1, .1, .9, .9, .9, .5, .5, .5), (-20, -5, 5, 0, 0, 0, .4, .4, .4, .2, .2, .2)]
+    if pool_cap is not None:
+        M.hip_abi().set_tuning(m.device_scene(), "POOL_CAP", pool_cap)
     for depth in (5, 7):
         m.set_max_level(depth)
         m.set_lights(lights)
@@ -961,3 +966,204 @@ def test_work_counters_can_be_switched_off(scenes):
         assert {k: again["stats"][k] for k in ALL_KEYS if k not in PRUNED} == {k: want["stats"][k] for k in ALL_KEYS if k not in PRUNED}
     finally:
         abi.scene_destroy(h)
+
+
+def test_headline_frame_without_work_counters(scenes, engine):
+    """BASELINE configs[2] (room, 1920x1080, 3 lights, depth 5) through
+    mt_render_chunk_device with mt_scene_set_stats(scene, 0) -- the kernels
+    bench.py times -- against the SHA-256 of the frame the compiled reference
+    rendered (tests/golden/frames.json).  Four consecutive frames: a first frame
+    without costs, then history-scheduled ones; in the automatic mode that is the
+    ray pool (probe_kernel), then the state machine ordered by the pool's cost
+    words, then by its own; then a SMALL launch (a 640x360 chunk: fewer than 9
+    blocks per resident wave -> ray pool again, twice: probe, then costs) and
+    the full frame once more (no usable history after the chunk)."""
+    import hashlib
+    import torch
+    frames = json.load(open(os.path.join(GOLDEN, "frames.json")))
+    want = frames["room_1920x1080_d5"]["sha256"]
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["room"])
+    h = m.device_scene()
+    abi.set_lights(h, scenegen.ROOM_LIGHTS)
+    W, H = 1920, 1080
+    sens = binding.sensor(scenegen.ROOM_CAMERA, W, H)
+    buf = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+    abi.read_stats(h)
+    abi.set_stats(h, False)
+    full = None
+    for launch in range(4):
+        buf.zero_()
+        abi.render_chunk_device(h, sens, W, H, (0, 0, W, H), 5, ctypes.c_void_p(buf.data_ptr()))
+        torch.cuda.synchronize()
+        full = buf.cpu().numpy()
+        assert hashlib.sha256(full.tobytes()).hexdigest() == want, (engine, launch)
+    small = torch.zeros((360, 640, 3), dtype=torch.uint8, device="cuda")
+    for launch in range(2):
+        small.zero_()
+        abi.render_chunk_device(h, sens, W, H, (700, 500, 640, 360), 5, ctypes.c_void_p(small.data_ptr()))
+        torch.cuda.synchronize()
+        assert np.array_equal(small.cpu().numpy(), full[500:860, 700:1340]), (engine, launch)
+    buf.zero_()
+    abi.render_chunk_device(h, sens, W, H, (0, 0, W, H), 5, ctypes.c_void_p(buf.data_ptr()))
+    torch.cuda.synchronize()
+    assert hashlib.sha256(buf.cpu().numpy().tobytes()).hexdigest() == want
+    a, b = abi.kernel_times(h)
+    print(engine, "kernel ms per launch:", [round(float(x + y), 2) for x, y in zip(a, b)])
+    st = abi.read_stats(h)
+    assert sum(st[k] for k in RAY_KEYS) == 0  # counters were off
+    abi.set_stats(h, True)
+
+
+def test_automatic_engine_with_debug_buffers(scenes, engine):
+    """Consecutive frames WITH debug buffer and work counters through the
+    engine of the fixture -- in the automatic mode: a large launch (state machine
+    once costs exist) and a small one (ray pool) alternate, so both branches and
+    the hand-over of the cost words run -- each compared with the oracle."""
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["mini"])
+    h = m.device_scene()
+    abi.set_lights(h, scenegen.ROOM_LIGHTS)
+    # one workgroup per CU and the switch at 1 block per wave: 320x180 (920 blocks) is "large" for
+    # a 256-CU GPU's 1024 resident waves only if the threshold is lowered too
+    abi.set_tuning(h, "BLOCKS_PER_CU", 1)
+    abi.set_tuning(h, "POOL_BELOW", 0.5)
+    o = orclib.OracleScene(scenes["mini"])
+    o.set_lights(scenegen.ROOM_LIGHTS)
+    big = o.render(scenegen.ROOM_CAMERA, 320, 180, debug=True)
+    small = o.render(scenegen.ROOM_CAMERA, 320, 180, chunk=(40, 30, 96, 64), debug=True)
+    sens = binding.sensor(scenegen.ROOM_CAMERA, 320, 180)
+    for launch in range(6):
+        if launch in (3, 4):
+            g, w = abi.render_chunk(h, sens, 320, 180, chunk=(40, 30, 96, 64), debug=True), small
+        else:
+            g, w = abi.render_chunk(h, sens, 320, 180, debug=True), big
+        assert_rgb_close(g["rgb"], w["rgb"], "%s launch %d" % (engine, launch))
+        assert np.array_equal(g["line"], w["line"]), launch
+        assert np.array_equal(g["point"], w["point"], equal_nan=True), launch
+        counters_match({k: g["stats"][k] for k in ALL_KEYS}, w["counters"])
+
+
+@pytest.mark.parametrize("n_lights", [255, 300])
+def test_more_lights_than_the_ray_pool_addresses(n_lights, engine):
+    """The ray pool addresses 254 lights.  The automatic mode must render such a
+    scene anyway (through the state machine, which has no limit); only an
+    explicit engine 2 is refused, with MT_ERR_UNSUPPORTED."""
+    rnd = np.random.RandomState(n_lights)
+    lights = [(float(rnd.uniform(10, 90)), float(rnd.uniform(60, 95)), float(rnd.uniform(10, 90)),
+               .001, .001, .001, .004, .004, .004, .002, .002, .002) for _ in range(n_lights)]
+    m = M.MythTracer(CORNELL)
+    o = orclib.OracleScene(CORNELL)
+    m.set_lights(lights)
+    o.set_lights(lights)
+    if engine == "ray_pool":
+        with pytest.raises(RuntimeError, match="254 lights|engine 2"):
+            m.render(CORNELL_CAM, 24, 24)
+        return
+    for frame in range(2):
+        g, r = m.render(CORNELL_CAM, 24, 24, debug=True), o.render(CORNELL_CAM, 24, 24, debug=True)
+        counters_match(g["counters"], r["counters"])
+        assert np.array_equal(g["line"], r["line"])
+        assert_rgb_close(g["rgb"], r["rgb"], "%d lights, frame %d" % (n_lights, frame))
+
+
+def _write_ppm(path, rgb):
+    with open(path, "wb") as f:
+        f.write(b"P6\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]))
+        f.write(np.ascontiguousarray(rgb, dtype=np.uint8).tobytes())
+
+
+def test_texture_files_end_to_end(tmp_path, engine):
+    """SURVEY f-3 as a whole: image FILE -> decoder -> RGB8 -> mt_texture upload
+    -> GetUVW + Texture::GetColorAt in the kernel (texture.cc:60-109,
+    mythtracer.cc:59-64).  A generated .mtl names a PPM and a PNG through map_Ka;
+    MythTracer::LoadObj reads them with the library's own decoders; the oracle
+    loads a twin .mtl whose textures are PPM files of the same pixels (PNG is
+    lossless; the oracle reads PPM only).  One triangle carries NaN texture
+    coordinates: the reference's colors.at() would throw there (texture.cc:45-52);
+    both sides define the colour as NaN -> channel 0.
+    PARITY UNPINNED for Texture::GetColorAt itself (texture.cc:11-58): the
+    reference's texture.cc needs SDL2, which the image lacks, and the reference
+    holds no texture fixture -- GPU and oracle are checked against each other."""
+    from PIL import Image
+    rnd = np.random.RandomState(77)
+    ta = rnd.randint(0, 256, size=(9, 13, 3)).astype(np.uint8)
+    tb = rnd.randint(0, 256, size=(16, 16, 3)).astype(np.uint8)
+    d_gpu, d_orc = tmp_path / "gpu", tmp_path / "orc"
+    d_gpu.mkdir(); d_orc.mkdir()
+    _write_ppm(str(d_gpu / "a.ppm"), ta)
+    Image.fromarray(tb, "RGB").save(str(d_gpu / "b.png"))
+    _write_ppm(str(d_orc / "a.ppm"), ta)
+    _write_ppm(str(d_orc / "b.png"), tb)  # the oracle's PPM reader goes by content, the name stays the .mtl's
+    mtl = ("newmtl pa\nKa 1 1 1\nKd 0.8 0.8 0.8\nKs 0.1 0.1 0.1\nNs 4\nmap_Ka a.ppm\n"
+           "newmtl pb\nKa 0.9 0.7 0.8\nKd 0.5 0.5 0.5\nKs 0 0 0\nNs 1\nmap_Ka b.png\n"
+           "newmtl pc\nKa 1 1 1\nKd 0.5 0.5 0.5\nKs 0 0 0\nNs 1\nmap_Ka a.ppm\n")
+    obj = ("mtllib t.mtl\n"
+           "v -6 -4 0\nv 0 -4 0\nv -6 4 0\nv 6 -4 0\nv 0 4 0\nv 6 4 0\nv 0 4.5 0\nv 6 4.5 0\nv 6 8 0\n"
+           "vn 0 0 -1\n"
+           "vt -0.5 -0.5\nvt 1.5 0\nvt 0 2.5\nvt 0 0\nvt 1 0\nvt 0 1\nvt nan nan\n"
+           "usemtl pa\nf 1/1/1 2/2/1 3/3/1 \n"
+           "usemtl pb\nf 2/4/1 4/5/1 5/6/1 \n"
+           "usemtl pc\nf 7/7/1 8/7/1 9/7/1 \n")
+    for d in (d_gpu, d_orc):
+        (d / "t.mtl").write_text(mtl)
+        (d / "t.obj").write_text(obj)
+    m = M.MythTracer(str(d_gpu / "t.obj"))
+    o = orclib.OracleScene(str(d_orc / "t.obj"))
+    flat = m.flatten()
+    assert sorted(t["texels"].dtype.name for t in flat["textures"]) == ["uint8", "uint8"]  # RGB8 on the device
+    assert sorted(t["texels"].shape for t in flat["textures"]) == [(9, 13, 3), (16, 16, 3)]
+    cam, lights = (0, 2, -9, 0, 0, 0, 80), [(0, 0, -6, .4, .4, .4, .7, .7, .7, .2, .2, .2)]
+    for frame in range(2):
+        g = _render_both(m, o, cam, 96, 80, lights)
+    rgb, line = g["rgb"], g["line"]
+    for ln in np.unique(line[line >= 0])[:2]:
+        assert len(np.unique(rgb[line == ln], axis=0)) > 20  # the colour follows the texels
+    nan_tri = line == np.unique(line[line >= 0])[-1]
+    assert nan_tri.any() and (rgb[nan_tri] == 0).all()
+
+
+def test_render_frame_multi_virtual_devices(scenes, engine):
+    """mt_render_frame_multi (main_net_master.cc:195-236): N scene
+    replicas -- all on GPU 0 here, one per GPU in production -- render the tiles
+    k = r (mod N) of ONE frame side by side, the tile buffers are gathered on the
+    first replica's device and blitted; the frame must be byte-identical to the
+    single launch, every ray counted once."""
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["mini"])
+    flat = m.flatten()
+    W, H = 330, 190  # ragged edge tiles
+    sens = binding.sensor(scenegen.ROOM_CAMERA, W, H)
+    hs = [abi.scene_create(flat) for _ in range(4)]
+    try:
+        for hh in hs:
+            abi.set_lights(hh, scenegen.ROOM_LIGHTS)
+        single = abi.render_chunk(hs[0], sens, W, H)
+        for n in (1, 2, 3, 4):
+            for frame in range(2):  # the second one is scheduled from every replica's own costs
+                r = abi.render_frame_multi(hs[:n], sens, W, H, 64, 64, 5)
+                assert np.array_equal(r["rgb"], single["rgb"]), (n, frame)
+                for k in RAY_KEYS + ("shaded_hits",):
+                    assert sum(st[k] for st in r["stats"]) == single["stats"][k], (n, k)
+                assert all(st["kernel_ms"] > 0 for st in r["stats"])
+        r = abi.render_frame_multi(hs, sens, W, H, 256, 256, 5, want_stats=False)  # fewer tiles (2) than replicas
+        assert np.array_equal(r["rgb"], single["rgb"])
+        with pytest.raises(RuntimeError):
+            abi.render_frame_multi([hs[0], hs[0]], sens, W, H)
+    finally:
+        for hh in hs:
+            abi.scene_destroy(hh)
+
+
+def test_facade_set_devices(scenes, engine):
+    """MythTracer::SetDevices({0, 0}): the W x H overload of RayTrace
+    (mythtracer.cc:258-278) renders through mt_render_frame_multi -- the drop-in
+    a C++ driver written against the facade gets on a multi-GPU node."""
+    g = load("mini_320x180")
+    m = M.MythTracer(scenes["mini"])
+    m.set_devices([0, 0, 0])
+    m.set_lights(scenegen.ROOM_LIGHTS)
+    for frame in range(2):
+        rgb = m.render_image(scenegen.ROOM_CAMERA, 320, 180)
+        assert_rgb_close(rgb, g["rgb"], "SetDevices frame %d" % frame)
+        assert np.array_equal(rgb, g["rgb"])
