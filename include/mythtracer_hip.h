@@ -242,10 +242,14 @@ int mt_scene_set_scheduling(mt_scene *scene, int use_cost_history);
  * latency engine: the recursion of every pixel is unrolled into a per-wave pool
  * of rays, so that a call's shadow loops and child calls are traced side by
  * side (shortest chain of dependent passes per pixel; wins when a launch has
- * few blocks per wave, e.g. one rank's share of a multi-GPU frame).  0 =
- * automatic (default): 2 for launches with fewer than 9 blocks per resident
- * wave and for launches without measured block costs, else 1.  Also forgets the
- * recorded costs.  Limits of engine 2: at most 254 lights (a pool entry holds the
+ * few blocks per wave, e.g. one rank's share of a multi-GPU frame).  3 =
+ * hybrid: ONE kernel in which every wave first works through the launch's
+ * longest blocks, cut into pieces, as a ray-pool wave and then through
+ * everything else as a state-machine wave (needs measured block costs and has no
+ * debug-buffer path: a launch without the one or with the other is rendered by
+ * engine 2).  0 = automatic (default): 2 for launches without measured block
+ * costs; with them, 3 for launches with fewer than 9 blocks per resident wave,
+ * else 1.  Also forgets the recorded costs.  Limits of engine 2: at most 254 lights (a pool entry holds the
  * light in 8 bits), and its scratch -- per resident wave `capacity` records of
  * 160 + 80 n_lights bytes, capacity <= 1024 -- must fit a budget (4 GiB; the
  * capacity shrinks to fit, down to the ~280 records its depth-first throttle
@@ -277,6 +281,9 @@ enum {
   MT_TUNE_QUAD_SHARE, MT_TUNE_QUAD_SHARE_MOVING, MT_TUNE_QUAD_KEEP,
   MT_TUNE_QUAD_WORK, MT_TUNE_QUAD_WORK_MOVING,
   MT_TUNE_POOL_SCRATCH_MB,    /* scratch budget of the ray pool (4096) */
+  MT_TUNE_HYBRID_POOL_SHARE,  /* engine 3: blocks above this share of an even split go to the ray pool in pieces (1.0) */
+  MT_TUNE_HYBRID_QUAD_SHARE,  /* ... above this one to the state machine as quarters, four lanes per pixel (1.0 = none) */
+  MT_TUNE_HYBRID_WORK1, MT_TUNE_HYBRID_WORK2, /* pool quarters / cells: summed cost over the whole block's (1.3, 3.3) */
   MT_TUNE_COUNT
 };
 int mt_scene_set_tuning(mt_scene *scene, int knob, double value);

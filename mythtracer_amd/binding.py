@@ -30,7 +30,7 @@ TUNE = {name: i for i, name in enumerate([
     "POOL_BELOW", "POOL_CAP", "PACKED_STACK", "BLOCKS_PER_CU", "FORECAST_RADIUS", "BLEND", "FORMS",
     "POOL_CUT_SHARE", "POOL_PIECE_TIME1", "POOL_PIECE_TIME2", "POOL_PIECE_WORK1", "POOL_PIECE_WORK2",
     "POOL_CELL_FACTOR", "QUAD_SHARE", "QUAD_SHARE_MOVING", "QUAD_KEEP", "QUAD_WORK", "QUAD_WORK_MOVING",
-    "POOL_SCRATCH_MB"])}
+    "POOL_SCRATCH_MB", "HYBRID_POOL_SHARE", "HYBRID_QUAD_SHARE", "HYBRID_WORK1", "HYBRID_WORK2"])}
 
 STAT_NAMES = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests",
               "node_visits", "tri_tests", "mt_tests", "shaded_hits"]
@@ -269,7 +269,7 @@ class HipAbi:
         self.check(self.lib.mt_scene_set_stats(h, 1 if enabled else 0))
 
     def set_engine(self, h, engine: int):
-        """0 = automatic, 1 = throughput engine (state machine), 2 = latency engine (ray pool)."""
+        """0 = automatic, 1 = throughput engine (state machine), 2 = latency engine (ray pool), 3 = hybrid."""
         self.check(self.lib.mt_scene_set_engine(h, int(engine)))
 
     def set_default_engine(self, engine: int):

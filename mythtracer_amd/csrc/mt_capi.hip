@@ -72,6 +72,13 @@ struct Tuning {
     v[MT_TUNE_QUAD_KEEP] = 1.0;
     v[MT_TUNE_QUAD_WORK] = 1.7;   v[MT_TUNE_QUAD_WORK_MOVING] = 1.5;
     v[MT_TUNE_POOL_SCRATCH_MB] = 4096.0;  // automatic mode: above this the state machine renders (explicit engine 2: the cap shrinks)
+    // hybrid launches: blocks above POOL_SHARE of an even split go to the ray pool in pieces, blocks above QUAD_SHARE to
+    // the state machine as quarters with four lanes per pixel (swept on one rank's share of the 4K frame at N = 8,
+    // scripts/hybrid_sweep.py: 0.8 / 0.9 / 1.0 / 1.15 / 1.3 -> slowest rank 3.90 / 3.65 / 3.65 / 3.72 / 3.92 ms; with the
+    // quarters' threshold below the pool's the state machine's 1.7x work per quartered block comes back: +0.3 ms)
+    v[MT_TUNE_HYBRID_POOL_SHARE] = 1.0;
+    v[MT_TUNE_HYBRID_QUAD_SHARE] = 1.0;
+    v[MT_TUNE_HYBRID_WORK1] = 1.3; v[MT_TUNE_HYBRID_WORK2] = 3.3;  // pool quarters / cells: summed cost over the state machine's whole-block cost
   }
 };
 
@@ -107,6 +114,8 @@ struct mt_scene {
   size_t item_forecast_bytes = 0;
   unsigned int *d_item_forms = nullptr;     // [2 n_items] cost of a block as one unit / as four quarters (forecast_kernel)
   size_t item_forms_bytes = 0;
+  unsigned char *d_item_form = nullptr;     // [n_items] hybrid launches: how each block was rendered (hybrid_schedule_kernel)
+  size_t item_form_bytes = 0;
   mt_sensor cost_sensor{};               // camera of the launch that measured the costs
   unsigned int *d_order_item = nullptr;  // [4 n_items]
   size_t order_item_bytes = 0;
@@ -192,6 +201,7 @@ int configure_launch(mt_scene *s) {
       const void *kernels[] = {(const void *)render_kernel<true>, (const void *)render_kernel<false>,
                                (const void *)primary_kernel<true>, (const void *)primary_kernel<false>,
                                (const void *)pool_kernel<true>, (const void *)pool_kernel<false>,
+                               (const void *)hybrid_kernel<true>, (const void *)hybrid_kernel<false>,
                                (const void *)probe_kernel, (const void *)intersect_kernel};
       for (const void *k : kernels) {
         HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
@@ -273,7 +283,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   // by its amount of work, i.e. when there are few blocks per wave (a rank's
   // share of a multi-GPU frame, a small chunk).
   int engine = s->engine;
-  const bool engine_auto = engine != 1 && engine != 2;
+  const bool engine_auto = engine != 1 && engine != 2 && engine != 3;
   // Ray pool: records per wave.  64 * (2^(max_depth+1) - 1) is every call of every pixel's recursion tree at once;
   // beyond kPoolCapMax the kernel's throttle keeps the pool within the capacity (depth first).  A record grows with
   // the number of lights (160 + 80 n bytes), so the capacity shrinks with it -- down to the floor the throttle needs
@@ -297,6 +307,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       pool_cap = fit;
     }
     if ((long long)s->tune.v[MT_TUNE_POOL_CAP] > 0) pool_cap = (long long)s->tune.v[MT_TUNE_POOL_CAP];  // tests: force the depth-first throttle
+    if (pool_cap > 65535) pool_cap = 65535;  // a pool entry holds the record number in 16 bits
     if (pool_cap < floor_cap) {
       pool_fits = (double)floor_cap * (double)per_rec * (double)(waves ? waves : 1) <= 4.0 * budget;
       pool_cap = floor_cap;
@@ -311,14 +322,23 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     // of the work is a guess, and the pool's short pixel chains forgive a bad
     // guess (12 ms against the state machine's 14.5 on the 1080p frame).
     // The state machine has no limit on lights or scratch: it takes what the pool cannot hold.
-    engine = (pool_fits && pool_roomy && (!have_costs || (float)P.n_items < per_wave * (float)waves)) ? 2 : 1;
+    // With measured costs such a launch goes to the HYBRID kernel (engine 3): only its longest blocks go through the
+    // pool, in pieces; the rest keeps the state machine's cost per ray (one rank's share of the 4K frame at N = 8:
+    // 3.63 ms against the pool's 3.88 and the state machine's 4.36; at N = 4 the state machine alone is ahead, 5.71
+    // against 5.80).  It has no debug-buffer path: such launches stay with the pool.
+    const bool small = (float)P.n_items < per_wave * (float)waves;
+    engine = !(pool_fits && pool_roomy) ? 1 : (!have_costs ? 2 : (small ? (d_debug == nullptr ? 3 : 2) : 1));
   }
+  // Engine 3 (hybrid: the longest blocks through the ray pool in pieces, the rest through the state machine, one
+  // kernel) needs measured costs to tell the two kinds apart and has no debug-buffer path; a launch without either
+  // is rendered by the ray pool (or the state machine where the pool does not fit).
+  if (engine == 3 && !(have_costs && pool_fits && d_debug == nullptr)) engine = pool_fits ? 2 : 1;
   if (engine == 2 && !pool_fits) {
     return fail(MT_ERR_UNSUPPORTED, "the ray pool (engine 2) holds at most %d lights within its scratch budget; "
                 "%d were set -- engine 0 (automatic) or 1 renders such scenes", kPoolMaxLights, n_l);
   }
-  const bool pool_engine = engine == 2;
-  const bool history = have_costs && (pool_engine || d_debug == nullptr);
+  const bool pool_engine = engine == 2, hybrid = engine == 3;
+  const bool history = have_costs && (pool_engine || d_debug == nullptr);  // (hybrid: both hold, see above)
   P.from_primary = history ? 0 : 1;
   {
     int rc = ensure_bytes((void **)&s->d_item_cost, &s->item_cost_bytes, (size_t)P.n_items * 4);
@@ -326,6 +346,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_item_forms, &s->item_forms_bytes, (size_t)P.n_items * 8);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_item, &s->order_item_bytes, (size_t)P.n_items * 64);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_sub, &s->order_sub_bytes, (size_t)P.n_items * 16);
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_item_form, &s->item_form_bytes, (size_t)P.n_items);
     if (rc != MT_OK) return rc;
   }
   P.item_cost = s->d_item_cost;
@@ -336,14 +357,15 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   P.order_item = s->d_order_item;
   P.order_sub = s->d_order_sub;
   P.n_work = s->d_work + 7;
-  if (pool_engine) {
+  if (pool_engine || hybrid) {
     int rc = ensure_bytes((void **)&s->d_pool, &s->pool_bytes, pool_stride * waves);
     if (rc != MT_OK) return rc;
     P.pool_scratch = s->d_pool;
     P.pool_stride = pool_stride;
     P.pool_cap = (int)pool_cap;
     P.prio_units = (unsigned)(s->n_cu * 4);  // one per SIMD
-  } else {
+  }
+  if (!pool_engine) {
     size_t fbytes = waves * ((size_t)(max_depth > 0 ? max_depth : 1) * kFrameSlots + kParkSlots) * 64 * sizeof(double);
     const size_t slots_px = (size_t)n_tiles * (size_t)tile_w * (size_t)tile_h;
     int rc = ensure_bytes((void **)&s->d_frames, &s->frames_bytes, fbytes);
@@ -364,11 +386,11 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   unsigned long long *d_item = nullptr;
   const char *item_dump = s->dbg_item_cycles.empty() ? nullptr : s->dbg_item_cycles.c_str();
   if (item_dump && P.n_items > 0) {
-    HIP_TRY(hipMalloc((void **)&d_item, (size_t)P.n_items * 16 * 16 * 3));
-    HIP_TRY(hipMemset(d_item, 0, (size_t)P.n_items * 16 * 16 * 3));
+    HIP_TRY(hipMalloc((void **)&d_item, (size_t)P.n_items * 16 * 16 * 4));
+    HIP_TRY(hipMemset(d_item, 0, (size_t)P.n_items * 16 * 16 * 4));
     P.item_cycles = d_item;
   }
-  HIP_TRY(hipMemsetAsync(s->d_work, 0, 8 * sizeof(unsigned), stream));
+  HIP_TRY(hipMemsetAsync(s->d_work, 0, 16 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
   HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
@@ -411,11 +433,12 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     SchedParams sp{history ? 1.0f : 0.3f, {1.0f, (float)tv[MT_TUNE_POOL_PIECE_TIME1], (float)tv[MT_TUNE_POOL_PIECE_TIME2]},
                    {1.0f, (float)tv[MT_TUNE_POOL_PIECE_WORK1], (float)tv[MT_TUNE_POOL_PIECE_WORK2]},
                    (float)tv[MT_TUNE_POOL_CELL_FACTOR],
-                   (!history || s->last_engine == 2) ? 1 : 0};  // a forecast is cut more eagerly
+                   (!history || s->last_engine == 2) ? 1 : 0};  // a forecast is cut more eagerly (own_costs: granularity in bits 30-31)
     if (tv[MT_TUNE_POOL_CUT_SHARE] >= 0.0) sp.cut_share = (float)tv[MT_TUNE_POOL_CUT_SHARE];
     hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
-                       reproject, radius, (history && s->last_engine == 1) ? 0 : 1,
-                       (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u, blend);
+                       reproject, radius, (history && (s->last_engine == 1 || s->last_engine == 3)) ? 0 : 1,
+                       (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u, blend,
+                       (history && s->last_engine == 3) ? s->d_item_form : nullptr, (float)tv[MT_TUNE_HYBRID_WORK1], (float)tv[MT_TUNE_HYBRID_WORK2]);
     hipLaunchKernelGGL(pool_schedule_kernel, dim3(1), dim3(kPoolSchedThreads), 0, stream, P,
                        s->grid_blocks * s->waves_per_block, sp);
     HIP_TRY(hipGetLastError());
@@ -439,9 +462,19 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       // work of a block rendered as quarters / rendered whole (swept with the share): 1.5 / 1.7
       const float quad_work = (float)s->tune.v[reproject ? MT_TUNE_QUAD_WORK_MOVING : MT_TUNE_QUAD_WORK];
       hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
-                         reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f, 16000u, blend);
-      hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
-                         s->grid_blocks * s->waves_per_block, quad_share, quad_keep);
+                         reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f, 16000u, blend,
+                         s->last_engine == 3 ? s->d_item_form : nullptr, (float)s->tune.v[MT_TUNE_HYBRID_WORK1], (float)s->tune.v[MT_TUNE_HYBRID_WORK2]);
+      if (hybrid) {
+        const double *tv = s->tune.v;
+        const float k = reproject ? (float)(tv[MT_TUNE_QUAD_SHARE_MOVING] / tv[MT_TUNE_QUAD_SHARE]) : 1.0f;  // a re-projected forecast is cut more eagerly
+        hipLaunchKernelGGL(hybrid_schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
+                           s->grid_blocks * s->waves_per_block, k * (float)tv[MT_TUNE_HYBRID_QUAD_SHARE],
+                           k * (float)tv[MT_TUNE_HYBRID_POOL_SHARE], (float)tv[MT_TUNE_POOL_PIECE_TIME1],
+                           (float)tv[MT_TUNE_POOL_PIECE_TIME2], (float)tv[MT_TUNE_POOL_CELL_FACTOR], s->d_item_form);
+      } else {
+        hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
+                           s->grid_blocks * s->waves_per_block, quad_share, quad_keep);
+      }
     } else if (s->stats_enabled) {
       hipLaunchKernelGGL(primary_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
     } else {
@@ -449,7 +482,10 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ek[1], stream));
-    if (s->stats_enabled) {
+    if (hybrid) {
+      if (s->stats_enabled) hipLaunchKernelGGL(hybrid_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
+      else hipLaunchKernelGGL(hybrid_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
+    } else if (s->stats_enabled) {
       hipLaunchKernelGGL(render_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
     } else {
       hipLaunchKernelGGL(render_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
@@ -481,7 +517,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     }
   }
   if (d_item) {  // debug: dump per-item durations (synchronises!)
-    std::vector<unsigned long long> host((size_t)P.n_items * 16 * 2 * 3);
+    std::vector<unsigned long long> host((size_t)P.n_items * 16 * 2 * 4);
     HIP_TRY(hipMemcpy(host.data(), d_item, host.size() * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d_item));
     if (FILE *f = fopen(item_dump, "wb")) {
@@ -572,6 +608,7 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_item_cost) (void)hipFree(s->d_item_cost);
   if (s->d_item_forecast) (void)hipFree(s->d_item_forecast);
   if (s->d_item_forms) (void)hipFree(s->d_item_forms);
+  if (s->d_item_form) (void)hipFree(s->d_item_form);
   if (s->d_order_item) (void)hipFree(s->d_order_item);
   if (s->d_order_sub) (void)hipFree(s->d_order_sub);
   if (s->d_rgb) (void)hipFree(s->d_rgb);
@@ -964,14 +1001,14 @@ int mt_scene_set_stats(mt_scene *s, int enabled) {
 }
 
 int mt_scene_set_engine(mt_scene *s, int engine) {
-  if (!s || engine < 0 || engine > 2) return fail(MT_ERR_ARG, "engine must be 0 (automatic), 1 or 2");
+  if (!s || engine < 0 || engine > 3) return fail(MT_ERR_ARG, "engine must be 0 (automatic), 1, 2 or 3");
   s->engine = engine;
   s->cost_signature = 0;
   return MT_OK;
 }
 
 int mt_set_default_engine(int engine) {
-  if (engine < 0 || engine > 2) return fail(MT_ERR_ARG, "engine must be 0 (automatic), 1 or 2");
+  if (engine < 0 || engine > 3) return fail(MT_ERR_ARG, "engine must be 0 (automatic), 1, 2 or 3");
   g_default_engine.store(engine);
   return MT_OK;
 }

@@ -286,8 +286,14 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
 // The frame kernel: TraceRayWorker for every pixel of the launch's tiles and
 // the pixel store.  Persistent waves pull work units in pool_schedule_kernel's
 // order; the first ones (the longest) run at raised wave priority.
-template <bool STATS>
-__global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void pool_kernel(DevScene S, RenderParams P) {
+// pool_engine is the body shared by pool_kernel (all units of the launch) and hybrid_kernel (mt_render.hip; MIXED: the
+// order holds units of both engines, the pool's marked by kHybridPoolSub in order_sub).  `carry`: a unit index this
+// wave has fetched already, or kCarryNone.  Returns kCarryDone when the order is exhausted, kCarryFail after a
+// failure, else (MIXED) the first fetched unit that belongs to the other engine.
+constexpr unsigned kCarryNone = 0xffffffffu, kCarryDone = 0xfffffffeu, kCarryFail = 0xfffffffdu;
+constexpr int kHybridPoolSub = 32;
+template <bool STATS, bool MIXED>
+__device__ __forceinline__ unsigned pool_engine(const DevScene &S, const RenderParams &P, unsigned carry) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
@@ -319,19 +325,29 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void pool_kernel(DevScene S
   const V3 s_ds = v3_load(P.sensor.delta_scanline);
   const V3 s_dp = v3_load(P.sensor.delta_pixel);
   const unsigned n_work = *P.n_work;
+  unsigned result = kCarryDone;
   // Records a pass may need on top of those its rays already have, kept back
   // while the free ones run low (see the throttle below).
   const int reserve = 4 * (P.max_depth + 1);
 
   for (;;) {
-    const unsigned w = pool_fetch_work(P.work_counter + 1, lane);
+    unsigned w = carry;
+    if (carry == kCarryNone) w = pool_fetch_work(P.work_counter + 1, lane);
+    carry = kCarryNone;
     if (S.hb) {
       const unsigned long long ex = __builtin_amdgcn_read_exec();
       if (lane == 0) { S.hb[wave_id * 4 + 0] = 1 | ((unsigned long long)w << 8); S.hb[wave_id * 4 + 1] = ex; }
     }
     if (w >= n_work) break;
     const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)P.order_item[w]);
-    const int sub = __builtin_amdgcn_readfirstlane((int)P.order_sub[w]);
+    int sub = __builtin_amdgcn_readfirstlane((int)P.order_sub[w]);
+    if (MIXED) {
+      if (sub < kHybridPoolSub) {  // the state machine's
+        result = w;
+        break;
+      }
+      sub -= kHybridPoolSub;
+    }
     // The longest units run at raised priority: one per SIMD at most (more
     // would only compete with each other), so that they get a SIMD's issue
     // slots ahead of the two short-unit waves that share it.
@@ -760,6 +776,8 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void pool_kernel(DevScene S
         atomicAdd(P.item_cost + item, c > 0x03ffffffull ? 0x03ffffffu : (unsigned)c);
         if (P.item_cycles) {
           P.item_cycles[(size_t)w * 2] = ticks;
+          P.item_cycles[(size_t)(P.n_items * 48u + w) * 2] = item_t0;  // start stamp (scripts/unit_timeline.py)
+          P.item_cycles[(size_t)(P.n_items * 48u + w) * 2 + 1] = (unsigned long long)wave_id;
           P.item_cycles[(size_t)w * 2 + 1] =
               ((unsigned long long)passes << 40) | ((unsigned long long)item << 8) | (unsigned)(sub + 1);
 #ifdef MT_DIAG
@@ -772,9 +790,19 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void pool_kernel(DevScene S
       }
     }
     pool_flush_item_stats<STATS>(st, P.counters, lane);
-    if (failed) break;
+    if (failed) {
+      result = kCarryFail;
+      break;
+    }
   }
-  if (S.hb && lane == 0) S.hb[wave_id * 4 + 0] = 5;
+  __builtin_amdgcn_s_setprio(0);
+  return result;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void pool_kernel(DevScene S, RenderParams P) {
+  (void)pool_engine<STATS, false>(S, P, kCarryNone);
+  if (S.hb && (threadIdx.x & 63) == 0) S.hb[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + 0] = 5;
 }
 
 }  // namespace mt

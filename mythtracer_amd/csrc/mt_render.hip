@@ -245,11 +245,17 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScen
 // did not see, `unseen`, the mean cost of a block.  The forecast only orders
 // the work and picks the blocks handed out in pieces.
 // pool != 0: cost words of the latency engine (granularity in bits 30-31).
+// form != nullptr: the previous launch was a HYBRID one -- form[b] = how block b was rendered: 0 / 1 by the state
+// machine (whole / as quarters: bit 31 of its cost word, as ever), 2 / 3 by the ray pool as quarters / cells, whose
+// summed costs are scaled to the state machine's whole-block scale by wq / wc.
 __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, int radius, int pool, float w1,
-                                float w2, unsigned unseen, float blend) {
+                                float w2, unsigned unseen, float blend, const unsigned char *form, float wq, float wc) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_items) return;
-  auto cost_of = [&](unsigned word) -> unsigned {
+  auto cost_of = [&](unsigned word, unsigned idx) -> unsigned {
+    if (form != nullptr && form[idx] >= 2) {
+      return (unsigned)((float)(word & 0x3fffffffu) / (form[idx] == 2 ? wq : wc));
+    }
     if (pool) {
       const unsigned lvl = word >> 30;
       const float c = (float)(word & 0x3fffffffu);
@@ -263,8 +269,8 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
     // blend > 0 (the camera stands still and the previous launch made a forecast too): the new forecast is a mix
     // of the old one and the measurement -- a block near a cutting threshold is otherwise measured whole in one
     // frame and in pieces in the next, and the schedule alternates between two states
-    unsigned f = cost_of(P.item_cost[i]);
-    if (!pool && P.item_whole != nullptr) {
+    unsigned f = cost_of(P.item_cost[i], i);
+    if (!pool && P.item_whole != nullptr && !(form != nullptr && form[i] >= 2)) {
       // A block near the cutting threshold: measured whole it costs c, in four pieces s, and s / w1 is only a guess
       // of c -- when the guess is below the threshold and c above it, the block changes its form every few frames
       // and every frame that renders it whole ends late.  Once both have been measured, THEIR ratio scales the one to
@@ -323,7 +329,8 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
           const int jj = (t - P.first_tile) / P.tile_stride;
           if (jj >= P.n_tiles) continue;
           const int lx = ((int)qx - P.region_x) % P.tile_w, ly = ((int)qy - P.region_y) % P.tile_h;
-          mxc = max(mxc, cost_of(P.item_cost[(size_t)jj * per_tile + (size_t)(ly / 8) * P.blocks_x + lx / 8]));
+          const unsigned nb = (unsigned)((size_t)jj * per_tile + (size_t)(ly / 8) * P.blocks_x + lx / 8);
+          mxc = max(mxc, cost_of(P.item_cost[nb], nb));
           any = true;
         }
       }
@@ -399,6 +406,72 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
   }
 }
 
+// Work order of a HYBRID launch (engine 3, hybrid_kernel below): blocks whose forecast lies above pool_share of an
+// even share of the frame's work go to the ray pool in pieces (4x4 quarters; 2x2 cells when a quarter would still be
+// cell_factor times above that; order_sub = kHybridPoolSub + piece); the others go to the state machine as in
+// schedule_kernel (whole, or above quad_share as quarters with four lanes per pixel).  The pool's units come first,
+// longest expected unit first within either kind.  form[b] records how block b is rendered (forecast_kernel needs
+// it to read the costs).
+__global__ __launch_bounds__(kSchedThreads) void hybrid_schedule_kernel(RenderParams P, int n_waves, float quad_share,
+                                                                        float pool_share, float piece_time1,
+                                                                        float piece_time2, float cell_factor,
+                                                                        unsigned char *form) {
+  __shared__ unsigned long long s_sum;
+  __shared__ unsigned s_count[2][kSchedBuckets];
+  __shared__ unsigned s_start[2][kSchedBuckets];
+  const int tid = threadIdx.x;
+  if (tid == 0) s_sum = 0ull;
+  for (int b = tid; b < 2 * kSchedBuckets; b += kSchedThreads) (&s_count[0][0])[b] = 0u;
+  __syncthreads();
+  const float kQuarterTime = 0.45f;
+  unsigned long long part = 0ull;
+  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) part += P.item_forecast[i] & 0x7fffffffu;
+  atomicAdd(&s_sum, part);
+  __syncthreads();
+  const float share = (float)s_sum / (float)(n_waves > 0 ? n_waves : 1);
+  const float quad_above = share * quad_share, pool_above = share * pool_share;
+  auto decide = [&](unsigned i, int &f, unsigned &unit, unsigned &n) {
+    const unsigned c = P.item_forecast[i] & 0x7fffffffu;
+    if ((float)c > pool_above && c > 0u) {
+      f = ((float)c * piece_time1 > cell_factor * pool_above) ? 3 : 2;
+      unit = (unsigned)((float)c * (f == 3 ? piece_time2 : piece_time1));
+      n = f == 3 ? 16u : 4u;
+    } else if ((float)c > quad_above && c > 0u) {
+      f = 1; unit = (unsigned)((float)c * kQuarterTime); n = 4u;
+    } else {
+      f = 0; unit = c; n = 1u;
+    }
+  };
+  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
+    int f; unsigned unit, n;
+    decide(i, f, unit, n);
+    atomicAdd(&s_count[f >= 2 ? 0 : 1][cost_bucket(unit)], n);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned acc = 0u;
+    for (int g = 0; g < 2; g++) {  // the pool's units come first
+      for (int b = 0; b < kSchedBuckets; b++) {
+        s_start[g][b] = acc;
+        acc += s_count[g][b];
+      }
+    }
+    P.n_work[0] = acc;
+  }
+  __syncthreads();
+  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
+    int f; unsigned unit, n;
+    decide(i, f, unit, n);
+    const unsigned at = atomicAdd(&s_start[f >= 2 ? 0 : 1][cost_bucket(unit)], n);
+    for (unsigned q = 0; q < n; q++) {
+      P.order_item[at + q] = i;
+      P.order_sub[at + q] = (signed char)(f == 0 ? -1 : (f == 1 ? (int)q : kHybridPoolSub + (f == 3 ? 4 + (int)q : (int)q)));
+    }
+    P.item_cost[i] = f == 1 ? 0x80000000u : 0u;
+    form[i] = (unsigned char)f;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // The frame kernel: TraceRayWorker for every pixel of the launch's tiles and
 // the pixel store.  With cost history (P.from_primary == 0) it traces the
@@ -410,8 +483,10 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
 // (Plain 4x4 quarters with one lane per pixel do not help -- a pass over 16 lanes
 // costs about 80 % of a pass over 64; quarters pay off only with four lanes per
 // pixel, i.e. with the pixel's shadow loops running side by side.)
-template <bool STATS>
-__global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene S, RenderParams P) {
+// sm_engine is the body shared by render_kernel and hybrid_kernel (below); `carry` and the return value as for
+// pool_engine (mt_pool.h).
+template <bool STATS, bool MIXED>
+__device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderParams &P, unsigned carry) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
@@ -435,12 +510,15 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
   const V3 s_start = v3_load(P.sensor.start_point);
   const V3 s_ds = v3_load(P.sensor.delta_scanline);
   const V3 s_dp = v3_load(P.sensor.delta_pixel);
+  unsigned result = kCarryDone;
   const bool from_primary = P.from_primary != 0;
   const unsigned n2 = P.class_count[2], n1 = P.class_count[1], n0 = P.class_count[0];
   const unsigned n_work = from_primary ? 4u * n2 + n1 + n0 : *P.n_work;
 
   for (;;) {
-    const unsigned w = fetch_work(P.work_counter + 1, lane);
+    unsigned w = carry;
+    if (carry == kCarryNone) w = fetch_work(P.work_counter + 1, lane);
+    carry = kCarryNone;
     if (S.hb) {
       const unsigned long long ex = __builtin_amdgcn_read_exec();
       if (lane == 0) { S.hb[wave_id * 4 + 0] = 1 | ((unsigned long long)w << 8); S.hb[wave_id * 4 + 1] = ex; }
@@ -453,6 +531,10 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
       // (schedule_kernel); the longest blocks come as four quarters.
       item = P.order_item[w];
       sub = (int)P.order_sub[w];
+      if (MIXED && __builtin_amdgcn_readfirstlane(sub) >= kHybridPoolSub) {  // the ray pool's
+        result = w;
+        break;
+      }
       if (w < (n_work >> 4)) __builtin_amdgcn_s_setprio(3);
       else if (w < (n_work >> 2)) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(0);
@@ -867,6 +949,8 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
         atomicAdd(P.item_cost + item, c > 0x0fffffffull ? 0x0fffffffu : (unsigned)c);
         if (P.item_cycles) {
           P.item_cycles[(size_t)w * 2] = ticks;
+          P.item_cycles[(size_t)(P.n_items * 48u + w) * 2] = item_t0;  // start stamp (scripts/unit_timeline.py)
+          P.item_cycles[(size_t)(P.n_items * 48u + w) * 2 + 1] = (unsigned long long)wave_id;
           P.item_cycles[(size_t)w * 2 + 1] =
               ((unsigned long long)passes << 40) | ((unsigned long long)item << 8) | (unsigned)(sub + 1);
 #ifdef MT_DIAG
@@ -878,6 +962,27 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
     flush_item_stats<STATS>(st, P.counters, lane);
   }
   if (S.hb && lane == 0) S.hb[wave_id * 4 + 0] = 5;
+  __builtin_amdgcn_s_setprio(0);
+  return result;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene S, RenderParams P) {
+  (void)sm_engine<STATS, false>(S, P, kCarryNone);
+}
+
+// The HYBRID frame kernel (engine 3): the work order starts with the longest blocks, cut into pieces for the ray
+// pool (order_sub = kHybridPoolSub + piece: their chains of dependent passes are the recursion depth, not the number of
+// rays of the recursion tree), and goes on with everything else for the state machine (lowest cost per ray).  Every
+// wave works through the pool's units first -- they are the ones a frame must not end on -- and becomes a state-machine
+// wave with the first unit it fetches that is not the pool's.  (One merged order with waves changing over in both
+// directions was measured too: 1.5 % slower on a frame without pool units, no better at N = 8.)  Same arithmetic per
+// pixel in either part, as in the two kernels above.
+template <bool STATS>
+__global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void hybrid_kernel(DevScene S, RenderParams P) {
+  const unsigned carry = pool_engine<STATS, true>(S, P, kCarryNone);
+  if (carry >= kCarryFail) return;  // the order is exhausted, or a device-side bound tripped (status is set)
+  (void)sm_engine<STATS, false>(S, P, carry);
 }
 
 // OctTree::IntersectRay for a batch of arbitrary rays: lane i of the grid
@@ -960,5 +1065,7 @@ template __global__ void primary_kernel<true>(DevScene, RenderParams);
 template __global__ void primary_kernel<false>(DevScene, RenderParams);
 template __global__ void pool_kernel<true>(DevScene, RenderParams);
 template __global__ void pool_kernel<false>(DevScene, RenderParams);
+template __global__ void hybrid_kernel<true>(DevScene, RenderParams);
+template __global__ void hybrid_kernel<false>(DevScene, RenderParams);
 
 }  // namespace mt

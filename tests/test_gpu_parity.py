@@ -34,7 +34,7 @@ def _libs(native_libs):
     assert M.hip_abi().device_count() >= 1, "no GPU visible: the HIP path cannot run"
 
 
-@pytest.fixture(params=["state_machine", "ray_pool", "auto"], autouse=True)
+@pytest.fixture(params=["state_machine", "ray_pool", "hybrid", "auto"], autouse=True)
 def engine(request):
     """Every test runs through both frame engines (include/mythtracer_hip.h,
     mt_scene_set_engine) and through the shipping default, the AUTOMATIC choice
@@ -44,7 +44,7 @@ def engine(request):
     the API (mt_set_default_engine: scenes created from now on), not through the
     environment."""
     abi = M.hip_abi()
-    abi.set_default_engine({"state_machine": 1, "ray_pool": 2, "auto": 0}[request.param])
+    abi.set_default_engine({"state_machine": 1, "ray_pool": 2, "hybrid": 3, "auto": 0}[request.param])
     yield request.param
     abi.set_default_engine(0)
 
