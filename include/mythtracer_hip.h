@@ -284,6 +284,7 @@ enum {
   MT_TUNE_HYBRID_POOL_SHARE,  /* engine 3: blocks above this share of an even split go to the ray pool in pieces (1.0) */
   MT_TUNE_HYBRID_QUAD_SHARE,  /* ... above this one to the state machine as quarters, four lanes per pixel (1.0 = none) */
   MT_TUNE_HYBRID_WORK1, MT_TUNE_HYBRID_WORK2, /* pool quarters / cells: summed cost over the whole block's (1.3, 3.3) */
+  MT_TUNE_FORECAST_STEP,      /* pixels between the positions a re-projected forecast takes its maximum over (8) */
   MT_TUNE_COUNT
 };
 int mt_scene_set_tuning(mt_scene *scene, int knob, double value);

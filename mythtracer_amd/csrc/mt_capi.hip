@@ -78,6 +78,7 @@ struct Tuning {
     // quarters' threshold below the pool's the state machine's 1.7x work per quartered block comes back: +0.3 ms)
     v[MT_TUNE_HYBRID_POOL_SHARE] = 1.0;
     v[MT_TUNE_HYBRID_QUAD_SHARE] = 1.0;
+    v[MT_TUNE_FORECAST_STEP] = 8.0;       // pixels between the old-image positions a re-projected forecast takes its maximum over
     v[MT_TUNE_HYBRID_WORK1] = 1.3; v[MT_TUNE_HYBRID_WORK2] = 3.3;  // pool quarters / cells: summed cost over the state machine's whole-block cost
   }
 };
@@ -438,7 +439,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
                        reproject, radius, (history && (s->last_engine == 1 || s->last_engine == 3)) ? 0 : 1,
                        (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u, blend,
-                       (history && s->last_engine == 3) ? s->d_item_form : nullptr, (float)tv[MT_TUNE_HYBRID_WORK1], (float)tv[MT_TUNE_HYBRID_WORK2]);
+                       (history && s->last_engine == 3) ? s->d_item_form : nullptr, (float)tv[MT_TUNE_HYBRID_WORK1], (float)tv[MT_TUNE_HYBRID_WORK2], (float)tv[MT_TUNE_FORECAST_STEP]);
     hipLaunchKernelGGL(pool_schedule_kernel, dim3(1), dim3(kPoolSchedThreads), 0, stream, P,
                        s->grid_blocks * s->waves_per_block, sp);
     HIP_TRY(hipGetLastError());
@@ -463,7 +464,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       const float quad_work = (float)s->tune.v[reproject ? MT_TUNE_QUAD_WORK_MOVING : MT_TUNE_QUAD_WORK];
       hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
                          reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f, 16000u, blend,
-                         s->last_engine == 3 ? s->d_item_form : nullptr, (float)s->tune.v[MT_TUNE_HYBRID_WORK1], (float)s->tune.v[MT_TUNE_HYBRID_WORK2]);
+                         s->last_engine == 3 ? s->d_item_form : nullptr, (float)s->tune.v[MT_TUNE_HYBRID_WORK1], (float)s->tune.v[MT_TUNE_HYBRID_WORK2], (float)s->tune.v[MT_TUNE_FORECAST_STEP]);
       if (hybrid) {
         const double *tv = s->tune.v;
         const float k = reproject ? (float)(tv[MT_TUNE_QUAD_SHARE_MOVING] / tv[MT_TUNE_QUAD_SHARE]) : 1.0f;  // a re-projected forecast is cut more eagerly

@@ -249,7 +249,8 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScen
 // machine (whole / as quarters: bit 31 of its cost word, as ever), 2 / 3 by the ray pool as quarters / cells, whose
 // summed costs are scaled to the state machine's whole-block scale by wq / wc.
 __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, int radius, int pool, float w1,
-                                float w2, unsigned unseen, float blend, const unsigned char *form, float wq, float wc) {
+                                float w2, unsigned unseen, float blend, const unsigned char *form, float wq, float wc,
+                                float step_px) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_items) return;
   auto cost_of = [&](unsigned word, unsigned idx) -> unsigned {
@@ -321,7 +322,7 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
       unsigned mxc = 0u;
       for (int dy = -radius; dy <= radius; dy++) {
         for (int dx = -radius; dx <= radius; dx++) {
-          const double qx = ox + 8.0 * dx, qy = oy + 8.0 * dy;
+          const double qx = ox + (double)step_px * dx, qy = oy + (double)step_px * dy;
           if (qx < P.region_x || qy < P.region_y || qx >= P.region_x + P.region_w || qy >= P.region_y + P.region_h) continue;
           const int tx = ((int)qx - P.region_x) / P.tile_w, ty = ((int)qy - P.region_y) / P.tile_h;
           const int t = ty * P.tiles_x + tx;

@@ -14,9 +14,12 @@ using math3d::V3D;
 
 class Texture {
  public:
-  // Dependency-free loader: binary PPM (P6), 24/32-bit BMP, uncompressed
+  // Dependency-free loaders, chosen by the file's magic bytes: PNG (8-bit,
+  // non-interlaced; own inflate), baseline JPEG (libjpeg's default integer
+  // arithmetic restated), binary PPM (P6), 24/32-bit BMP, uncompressed
   // true-colour TGA.  (The reference decodes through SDL2_image,
-  // texture.cc:60-109, which this build does not link.)  Colour = byte/255.0.
+  // texture.cc:60-109, which this build does not link.)  Colour = byte/255.0,
+  // texture.cc:100-104.
   static Texture* LoadFromFile(const char* fname);
 
   size_t width = 0;
