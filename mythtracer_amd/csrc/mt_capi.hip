@@ -833,6 +833,89 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
       h.planes[6 + k] = r.hi[k];
     }
   }
+  // Spatially sorted copies of the long lists (DevScene::ll_*): a median-split tree over the boxes' centres, cut on
+  // the longest axis of the centres' extent at a multiple of 64 (16 below 64) entries, so that 16 consecutive entries
+  // -- one block box -- and 64 -- one super box -- are spatial neighbours.  Every list is padded to a multiple of 64.
+  std::vector<int32_t> ll_tri;
+  std::vector<float> ll_box, ll_grp, ll_sup;
+  {
+    const float inv[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    std::vector<int32_t> order, work;
+    for (int i = 0; i < nn; i++) {
+      HsRec &h = hsr[i];
+      h.ll_begin = -1;
+      const int pb = recs[i].prim_begin, pc = recs[i].prim_count;
+      if (pc <= kHsShortList) continue;
+      order.resize((size_t)pc);
+      for (int k = 0; k < pc; k++) order[(size_t)k] = pb + k;
+      // iterative median split over [lo, hi) of `order`
+      std::vector<std::pair<int, int>> todo{{0, pc}};
+      while (!todo.empty()) {
+        const int lo = todo.back().first, hi = todo.back().second;
+        todo.pop_back();
+        const int n = hi - lo;
+        if (n <= 16) continue;
+        double cmin[3] = {1e300, 1e300, 1e300}, cmax[3] = {-1e300, -1e300, -1e300};
+        for (int k = lo; k < hi; k++) {
+          const double *b = d->tri_aabb + (size_t)order[(size_t)k] * 6;
+          for (int a = 0; a < 3; a++) {
+            const double c = b[a] * 0.5 + b[3 + a] * 0.5;
+            cmin[a] = std::min(cmin[a], c);
+            cmax[a] = std::max(cmax[a], c);
+          }
+        }
+        int ax = 0;
+        for (int a = 1; a < 3; a++) {
+          if (cmax[a] - cmin[a] > cmax[ax] - cmin[ax]) ax = a;
+        }
+        const int unit = n > 64 ? 64 : 16;
+        int left = ((n / 2 + unit - 1) / unit) * unit;
+        if (left >= n) left = n - (n % unit ? n % unit : unit);
+        if (left <= 0 || left >= n) continue;
+        auto key = [&](int32_t t) {
+          const double *b = d->tri_aabb + (size_t)t * 6;
+          return b[ax] * 0.5 + b[3 + ax] * 0.5;
+        };
+        std::nth_element(order.begin() + lo, order.begin() + lo + left, order.begin() + hi,
+                         [&](int32_t x, int32_t y) { const double kx = key(x), ky = key(y); return kx < ky || (kx == ky && x < y); });
+        todo.push_back({lo, lo + left});
+        todo.push_back({lo + left, hi});
+      }
+      h.ll_begin = (int32_t)ll_tri.size();
+      const int padded = ((pc + 63) / 64) * 64;
+      for (int k = 0; k < padded; k++) {
+        if (k < pc) {
+          const int32_t t = order[(size_t)k];
+          ll_tri.push_back(t);
+          for (int q = 0; q < 6; q++) ll_box.push_back((float)d->tri_aabb[(size_t)t * 6 + q]);
+        } else {
+          ll_tri.push_back(-1);
+          for (int q = 0; q < 6; q++) ll_box.push_back(inv[q]);
+        }
+      }
+    }
+    auto unions = [&](const std::vector<float> &src, size_t per, std::vector<float> *dst) {
+      const size_t n = src.size() / 6;
+      for (size_t b = 0; b < n; b += per) {
+        float u[6] = {inv[0], inv[1], inv[2], inv[3], inv[4], inv[5]};
+        for (size_t j = b; j < std::min(b + per, n); j++) {
+          if (!(src[j * 6] <= src[j * 6 + 3])) continue;  // padding (inverted)
+          for (int q = 0; q < 3; q++) {
+            u[q] = std::min(u[q], src[j * 6 + q]);
+            u[3 + q] = std::max(u[3 + q], src[j * 6 + 3 + q]);
+          }
+        }
+        for (int q = 0; q < 6; q++) dst->push_back(u[q]);
+      }
+    };
+    unions(ll_box, 16, &ll_grp);
+    unions(ll_grp, 4, &ll_sup);
+    // look-ahead padding of the scalar-stream scans (four boxes ahead)
+    ll_tri.resize(ll_tri.size() + 64, -1);
+    ll_box.resize(ll_box.size() + 64 * 6, 0.0f);
+    ll_grp.resize(ll_grp.size() + 16 * 6, 0.0f);
+    ll_sup.resize(ll_sup.size() + 16 * 6, 0.0f);
+  }
   // Second level (mt_device.h kSuperBlocks): one fp32 union box per 8 consecutive blocks, for the long lists.
   std::vector<float> supers;
   {
@@ -856,6 +939,10 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   if ((rc = upload(s, supers.data(), supers.size(), &s->dev.sup_aabb32)) != MT_OK) return rc;
   if ((rc = upload(s, subs.data(), subs.size(), &s->dev.sub_aabb32)) != MT_OK) return rc;
   if ((rc = upload(s, hsr.data(), hsr.size(), &s->dev.hs_rec)) != MT_OK) return rc;
+  if ((rc = upload(s, ll_tri.data(), ll_tri.size(), &s->dev.ll_tri)) != MT_OK) return rc;
+  if ((rc = upload(s, ll_box.data(), ll_box.size(), &s->dev.ll_aabb32)) != MT_OK) return rc;
+  if ((rc = upload(s, ll_grp.data(), ll_grp.size(), &s->dev.ll_grp32)) != MT_OK) return rc;
+  if ((rc = upload(s, ll_sup.data(), ll_sup.size(), &s->dev.ll_sup32)) != MT_OK) return rc;
   if ((rc = upload(s, recs.data(), recs.size(), &s->dev.nodes)) != MT_OK) return rc;
   const size_t nt = (size_t)d->n_tris;
   {

@@ -72,8 +72,8 @@ struct HsRec {
   float own[6];
   uint8_t kid_count[8];  // prim_count of the children that are "short leaves" (kid_leaf), else 0
   double planes[9];      // lo xyz, centre xyz, hi xyz (NodeRec): the children's exact boxes
-  int32_t kid_leaf;      // bit c: child c is a leaf with 1..kHsLeafTris triangles -- its list is scanned from the parent's step
-  int32_t pad;
+  int32_t kid_leaf;      // bit c: child c is a leaf with 1..kHsLeafTris triangles (unused by the walk as shipped)
+  int32_t ll_begin;      // own list longer than kHsShortList: its position in the spatially sorted copy (DevScene::ll_*), else -1
   int32_t kid_begin[8];  // prim_begin of the children
 };
 static_assert(sizeof(HsRec) == 352, "HsRec must be 352 bytes");
@@ -98,6 +98,18 @@ struct DevScene {
   const float *sup_aabb32;   // fp32 union box of each run of kSuperBlocks consecutive blocks (long lists)
   const float *sub_aabb32;   // per node: fp32 union box of all triangles in its subtree
   const HsRec *hs_rec;       // per node (hit-set traversal)
+  // Spatially SORTED copies of the long lists (more than kHsShortList triangles: the root's 1 550, its children's
+  // 600-900 ...), used by the hit-set walk only.  The reference scans a node's list in list order and lets the later
+  // of two equally distant hits win (octtree.cc:186-195); for rays whose Moeller-Trumbore distances cannot be NaN that
+  // fold is the minimum under (distance ascending, list position descending), whatever the order of evaluation -- so
+  // the CULLING structure over a list is free: here the list's triangles in the order of a median-split tree over
+  // their boxes, 16 consecutive ones under one fp32 union box, 4 such blocks under another.  Every list starts at a
+  // multiple of 64 entries and is padded to one (ll_tri = -1, inverted boxes).  ll_tri = the triangle's stream index
+  // (= its list position: the tie rule's rank).
+  const int32_t *ll_tri;
+  const float *ll_aabb32;    // 6 per entry
+  const float *ll_grp32;     // 6 per 16 entries
+  const float *ll_sup32;     // 6 per 64 entries
   double bmax[3];            // max |coordinate| of any triangle box, per axis
   const double *tri_vertex;  // 9 per triangle
   const double *tri_normal;  // 9 per triangle

@@ -1401,6 +1401,10 @@ __device__ __forceinline__ DevScene scan_ctx_self(const DevScene *self) {
   S.grp_aabb32 = G->grp_aabb32;
   S.sup_aabb32 = G->sup_aabb32;
   S.tri_vertex = G->tri_vertex;
+  S.ll_tri = G->ll_tri;
+  S.ll_aabb32 = G->ll_aabb32;
+  S.ll_grp32 = G->ll_grp32;
+  S.ll_sup32 = G->ll_sup32;
   S.self = uniform_ptr(self);
   return S;
 }
@@ -1563,6 +1567,116 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
   return o;
 }
 
+
+// ---- long list through its spatially sorted copy (DevScene::ll_*; hit-set walk, NaN-free rays only) -----------------
+// lb = the list's first entry in the sorted copy, n = its padded length (multiples of 64).  Super boxes (one per 64
+// entries) -> block boxes of the live supers -> the fp32 boxes of the live blocks' entries mark per-lane candidates ->
+// every lane resolves its candidates (exact fp64 box, Moeller-Trumbore) in ANY order and keeps the minimum under
+// (distance, -stream index): the reference's fold (octtree.cc:177-196) for distances that cannot be NaN.
+template <bool STATS>
+__device__ __forceinline__ void resolve_sorted(const DevScene &S, const RayRegs &r, int base, unsigned long long &cand,
+                                               int &best, double &best_t, LaneStats &st) {
+  const MT_CONST int32_t *lt = as_const(S.ll_tri);
+  for (int guard = 0; guard < 64 && __ballot(cand != 0ull) != 0ull; guard++) {
+    if (cand != 0ull) {
+      const int t = lt[base + __builtin_ctzll(cand)];
+      cand &= cand - 1ull;
+      if (t >= 0) {  // (padding entries hold inverted boxes and are never marked; belt and braces)
+        const double *ep = S.tri_aabb + (size_t)t * 6;
+        const double *vp = S.tri_vertex + (size_t)t * 9;
+        const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
+        const double v[9] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
+        if (STATS) st.v[ST_BYTES_VECTOR] += 124u;
+        if (slab_pass_lane<false>(e, r)) {
+          if (STATS) st.v[ST_MT_TESTS]++;
+          double tt;
+          if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
+            if (best < 0 || tt < best_t || (tt == best_t && t > best)) {
+              best = t;
+              best_t = tt;
+            }
+          }
+        }
+      }
+    }
+  }
+  cand = 0ull;
+}
+
+template <int OCT, bool STATS>
+__device__ __attribute__((noinline)) ScanOut scan_sorted_call(const DevScene *self, int lb, int n, MT_RAY_PARAMS,
+                                                              MT_F32_PARAMS) {
+  MT_RAY_FROM_PARAMS(r);
+  MT_F32_FROM_PARAMS(f);
+  self = uniform_ptr(self);
+  const DevScene S = scan_ctx_self(self);
+  lb = uniform_i32(lb);
+  n = uniform_i32(n);
+  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  ScanOut o{-1, 0.0, 0u};
+  LaneStats st;
+  st.clear();
+  const MT_CONST float *sup = as_const(S.ll_sup32) + (size_t)(lb / 64) * 6;
+  const MT_CONST float *grp = as_const(S.ll_grp32) + (size_t)(lb / 16) * 6;
+  const int n_sup = n / 64;
+  for (int s0 = 0; s0 < n_sup; s0 += 64) {  // (64 supers = 4 096 entries per round)
+    const int ns = (n_sup - s0) < 64 ? (n_sup - s0) : 64;
+    unsigned long long sl = group_live_mask<OCT>(sup + (size_t)s0 * 6, ns, f);
+    if (STATS) st.bytes_scalar += 96u * (unsigned)((ns + 3) / 4 + 1);
+    while (sl != 0ull) {
+      const int si = s0 + __builtin_ctzll(sl);
+      sl &= sl - 1ull;
+      unsigned long long bl = group_live_mask<OCT>(grp + (size_t)si * 4 * 6, 4, f);
+      if (STATS) st.bytes_scalar += 96u * 2u;
+      if (bl == 0ull) continue;
+      // the live blocks of this super: their entries' fp32 boxes, four per scalar fetch; candidates of the super's 64
+      // entries in one word
+      unsigned long long cand = 0ull;
+      const int base = lb + si * 64;
+      const MT_CONST float *tb = as_const(S.ll_aabb32) + (size_t)base * 6;
+      while (bl != 0ull) {
+        const int b = __builtin_ctzll(bl);
+        bl &= bl - 1ull;
+        QuadRegs A, B;
+        const MT_CONST float *p = tb + (size_t)b * 16 * 6;
+        issue_quad(A, p);
+        await_quad(A);
+        issue_quad(B, p + 24);
+        mark_quad<OCT>(f, A, 0, 16, b * 16, lane, cand);
+        await_quad(B);
+        issue_quad(A, p + 48);
+        mark_quad<OCT>(f, B, 4, 16, b * 16 + 4, lane, cand);
+        await_quad(A);
+        issue_quad(B, p + 72);
+        mark_quad<OCT>(f, A, 8, 16, b * 16 + 8, lane, cand);
+        await_quad(B);
+        mark_quad<OCT>(f, B, 12, 16, b * 16 + 12, lane, cand);
+        if (STATS) st.bytes_scalar += 96u * 4u;
+      }
+      if (__ballot(cand != 0ull) != 0ull) resolve_sorted<STATS>(S, r, base, cand, o.best, o.best_t, st);
+    }
+  }
+  o.mt_tests = st.v[ST_MT_TESTS];
+  o.bytes_v = st.v[ST_BYTES_VECTOR];
+  o.bytes_s = st.bytes_scalar;
+  return o;
+}
+
+template <bool STATS>
+__device__ __forceinline__ ScanOut scan_sorted_dispatch(const DevScene &S, int oct, int lb, int n, const RayRegs &r,
+                                                        const Filter32 &f) {
+  switch (oct) {
+    case 0: return scan_sorted_call<0, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+    case 1: return scan_sorted_call<1, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+    case 2: return scan_sorted_call<2, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+    case 3: return scan_sorted_call<3, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+    case 4: return scan_sorted_call<4, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+    case 5: return scan_sorted_call<5, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+    case 6: return scan_sorted_call<6, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+    case 7: return scan_sorted_call<7, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+    default: return scan_sorted_call<8, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
+  }
+}
 
 template <int MODE, int OCT, bool STATS>
 __device__ __attribute__((noinline)) ScanOut scan_exact_call(const double *b64, const double *vtx, int pb,
@@ -1904,8 +2018,14 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   // is closed when its last child is done.  Nodes the reference would not have
   // reached (behind its early exit) may be looked at; that changes the work,
   // not the result.
+  // (tame: magnitudes for which no Moeller-Trumbore distance can be NaN or infinite -- |d| <= 2^100, |o| and every
+  // coordinate of the scene <= 2^200: all intermediate products stay below 2^700 -- so that a list's hits may be folded
+  // in any order, scan_sorted_call)
+  const bool tame = __builtin_fabs(dx) <= 0x1p100 && __builtin_fabs(dy) <= 0x1p100 && __builtin_fabs(dz) <= 0x1p100 &&
+                    __builtin_fabs(ox) <= 0x1p200 && __builtin_fabs(oy) <= 0x1p200 && __builtin_fabs(oz) <= 0x1p200;
   bool hs_done = false;
-  if (cull && S.force_mode == 0 && S.tree_depth <= kHsMaxDepth && S.n_tris < (1 << 28)) {
+  if (cull && S.force_mode == 0 && S.tree_depth <= kHsMaxDepth && S.n_tris < (1 << 28) &&
+      S.bmax[0] <= 0x1p200 && S.bmax[1] <= 0x1p200 && S.bmax[2] <= 0x1p200 && __ballot(want && !tame) == 0ull) {
     hs_done = true;
     const int L = S.tree_depth > 1 ? S.tree_depth - 1 : 0;  // levels that can hold a node with children
     MT_LDS double *const h_own_t = (MT_LDS double *)(uintptr_t)stk.base;  // [L][64] own list's best distance
@@ -2251,7 +2371,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           // (the triangle-parallel scan of the ordered descent for a handful of lanes was 1.3 % slower here)
           ScanOut o{-1, 0.0, 0u};
           if (in_list) {
-            o = scan_filtered_dispatch<STATS, true>(S, oct, blocks_ok ? S.grp_aabb32 : nullptr, pb, pc, r, f32);
+            // (every list that comes here is longer than kHsShortList: it has a spatially sorted copy)
+            o = scan_sorted_dispatch<STATS>(S, oct, uniform_i32(ri[79]), ((pc + 63) >> 6) << 6, r, f32);
             if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
           }
           if (in_list) {
