@@ -838,6 +838,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   // -- one block box -- and 64 -- one super box -- are spatial neighbours.  Every list is padded to a multiple of 64.
   std::vector<int32_t> ll_tri;
   std::vector<float> ll_box, ll_grp, ll_sup;
+  std::vector<double> ll_exact;
   {
     const float inv[6] = {3.0e38f, 3.0e38f, 3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
     std::vector<int32_t> order, work;
@@ -888,9 +889,12 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
           const int32_t t = order[(size_t)k];
           ll_tri.push_back(t);
           for (int q = 0; q < 6; q++) ll_box.push_back((float)d->tri_aabb[(size_t)t * 6 + q]);
+          for (int q = 0; q < 6; q++) ll_exact.push_back(d->tri_aabb[(size_t)t * 6 + q]);
+          for (int q = 0; q < 9; q++) ll_exact.push_back(d->tri_vertex[(size_t)t * 9 + q]);
         } else {
           ll_tri.push_back(-1);
           for (int q = 0; q < 6; q++) ll_box.push_back(inv[q]);
+          for (int q = 0; q < 15; q++) ll_exact.push_back(0.0);
         }
       }
     }
@@ -913,6 +917,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     // look-ahead padding of the scalar-stream scans (four boxes ahead)
     ll_tri.resize(ll_tri.size() + 64, -1);
     ll_box.resize(ll_box.size() + 64 * 6, 0.0f);
+    ll_exact.resize(ll_exact.size() + 15, 0.0);
     ll_grp.resize(ll_grp.size() + 16 * 6, 0.0f);
     ll_sup.resize(ll_sup.size() + 16 * 6, 0.0f);
   }
@@ -941,6 +946,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   if ((rc = upload(s, hsr.data(), hsr.size(), &s->dev.hs_rec)) != MT_OK) return rc;
   if ((rc = upload(s, ll_tri.data(), ll_tri.size(), &s->dev.ll_tri)) != MT_OK) return rc;
   if ((rc = upload(s, ll_box.data(), ll_box.size(), &s->dev.ll_aabb32)) != MT_OK) return rc;
+  if ((rc = upload(s, ll_exact.data(), ll_exact.size(), &s->dev.ll_exact)) != MT_OK) return rc;
   if ((rc = upload(s, ll_grp.data(), ll_grp.size(), &s->dev.ll_grp32)) != MT_OK) return rc;
   if ((rc = upload(s, ll_sup.data(), ll_sup.size(), &s->dev.ll_sup32)) != MT_OK) return rc;
   if ((rc = upload(s, recs.data(), recs.size(), &s->dev.nodes)) != MT_OK) return rc;

@@ -79,7 +79,7 @@ struct HsRec {
 static_assert(sizeof(HsRec) == 352, "HsRec must be 352 bytes");
 constexpr int kHsRecLanes = 22;   // 16 bytes per lane
 #ifndef MT_HS_SHORT
-#define MT_HS_SHORT 64
+#define MT_HS_SHORT 32
 #endif
 constexpr int kHsShortList = MT_HS_SHORT;  // own lists up to this length are scanned from LDS (64 fp32 boxes staged behind the frames; one candidate bit each)
 constexpr int kHsLeafTris = 16;   // 16 fp32 boxes = 384 bytes = 24 lanes of one LDS-DMA instruction
@@ -107,6 +107,7 @@ struct DevScene {
   // multiple of 64 entries and is padded to one (ll_tri = -1, inverted boxes).  ll_tri = the triangle's stream index
   // (= its list position: the tie rule's rank).
   const int32_t *ll_tri;
+  const double *ll_exact;    // 15 per entry: the triangle's fp64 box (6) and vertices (9), for the candidates
   const float *ll_aabb32;    // 6 per entry
   const float *ll_grp32;     // 6 per 16 entries
   const float *ll_sup32;     // 6 per 64 entries

@@ -1402,6 +1402,7 @@ __device__ __forceinline__ DevScene scan_ctx_self(const DevScene *self) {
   S.sup_aabb32 = G->sup_aabb32;
   S.tri_vertex = G->tri_vertex;
   S.ll_tri = G->ll_tri;
+  S.ll_exact = G->ll_exact;
   S.ll_aabb32 = G->ll_aabb32;
   S.ll_grp32 = G->ll_grp32;
   S.ll_sup32 = G->ll_sup32;
@@ -1579,13 +1580,15 @@ __device__ __forceinline__ void resolve_sorted(const DevScene &S, const RayRegs 
   const MT_CONST int32_t *lt = as_const(S.ll_tri);
   for (int guard = 0; guard < 64 && __ballot(cand != 0ull) != 0ull; guard++) {
     if (cand != 0ull) {
-      const int t = lt[base + __builtin_ctzll(cand)];
+      const int pos = base + __builtin_ctzll(cand);
       cand &= cand - 1ull;
+      const int t = lt[pos];
+      // exact box and vertices come from the sorted copy too (15 doubles per entry): one round trip per candidate,
+      // no dependence on the index load
+      const double *ep = S.ll_exact + (size_t)pos * 15;
+      const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
+      const double v[9] = {ep[6], ep[7], ep[8], ep[9], ep[10], ep[11], ep[12], ep[13], ep[14]};
       if (t >= 0) {  // (padding entries hold inverted boxes and are never marked; belt and braces)
-        const double *ep = S.tri_aabb + (size_t)t * 6;
-        const double *vp = S.tri_vertex + (size_t)t * 9;
-        const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
-        const double v[9] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
         if (STATS) st.v[ST_BYTES_VECTOR] += 124u;
         if (slab_pass_lane<false>(e, r)) {
           if (STATS) st.v[ST_MT_TESTS]++;
@@ -1619,16 +1622,29 @@ __device__ __attribute__((noinline)) ScanOut scan_sorted_call(const DevScene *se
   const MT_CONST float *sup = as_const(S.ll_sup32) + (size_t)(lb / 64) * 6;
   const MT_CONST float *grp = as_const(S.ll_grp32) + (size_t)(lb / 16) * 6;
   const int n_sup = n / 64;
-  for (int s0 = 0; s0 < n_sup; s0 += 64) {  // (64 supers = 4 096 entries per round)
-    const int ns = (n_sup - s0) < 64 ? (n_sup - s0) : 64;
-    unsigned long long sl = group_live_mask<OCT>(sup + (size_t)s0 * 6, ns, f);
-    if (STATS) st.bytes_scalar += 96u * (unsigned)((ns + 3) / 4 + 1);
-    while (sl != 0ull) {
-      const int si = s0 + __builtin_ctzll(sl);
-      sl &= sl - 1ull;
-      unsigned long long bl = group_live_mask<OCT>(grp + (size_t)si * 4 * 6, 4, f);
-      if (STATS) st.bytes_scalar += 96u * 2u;
-      if (bl == 0ull) continue;
+  for (int s0 = 0; s0 < n_sup; s0 += 16) {  // (16 supers = 64 blocks = 1 024 entries per round)
+    const int ns = (n_sup - s0) < 16 ? (n_sup - s0) : 16;
+    // which blocks of this round may some lane hit?  Short rounds (fewer than kSuperMin blocks): the block boxes
+    // directly, one dependent fetch fewer; else the super boxes first and the block boxes of the live supers
+    unsigned long long live = 0ull;
+    if (ns * 4 < kSuperMin) {
+      live = group_live_mask<OCT>(grp + (size_t)s0 * 4 * 6, ns * 4, f);
+      if (STATS) st.bytes_scalar += 96u * (unsigned)(ns + 1);
+    } else {
+      unsigned long long sl = group_live_mask<OCT>(sup + (size_t)s0 * 6, ns, f);
+      if (STATS) st.bytes_scalar += 96u * (unsigned)((ns + 3) / 4 + 1);
+      while (sl != 0ull) {
+        const int sj = __builtin_ctzll(sl);
+        sl &= sl - 1ull;
+        live |= group_live_mask<OCT>(grp + (size_t)(s0 + sj) * 4 * 6, 4, f) << (4 * sj);
+        if (STATS) st.bytes_scalar += 96u * 2u;
+      }
+    }
+    while (live != 0ull) {
+      const int sj = __builtin_ctzll(live) >> 2;
+      const int si = s0 + sj;
+      unsigned long long bl = (live >> (4 * sj)) & 0xfull;
+      live &= ~(0xfull << (4 * sj));
       // the live blocks of this super: their entries' fp32 boxes, four per scalar fetch; candidates of the super's 64
       // entries in one word
       unsigned long long cand = 0ull;
