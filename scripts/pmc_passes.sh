@@ -1,16 +1,20 @@
 #!/bin/bash
-# rocprofv3 passes for bench.py on the GPU box (run through gpurun):
-#   bash scripts/pmc_passes.sh <tag>
-# pass 0: --kernel-trace --stats ; passes 1..n: one --pmc group each (no other
-# trace domains, as the pool requires).  Output: gpurun_out/prof_<tag>/...
+# rocprofv3 passes on the GPU box (run through gpurun):
+#   bash scripts/pmc_passes.sh <tag> <program and arguments, python3 first>
+# e.g.  bash scripts/pmc_passes.sh r03 python3 bench.py --steps 8 --warmup 4 --no-cpu-baseline --no-extras
+#       bash scripts/pmc_passes.sh r03_cold python3 scripts/profile_run.py cold
+# pass 0: --kernel-trace --stats ; passes 1..n: one --pmc group each (no other trace domains, as the pool requires;
+# the program itself follows `--` directly).  Output: gpurun_out/prof_<tag>/...
 set -e
-TAG=${1:-r01}
+TAG=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
+PROG="$1"; shift
+ARGS=()
+for a in "$@"; do case "$a" in /*|-*) ARGS+=("$a");; *) if [ -e "$ROOT/$a" ]; then ARGS+=("$ROOT/$a"); else ARGS+=("$a"); fi;; esac; done
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras"
-timeout -k 10 150 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $BENCH > "$OUT/stats.log" 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats -d "$OUT/stats" --output-format csv -- $PROG "${ARGS[@]}" > "$OUT/stats.log" 2>&1
 echo "stats done" >> "$OUT/progress.txt"
 i=0
 for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
@@ -21,10 +25,9 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
            "WRITE_SIZE" \
            "TCC_HIT_sum TCC_MISS_sum" \
            "SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
-           "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES" \
-           "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum"; do
+           "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --kernel-trace --pmc $grp -d "$OUT/pmc$i" --output-format csv -- $BENCH > "$OUT/pmc$i.log" 2>&1 || echo "pass $i ($grp) failed" >> "$OUT/failed.txt"
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp -d "$OUT/pmc$i" --output-format csv -- $PROG "${ARGS[@]}" > "$OUT/pmc$i.log" 2>&1 || echo "pass $i ($grp) failed" >> "$OUT/failed.txt"
   echo "pass $i done" >> "$OUT/progress.txt"
 done
 find "$OUT" -name "*.db" -delete 2>/dev/null || true
