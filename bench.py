@@ -237,6 +237,11 @@ def main():
     if world > 1:
         mine = torch.zeros(n_max * tiling.slot_bytes(tw, th), dtype=torch.uint8, device=dev)
         gathered = ([torch.zeros_like(mine, device=xdev) for _ in range(world)] if rank == 0 else None)
+        # the ranks' block costs of the frame just rendered, 4 bytes per 8x8 block of the whole frame: a moving
+        # camera's next frame is ordered by them (include/mythtracer_hip.h, mt_scene_export_costs_device)
+        map_w, map_h = (W + 7) // 8, (H + 7) // 8
+        cost_map = torch.zeros((map_h, map_w), dtype=torch.int32, device=dev)
+        exchange_costs = args.regime == "moving" and tw % 8 == 0 and th % 8 == 0
 
     def E():
         return torch.cuda.Event(enable_timing=True)
@@ -262,6 +267,17 @@ def main():
                 if emulate:
                     torch.cuda.synchronize()  # `slots` is a temporary here
             multi.gather_and_blit(dist, mine.to(xdev), gathered, rank, world, W, H, tw, th, blit)
+            if exchange_costs:
+                # second exchange step: every rank's costs into one map (element-wise MAX: a block belongs to one rank)
+                cost_map.zero_()
+                abi.export_costs_device(h, ctypes.c_void_p(cost_map.data_ptr()), map_w, map_h, stream)
+                if emulate:
+                    cm = cost_map.cpu()
+                    dist.all_reduce(cm, op=dist.ReduceOp.MAX)
+                    cost_map.copy_(cm)
+                else:
+                    dist.all_reduce(cost_map, op=dist.ReduceOp.MAX)
+                abi.import_costs_device(h, ctypes.c_void_p(cost_map.data_ptr()), map_w, map_h, stream)
         if i is not None:
             ev[i][2].record()
 
@@ -478,8 +494,9 @@ def main():
         }
         if world > 1:
             out["ranks_reported_by_backend"] = world
-            out["exchange_ms_device"] = {"gather_plus_blit_rank0": k_exchange_ms,
-                                         "bytes_gathered": int(n_max * tiling.slot_bytes(tw, th) * world)}
+            out["exchange_ms_device"] = {"gather_plus_blit_rank0_plus_cost_map_all_reduce": k_exchange_ms,
+                                         "bytes_gathered": int(n_max * tiling.slot_bytes(tw, th) * world),
+                                         "cost_map_bytes_all_reduced": int(map_w * map_h * 4) if exchange_costs else 0}
 
     # ---- untimed extras, one GPU only
     if world == 1 and rank == 0 and not args.no_extras:

@@ -214,6 +214,27 @@ int mt_render_frame_multi(mt_scene *const *scenes, int n_scenes,
                           int tile_w, int tile_h, int max_depth,
                           uint8_t *out_rgb, mt_stats *stats);
 
+/* Multi-GPU frames with a MOVING camera (the reference's loop turns it every
+ * frame, main_local.cc:51-76).  A launch orders its work by the block costs of
+ * the previous frame, re-projected through the camera change -- but a rank
+ * measured only its own tiles, and the old-image position of a block mostly
+ * lies in another rank's tile.  So the ranks exchange their costs, 4 bytes per
+ * 8x8 block of the frame (the path's second, tiny exchange step; the reference's
+ * master hands chunks out dynamically instead, main_net_master.cc:62-80):
+ * export writes the costs of this scene's LAST launch, on a common scale, into a
+ * frame-wide map d_map[map_h][map_w] of uint32 (map_w >= ceil(image_w / 8),
+ * map_h >= ceil(image_h / 8); only the blocks of that launch's tiles are
+ * written: zero the map first); the ranks combine their maps with an
+ * element-wise MAX (torch.distributed.all_reduce / RCCL); import hands the
+ * result to the scene, whose NEXT launch reads it wherever a re-projected
+ * forecast needs a cost (later launches fall back to the scene's own costs
+ * unless a new map is imported).  Nothing computed for a pixel depends on it.
+ * mt_render_frame_multi does the same between its replicas by itself. */
+int mt_scene_export_costs_device(mt_scene *scene, void *d_map, int map_w,
+                                 int map_h, void *stream);
+int mt_scene_import_costs_device(mt_scene *scene, const void *d_map, int map_w,
+                                 int map_h, void *stream);
+
 /* Fetches and clears the accumulated counters (kernel_ms/total_ms = 0). */
 int mt_scene_read_stats(mt_scene *scene, mt_stats *stats);
 

@@ -22,7 +22,7 @@ HIP_SYMBOLS = [
     "mt_scene_read_stats", "mt_intersect_rays", "mt_scene_set_traversal_mode",
     "mt_scene_kernel_times", "mt_scene_set_scheduling", "mt_scene_set_engine",
     "mt_scene_set_stats", "mt_set_default_engine", "mt_scene_set_tuning",
-    "mt_render_frame_multi",
+    "mt_render_frame_multi", "mt_scene_export_costs_device", "mt_scene_import_costs_device",
 ]
 
 # mt_scene_set_tuning knobs, in the order of the enum in include/mythtracer_hip.h
@@ -138,6 +138,8 @@ class HipAbi:
         L.mt_set_default_engine.argtypes = [ci]
         L.mt_scene_set_tuning.argtypes = [vp, ci, C.c_double]
         L.mt_render_frame_multi.argtypes = [vp, ci, C.POINTER(mt_sensor)] + [ci] * 5 + [vp, vp]
+        L.mt_scene_export_costs_device.argtypes = [vp, vp, ci, ci, vp]
+        L.mt_scene_import_costs_device.argtypes = [vp, vp, ci, ci, vp]
 
     def last_error(self) -> str:
         return self.lib.mt_last_error().decode(errors="replace")
@@ -292,6 +294,12 @@ class HipAbi:
                                                   tile_w, tile_h, max_depth, _ptr(rgb),
                                                   C.cast(st, C.c_void_p) if want_stats else None))
         return dict(rgb=rgb, stats=[st[i].as_dict() for i in range(n)])
+
+    def export_costs_device(self, h, d_map, map_w, map_h, stream=None):
+        self.check(self.lib.mt_scene_export_costs_device(h, d_map, map_w, map_h, stream))
+
+    def import_costs_device(self, h, d_map, map_w, map_h, stream=None):
+        self.check(self.lib.mt_scene_import_costs_device(h, d_map, map_w, map_h, stream))
 
     def set_scheduling(self, h, use_cost_history: bool):
         self.check(self.lib.mt_scene_set_scheduling(h, 1 if use_cost_history else 0))

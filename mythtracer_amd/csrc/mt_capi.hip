@@ -145,6 +145,13 @@ struct mt_scene {
   unsigned long long *d_prof = nullptr;   // -DMT_PROF build: phase cycle sums
   DevScene *d_dev = nullptr;              // device copy of `dev` (DevScene::self)
   Tuning tune;
+  // multi-GPU frames with a moving camera: every rank's costs of the previous frame (mt_scene_import_costs_device)
+  RenderParams last_P{};                  // geometry of the last launch (mt_scene_export_costs_device)
+  bool last_P_valid = false;
+  unsigned int *d_cost_map = nullptr;
+  size_t cost_map_bytes = 0;
+  int cost_map_w = 0, cost_map_h = 0;
+  unsigned long long cost_map_for_launch = ~0ull;  // the map describes the frame of launch number ... (launches_timed then)
   int tree_depth_levels = 0, n_tris_total = 0, n_nodes_total = 0;  // for MT_TUNE_PACKED_STACK
   // -DMT_DEBUG_KNOBS builds only (read from the environment once, in mt_scene_create)
   std::string dbg_item_cycles, dbg_timeline;
@@ -158,6 +165,11 @@ struct mt_scene {
   size_t multi_frame_bytes = 0;
   hipStream_t multi_stream = nullptr;
   hipEvent_t multi_done = nullptr;
+  unsigned int *d_multi_map = nullptr;    // this replica's block costs / the combined map on its way back
+  size_t multi_map_bytes = 0;
+  unsigned int *d_multi_maps = nullptr;   // first replica: all replicas' maps
+  size_t multi_maps_bytes = 0;
+  hipEvent_t multi_comb_done = nullptr;
 };
 
 namespace {
@@ -358,6 +370,10 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   P.order_item = s->d_order_item;
   P.order_sub = s->d_order_sub;
   P.n_work = s->d_work + 7;
+  // the combined cost map of all ranks, if one was imported after the previous launch (else nullptr: own costs only)
+  P.cost_map = (s->d_cost_map != nullptr && s->cost_map_for_launch == s->launches_timed) ? s->d_cost_map : nullptr;
+  P.cost_map_w = s->cost_map_w;
+  P.cost_map_h = s->cost_map_h;
   if (pool_engine || hybrid) {
     int rc = ensure_bytes((void **)&s->d_pool, &s->pool_bytes, pool_stride * waves);
     if (rc != MT_OK) return rc;
@@ -495,6 +511,8 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   HIP_TRY(hipEventRecord(ek[2], stream));
   HIP_TRY(hipGetLastError());
   s->launches_timed++;
+  s->last_P = P;
+  s->last_P_valid = true;
   s->cost_signature = sig;  // the costs now in d_item_cost belong to this geometry and engine
   s->last_engine = engine;
   s->cost_sensor = *sensor;
@@ -610,12 +628,16 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_item_forecast) (void)hipFree(s->d_item_forecast);
   if (s->d_item_forms) (void)hipFree(s->d_item_forms);
   if (s->d_item_form) (void)hipFree(s->d_item_form);
+  if (s->d_cost_map) (void)hipFree(s->d_cost_map);
   if (s->d_order_item) (void)hipFree(s->d_order_item);
   if (s->d_order_sub) (void)hipFree(s->d_order_sub);
   if (s->d_rgb) (void)hipFree(s->d_rgb);
   if (s->d_debug) (void)hipFree(s->d_debug);
   if (s->d_lights) (void)hipFree(s->d_lights);
   if (s->d_multi_tiles) (void)hipFree(s->d_multi_tiles);
+  if (s->d_multi_map) (void)hipFree(s->d_multi_map);
+  if (s->d_multi_maps) (void)hipFree(s->d_multi_maps);
+  if (s->multi_comb_done) (void)hipEventDestroy(s->multi_comb_done);
   if (s->d_multi_gather) (void)hipFree(s->d_multi_gather);
   if (s->d_multi_frame) (void)hipFree(s->d_multi_frame);
   if (s->multi_stream) (void)hipStreamDestroy(s->multi_stream);
@@ -1125,6 +1147,38 @@ int mt_scene_set_tuning(mt_scene *s, int knob, double value) {
   return MT_OK;
 }
 
+int mt_scene_export_costs_device(mt_scene *s, void *d_map, int map_w, int map_h, void *stream) {
+  if (!s || !d_map || map_w <= 0 || map_h <= 0) return fail(MT_ERR_ARG, "bad cost map arguments");
+  if (!s->last_P_valid) return fail(MT_ERR_ARG, "no launch to export the costs of");
+  const RenderParams &P = s->last_P;
+  if (map_w < (P.image_w + 7) / 8 || map_h < (P.image_h + 7) / 8 || (P.tile_w & 7) || (P.tile_h & 7) || (P.region_x & 7) || (P.region_y & 7)) {
+    return fail(MT_ERR_ARG, "cost map smaller than the image's 8x8 blocks, or tiles not on the 8-pixel grid");
+  }
+  HIP_TRY(hipSetDevice(s->device));
+  if (P.n_items == 0) return MT_OK;
+  const double *tv = s->tune.v;
+  const bool hy = s->last_engine == 3;
+  hipLaunchKernelGGL(export_costs_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, s->last_engine,
+                     (float)(hy ? tv[MT_TUNE_HYBRID_WORK1] : tv[MT_TUNE_POOL_PIECE_WORK1]),
+                     (float)(hy ? tv[MT_TUNE_HYBRID_WORK2] : tv[MT_TUNE_POOL_PIECE_WORK2]),
+                     (const unsigned char *)s->d_item_form, (unsigned *)d_map, map_w, map_h);
+  HIP_TRY(hipGetLastError());
+  return MT_OK;
+}
+
+int mt_scene_import_costs_device(mt_scene *s, const void *d_map, int map_w, int map_h, void *stream) {
+  if (!s || !d_map || map_w <= 0 || map_h <= 0) return fail(MT_ERR_ARG, "bad cost map arguments");
+  HIP_TRY(hipSetDevice(s->device));
+  const size_t bytes = (size_t)map_w * (size_t)map_h * sizeof(unsigned);
+  int rc = ensure_bytes((void **)&s->d_cost_map, &s->cost_map_bytes, bytes);
+  if (rc != MT_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(s->d_cost_map, d_map, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  s->cost_map_w = map_w;
+  s->cost_map_h = map_h;
+  s->cost_map_for_launch = s->launches_timed;  // valid for the NEXT launch only
+  return MT_OK;
+}
+
 int mt_scene_read_stats(mt_scene *s, mt_stats *st) {
   if (!s || !st) return fail(MT_ERR_ARG, "NULL argument");
   HIP_TRY(hipSetDevice(s->device));
@@ -1310,6 +1364,11 @@ int mt_render_frame_multi(mt_scene *const *scenes, int n, const mt_sensor *senso
   const long long n_max = (tiles_total + n - 1) / n;
   auto tiles_of = [&](int r) -> int { return r >= tiles_total ? 0 : (int)((tiles_total - r + n - 1) / n); };
   mt_scene *root = scenes[0];
+  // the replicas' block costs are exchanged after every frame (mt_scene_export_costs_device: a moving camera's next
+  // frame is ordered by the costs of ALL tiles of this one)
+  const bool share_costs = n > 1 && (tile_w & 7) == 0 && (tile_h & 7) == 0;
+  const int map_w = (image_w + 7) / 8, map_h = (image_h + 7) / 8;
+  const size_t map_bytes = (size_t)map_w * map_h * sizeof(unsigned);
 
   // ---- phase 1: every replica renders its tiles
   std::vector<int> rcs((size_t)n, MT_OK);
@@ -1331,6 +1390,11 @@ int mt_render_frame_multi(mt_scene *const *scenes, int n, const mt_sensor *senso
                           max_depth, s->d_multi_tiles, nullptr, s->multi_stream);
       s->stats_enabled = counters_were;
       if (rc2 != MT_OK) return rc2;
+      if (share_costs) {
+        if ((rc2 = ensure_bytes((void **)&s->d_multi_map, &s->multi_map_bytes, map_bytes)) != MT_OK) return rc2;
+        HIP_TRY(hipMemsetAsync(s->d_multi_map, 0, map_bytes, s->multi_stream));
+        if (tiles_of(r) > 0 && (rc2 = mt_scene_export_costs_device(s, s->d_multi_map, map_w, map_h, s->multi_stream)) != MT_OK) return rc2;
+      }
       HIP_TRY(hipEventRecord(s->multi_done, s->multi_stream));
       return MT_OK;
     };
@@ -1393,6 +1457,30 @@ int mt_render_frame_multi(mt_scene *const *scenes, int n, const mt_sensor *senso
     }
   }
   HIP_TRY(hipMemcpyAsync(out_rgb, root->d_multi_frame, (size_t)image_w * image_h * 3, hipMemcpyDeviceToHost, root->multi_stream));
+  if (share_costs) {
+    // all maps to the first replica's device, element-wise maximum, and back to every replica -- behind the frame's
+    // copy on the same streams, so that it is done before the next call's launches without anybody waiting for it
+    if ((rc = ensure_bytes((void **)&root->d_multi_maps, &root->multi_maps_bytes, (size_t)n * map_bytes)) != MT_OK) return rc;
+    if (!root->multi_comb_done) HIP_TRY(hipEventCreateWithFlags(&root->multi_comb_done, hipEventDisableTiming));
+    for (int r = 0; r < n; r++) {
+      mt_scene *s = scenes[r];
+      unsigned *dst = root->d_multi_maps + (size_t)r * map_w * map_h;
+      if (s->device != root->device) HIP_TRY(hipMemcpyPeerAsync(dst, root->device, s->d_multi_map, s->device, map_bytes, root->multi_stream));
+      else HIP_TRY(hipMemcpyAsync(dst, s->d_multi_map, map_bytes, hipMemcpyDeviceToDevice, root->multi_stream));
+    }
+    hipLaunchKernelGGL(max_maps_kernel, dim3(256), dim3(256), 0, root->multi_stream, root->d_multi_maps, n, (size_t)map_w * map_h);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(root->multi_comb_done, root->multi_stream));
+    for (int r = 0; r < n; r++) {
+      mt_scene *s = scenes[r];
+      HIP_TRY(hipSetDevice(s->device));
+      HIP_TRY(hipStreamWaitEvent(s->multi_stream, root->multi_comb_done, 0));
+      if (s->device != root->device) HIP_TRY(hipMemcpyPeerAsync(s->d_multi_map, s->device, root->d_multi_maps, root->device, map_bytes, s->multi_stream));
+      else HIP_TRY(hipMemcpyAsync(s->d_multi_map, root->d_multi_maps, map_bytes, hipMemcpyDeviceToDevice, s->multi_stream));
+      if ((rc = mt_scene_import_costs_device(s, s->d_multi_map, map_w, map_h, s->multi_stream)) != MT_OK) return rc;
+    }
+    HIP_TRY(hipSetDevice(root->device));
+  }
   HIP_TRY(hipStreamSynchronize(root->multi_stream));
   const double total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   // every replica's launch has completed (the root's stream waited for their events); its device status and counters

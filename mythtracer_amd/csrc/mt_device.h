@@ -212,6 +212,11 @@ struct RenderParams {
   signed char *order_sub;         // [<= 16 n_items] -1 = whole block, 0..3 = quarter, 4..19 = 2x2 cell (pool only)
   unsigned int *n_work;           // number of work units in order_item/order_sub
   unsigned long long *item_cycles;  // debug (MT_DEBUG_ITEM_CYCLES): s_memtime ticks per work item
+  // Frame-wide map of the previous frame's block costs (whole-block scale), one word per 8x8 block of the IMAGE, row
+  // major, cost_map_w words per row -- all ranks' costs combined (mt_scene_import_costs_device).  A re-projected
+  // forecast reads it instead of item_cost: the old-image position of a block mostly lies in another rank's tile.
+  const unsigned int *cost_map;
+  int32_t cost_map_w, cost_map_h;
 };
 
 // Bytes of LDS one wave needs for its traversal stack: 20-byte frames, or 16-byte

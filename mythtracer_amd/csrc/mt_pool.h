@@ -107,6 +107,20 @@ __device__ __forceinline__ PoolGeom pool_geometry(const RenderParams &P, unsigne
   return g;
 }
 
+// Does the 8x8 block at (x0, y0) hold a pixel whose primary ray (Sensor::GetRay, camera.cc:65-69) has an exactly zero
+// direction component?  (The normalisation cannot create or remove a zero.)
+__device__ inline bool block_has_zero_component_ray(const RenderParams &P, int x0, int y0) {
+  bool any = false;
+  for (int y = 0; y < 8; y++) {
+    double r[3];
+    for (int k = 0; k < 3; k++) r[k] = P.sensor.start_point[k] + P.sensor.delta_scanline[k] * (double)(y0 + y);
+    for (int x = 0; x < 8; x++) {
+      for (int k = 0; k < 3; k++) any = any || (r[k] + P.sensor.delta_pixel[k] * (double)(x0 + x)) == 0.0;
+    }
+  }
+  return any;
+}
+
 // Work fetch.  Written WITHOUT a divergent branch: every lane issues the add
 // (lane 0 adds 1, the others 0; hipcc merges them into one atomic per wave) and
 // lane 0's return value is broadcast.  The obvious form
@@ -189,7 +203,12 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void probe_kernel(DevScene 
   // the block's forecast = the largest of its four samples (they sit in four adjacent lanes)
   cost = max(cost, (unsigned)__builtin_amdgcn_update_dpp(0, (int)cost, 0xb1, 0xf, 0xf, false));  // quad_perm 1,0,3,2
   cost = max(cost, (unsigned)__builtin_amdgcn_update_dpp(0, (int)cost, 0x4e, 0xf, 0xf, false));  // quad_perm 2,3,0,1
-  if (have && which == 0) P.item_cost[item] = cost;
+  if (have && which == 0) {
+    // (a block on the pixel column or row whose primary rays have a zero direction component: among the longest)
+    const PoolGeom g0 = pool_geometry(P, item, -1, 0);
+    if (block_has_zero_component_ray(P, g0.px, g0.py)) cost = max(cost, 16000u * 30u);
+    P.item_cost[item] = cost;
+  }
 }
 
 // ---------------------------------------------------------------------------

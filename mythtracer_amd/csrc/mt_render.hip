@@ -315,7 +315,18 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
       my[k][1] = -old.start_point[k];
       ml[k][2] = -old.start_point[k];
     }
-    const double ox = det3(mx) / D, oy = det3(my) / D, lambda = det3(ml) / D;
+    double ox = det3(mx) / D, oy = det3(my) / D;
+    const double lambda = det3(ml) / D;
+    // A direction the old frame did not see, but not by much (the strip that a turning camera brings into view: up to
+    // two tiles wide at 3840 pixels): what lies just inside the old frame's edge is the better guess than the mean
+    // cost of a block -- objects continue across the edge.
+    if (lambda > 0.0) {
+      const double slack = 160.0;
+      if (ox < P.region_x && ox >= P.region_x - slack) ox = P.region_x + 0.5;
+      if (oy < P.region_y && oy >= P.region_y - slack) oy = P.region_y + 0.5;
+      if (ox >= P.region_x + P.region_w && ox < P.region_x + P.region_w + slack) ox = P.region_x + P.region_w - 0.5;
+      if (oy >= P.region_y + P.region_h && oy < P.region_y + P.region_h + slack) oy = P.region_y + P.region_h - 0.5;
+    }
     // old pixel -> old block of the SAME launch geometry (single-chunk launches and tiles alike)
     if (lambda > 0.0 && ox >= P.region_x && oy >= P.region_y && ox < P.region_x + P.region_w && oy < P.region_y + P.region_h) {
       bool any = false;
@@ -324,6 +335,17 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
         for (int dx = -radius; dx <= radius; dx++) {
           const double qx = ox + (double)step_px * dx, qy = oy + (double)step_px * dy;
           if (qx < P.region_x || qy < P.region_y || qx >= P.region_x + P.region_w || qy >= P.region_y + P.region_h) continue;
+          if (P.cost_map != nullptr) {  // every rank's costs of the old frame (0 = nobody reported that block)
+            const int mx_ = (int)qx >> 3, my_ = (int)qy >> 3;
+            if (mx_ < P.cost_map_w && my_ < P.cost_map_h) {
+              const unsigned c = P.cost_map[(size_t)my_ * P.cost_map_w + mx_];
+              if (c != 0u) {
+                mxc = max(mxc, c);
+                any = true;
+              }
+            }
+            continue;
+          }
           const int tx = ((int)qx - P.region_x) / P.tile_w, ty = ((int)qy - P.region_y) / P.tile_h;
           const int t = ty * P.tiles_x + tx;
           if (t < P.first_tile || (t - P.first_tile) % P.tile_stride != 0) continue;  // another rank's tile
@@ -338,7 +360,52 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
       if (any) best = mxc;
     }
   }
+  // A block with a primary ray that has a ZERO direction component (a camera on an axis: one pixel column or row of
+  // the frame) is among the frame's longest, whatever the old frame measured where it projects to -- the turned
+  // camera's rays there were ordinary ones.  Such rays leave the hit-set walk for the exact, lane-serial descent and
+  // pass the reference's box tests through NaN (mt_trace.h): about thirty times a block's mean cost.  Telling the
+  // scheduler so lets those blocks start first and in pieces (frames of a turning camera that pass through such a
+  // position: 9.0 -> ms at 1080p, 6.7 -> ms for the rank that owns the column at N = 8).
+  if (block_has_zero_component_ray(P, (int)px - 4, (int)py - 4)) best = max(best, unseen * 30u);
   P.item_forecast[i] = best;
+}
+
+// The block costs of the launch described by P, on the whole-block scale of the state machine, into a frame-wide
+// map (see RenderParams::cost_map): block (bx, by) of the IMAGE -> map[by * map_w + bx]; blocks of tiles that are not
+// this launch's keep what the map holds (the caller zeroes it).  engine = the engine that measured the costs (how
+// to read the words: forecast_kernel), wq1 / wq2 = the work factors of its pieces.
+__global__ void export_costs_kernel(RenderParams P, int engine, float wq1, float wq2, const unsigned char *form,
+                                    unsigned *map, int map_w, int map_h) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.n_items) return;
+  const unsigned word = P.item_cost[i];
+  float c;
+  if (engine == 2 || (engine == 3 && form[i] >= 2)) {
+    const unsigned lvl = engine == 2 ? (word >> 30) : (unsigned)(form[i] - 1);
+    c = (float)(word & 0x3fffffffu);
+    c = lvl == 1u ? c / wq1 : (lvl >= 2u ? c / wq2 : c);
+  } else {
+    c = (float)(word & 0x7fffffffu);
+    if (word >> 31) c /= 1.7f;
+  }
+  const int per_tile = P.blocks_x * P.blocks_y;
+  const int j = (int)(i / (unsigned)per_tile), b = (int)(i % (unsigned)per_tile);
+  const int tile = P.first_tile + j * P.tile_stride;
+  const int px = P.region_x + (tile % P.tiles_x) * P.tile_w + (b % P.blocks_x) * 8;
+  const int py = P.region_y + (tile / P.tiles_x) * P.tile_h + (b / P.blocks_x) * 8;
+  const int bx = px >> 3, by = py >> 3;
+  if (px >= P.region_x + P.region_w || py >= P.region_y + P.region_h || bx >= map_w || by >= map_h) return;  // (clipped edge tiles)
+  const unsigned v = (unsigned)c;
+  map[(size_t)by * map_w + bx] = v > 0u ? v : 1u;
+}
+
+// maps[0][i] = max over the n maps of maps[r][i] (mt_render_frame_multi: the replicas' cost maps combined)
+__global__ void max_maps_kernel(unsigned *maps, int n, size_t words) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned m = maps[i];
+    for (int r = 1; r < n; r++) m = max(m, maps[(size_t)r * words + i]);
+    maps[i] = m;
+  }
 }
 
 constexpr int kSchedThreads = 1024;

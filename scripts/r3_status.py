@@ -69,6 +69,54 @@ for name in (sys.argv[1:] or ["now"]):
                     per.append(float((a + b).mean()))
                 print("[%s] %-13s 4K, %d ranks: slowest %.3f ms (rank %d), fastest %.3f, mean %.3f" % (
                     name, ENG[e], world, max(per), int(np.argmax(per)), min(per), sum(per) / len(per)), flush=True)
+    if "pan" in what:
+        # the bench's regime at N ranks: the camera pans 2 degrees per frame within +-8 degrees; every rank is a scene
+        # of its own here (its cost history), frames outside, ranks inside; after every frame the ranks' cost maps are
+        # combined (MAX) and imported, as bench.py does with an all-reduce.  The N-GPU frame time is the slowest rank's.
+        W4, H4, T = 3840, 2160, 64
+        mw, mh = (W4 + 7) // 8, (H4 + 7) // 8
+        def cam_of(j):
+            j %= 16
+            tri = j if j <= 4 else (8 - j if j <= 12 else j - 16)
+            c = list(sg.ROOM_CAMERA); c[4] += 2.0 * tri
+            return c
+        s_pan = [binding.sensor(cam_of(j), W4, H4) for j in range(16)]
+        res = {}
+        for exchange in ((True, False) if os.environ.get("NOEXCHANGE") else (True,)):
+            for world in [int(x) for x in os.environ.get("WORLDS", "1,8").split(",")]:
+                hs = [abi.scene_create(flat) for _ in range(world)]
+                maps = [torch.zeros((mh, mw), dtype=torch.int32, device="cuda") for _ in range(world)]
+                comb = torch.zeros((mh, mw), dtype=torch.int32, device="cuda")
+                for hh in hs:
+                    abi.set_lights(hh, sg.ROOM_LIGHTS); abi.set_stats(hh, False)
+                geo = [tiling.rank_tiles(W4, H4, T, T, r, world) for r in range(world)]
+                slots = [torch.zeros(max(g[2], 1) * tiling.slot_bytes(T, T), dtype=torch.uint8, device="cuda") for g in geo]
+                per = np.zeros((world, 40))
+                for i in range(40):
+                    for r in range(world):
+                        f, st_, n = geo[r]
+                        if exchange and world > 1 and i > 0:
+                            abi.import_costs_device(hs[r], ctypes.c_void_p(comb.data_ptr()), mw, mh)
+                        abi.render_tiles_device(hs[r], s_pan[i % 16], W4, H4, T, T, f, st_, n, 5, ctypes.c_void_p(slots[r].data_ptr()))
+                        if exchange and world > 1:
+                            maps[r].zero_()
+                            abi.export_costs_device(hs[r], ctypes.c_void_p(maps[r].data_ptr()), mw, mh)
+                        torch.cuda.synchronize()
+                        a, b = abi.kernel_times(hs[r])
+                        per[r, i] = float(a[-1] + b[-1])
+                    if exchange and world > 1:
+                        comb = torch.stack(maps).max(dim=0).values.contiguous()
+                for hh in hs:
+                    abi.scene_destroy(hh)
+                if os.environ.get("PERFRAME"):
+                    print("    per frame (slowest rank: ms): " + " ".join("%d:%.1f" % (int(np.argmax(per[:, i])), per[:, i].max()) for i in range(8, 40)), flush=True)
+                t = float(per[:, 8:].max(axis=0).mean())
+                if exchange: res[world] = t
+                print("[%s] automatic 4K panning camera, %d ranks%s: frame = slowest rank per frame, mean %.3f ms (ranks' means %s)" % (
+                    name, world, "" if exchange else " WITHOUT the cost-map exchange", t, " ".join("%.2f" % x for x in per[:, 8:].mean(axis=1))), flush=True)
+        if 1 in res:
+            for world in res:
+                if world != 1: print("[%s]   -> %d GPUs: %.2fx over one (render only, no exchange)" % (name, world, res[1] / res[world]), flush=True)
     if "irr" in what:
         rnd = np.random.RandomState(1)
         n_waves = 2048

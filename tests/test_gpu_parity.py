@@ -1146,6 +1146,15 @@ def test_render_frame_multi_virtual_devices(scenes, engine):
                 for k in RAY_KEYS + ("shaded_hits",):
                     assert sum(st[k] for st in r["stats"]) == single["stats"][k], (n, k)
                 assert all(st["kernel_ms"] > 0 for st in r["stats"])
+        # a turning camera: the replicas exchange their block costs after every frame (the next one's re-projected
+        # forecast reads all tiles' costs); the order of the work changes no pixel
+        cam = list(scenegen.ROOM_CAMERA)
+        for frame in range(4):
+            cam[4] += 2.0
+            s_f = binding.sensor(cam, W, H)
+            want = abi.render_chunk(hs[3], s_f, W, H)["rgb"]
+            got = abi.render_frame_multi(hs[:3], s_f, W, H, 64, 64, 5, want_stats=False)["rgb"]
+            assert np.array_equal(got, want), frame
         r = abi.render_frame_multi(hs, sens, W, H, 256, 256, 5, want_stats=False)  # fewer tiles (2) than replicas
         assert np.array_equal(r["rgb"], single["rgb"])
         with pytest.raises(RuntimeError):
@@ -1167,3 +1176,58 @@ def test_facade_set_devices(scenes, engine):
         rgb = m.render_image(scenegen.ROOM_CAMERA, 320, 180)
         assert_rgb_close(rgb, g["rgb"], "SetDevices frame %d" % frame)
         assert np.array_equal(rgb, g["rgb"])
+
+
+def test_cost_map_exchange_between_ranks(scenes, engine):
+    """Multi-GPU frames with a moving camera: every rank exports the block costs
+    of its tiles into a frame-wide map, the maps are combined (MAX) and imported,
+    and the next frame's re-projected forecast reads them
+    (mt_scene_export_costs_device / mt_scene_import_costs_device).  Three virtual
+    ranks on one GPU, a scene each, five frames of a turning camera: every map
+    holds exactly its rank's blocks, and every frame equals the oracle's (the
+    order of the work changes no pixel)."""
+    import torch
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["mini"])
+    flat = m.flatten()
+    o = orclib.OracleScene(scenes["mini"])
+    o.set_lights(scenegen.ROOM_LIGHTS)
+    W, H, T, world = 256, 144, 32, 3
+    mw, mh = (W + 7) // 8, (H + 7) // 8
+    hs = [abi.scene_create(flat) for _ in range(world)]
+    try:
+        for hh in hs:
+            abi.set_lights(hh, scenegen.ROOM_LIGHTS)
+        comb = None
+        cam = list(scenegen.ROOM_CAMERA)
+        for frame_no in range(5):
+            sens = binding.sensor(cam, W, H)
+            frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+            maps = []
+            for r in range(world):
+                f, s, n = tiling.rank_tiles(W, H, T, T, r, world)
+                slots = torch.zeros(n * tiling.slot_bytes(T, T), dtype=torch.uint8, device="cuda")
+                if comb is not None:
+                    abi.import_costs_device(hs[r], ctypes.c_void_p(comb.data_ptr()), mw, mh)
+                abi.render_tiles_device(hs[r], sens, W, H, T, T, f, s, n, 5, ctypes.c_void_p(slots.data_ptr()))
+                abi.blit_tiles_device(hs[r], W, H, T, T, f, s, n, ctypes.c_void_p(slots.data_ptr()), ctypes.c_void_p(frame.data_ptr()))
+                cm = torch.zeros((mh, mw), dtype=torch.int32, device="cuda")
+                abi.export_costs_device(hs[r], ctypes.c_void_p(cm.data_ptr()), mw, mh)
+                torch.cuda.synchronize()
+                abi.read_stats(hs[r])
+                own = np.zeros((mh, mw), dtype=bool)
+                for j in range(n):
+                    x, y, cw, ch = tiling.tile_rect(f + j * s, W, H, T, T)
+                    own[y // 8:(y + ch + 7) // 8, x // 8:(x + cw + 7) // 8] = True
+                assert np.array_equal(cm.cpu().numpy() != 0, own), (frame_no, r)
+                maps.append(cm)
+            comb = torch.stack(maps).max(dim=0).values.contiguous()
+            assert (comb.cpu().numpy() != 0).all()
+            want = o.render(cam, W, H)["rgb"]
+            assert_rgb_close(frame.cpu().numpy(), want, "%s frame %d" % (engine, frame_no))
+            cam[4] += 2.0
+        with pytest.raises(RuntimeError):
+            abi.export_costs_device(hs[0], ctypes.c_void_p(comb.data_ptr()), 3, 3)
+    finally:
+        for hh in hs:
+            abi.scene_destroy(hh)
