@@ -421,7 +421,22 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   // re-projects them (radius 1 block; 2 when the origin moved too: parallax).
   int reproject = 0, radius = 0;
   float blend = 0.0f;  // see forecast_kernel
+  // Did the frame that measured the costs have a pixel column or row whose primary rays had a zero direction component
+  // (found on the host: such a column or row runs through the whole image, so its ends are enough)?  Its blocks'
+  // costs are skipped by a re-projected forecast (forecast_kernel).
+  int old_irr = 0;
   if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {
+    const mt_sensor &o = s->cost_sensor;
+    for (int k = 0; k < 3 && !old_irr; k++) {
+      for (int x = 0; x < image_w && !old_irr; x++) {
+        if (o.start_point[k] + o.delta_scanline[k] * 0.0 + o.delta_pixel[k] * (double)x == 0.0 ||
+            o.start_point[k] + o.delta_scanline[k] * (double)(image_h - 1) + o.delta_pixel[k] * (double)x == 0.0) old_irr = 1;
+      }
+      for (int y = 0; y < image_h && !old_irr; y++) {
+        if (o.start_point[k] + o.delta_scanline[k] * (double)y + o.delta_pixel[k] * 0.0 == 0.0 ||
+            o.start_point[k] + o.delta_scanline[k] * (double)y + o.delta_pixel[k] * (double)(image_w - 1) == 0.0) old_irr = 1;
+      }
+    }
     reproject = 1;
     radius = memcmp(s->cost_sensor.origin, sensor->origin, sizeof sensor->origin) != 0 ? 2 : 1;
     if (s->tune.v[MT_TUNE_FORECAST_RADIUS] >= 0.0) radius = (int)s->tune.v[MT_TUNE_FORECAST_RADIUS];
@@ -455,7 +470,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
                        reproject, radius, (history && (s->last_engine == 1 || s->last_engine == 3)) ? 0 : 1,
                        (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u, blend,
-                       (history && s->last_engine == 3) ? s->d_item_form : nullptr, (float)tv[MT_TUNE_HYBRID_WORK1], (float)tv[MT_TUNE_HYBRID_WORK2], (float)tv[MT_TUNE_FORECAST_STEP]);
+                       (history && s->last_engine == 3) ? s->d_item_form : nullptr, (float)tv[MT_TUNE_HYBRID_WORK1], (float)tv[MT_TUNE_HYBRID_WORK2], (float)tv[MT_TUNE_FORECAST_STEP], old_irr);
     hipLaunchKernelGGL(pool_schedule_kernel, dim3(1), dim3(kPoolSchedThreads), 0, stream, P,
                        s->grid_blocks * s->waves_per_block, sp);
     HIP_TRY(hipGetLastError());
@@ -480,7 +495,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       const float quad_work = (float)s->tune.v[reproject ? MT_TUNE_QUAD_WORK_MOVING : MT_TUNE_QUAD_WORK];
       hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
                          reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f, 16000u, blend,
-                         s->last_engine == 3 ? s->d_item_form : nullptr, (float)s->tune.v[MT_TUNE_HYBRID_WORK1], (float)s->tune.v[MT_TUNE_HYBRID_WORK2], (float)s->tune.v[MT_TUNE_FORECAST_STEP]);
+                         s->last_engine == 3 ? s->d_item_form : nullptr, (float)s->tune.v[MT_TUNE_HYBRID_WORK1], (float)s->tune.v[MT_TUNE_HYBRID_WORK2], (float)s->tune.v[MT_TUNE_FORECAST_STEP], old_irr);
       if (hybrid) {
         const double *tv = s->tune.v;
         const float k = reproject ? (float)(tv[MT_TUNE_QUAD_SHARE_MOVING] / tv[MT_TUNE_QUAD_SHARE]) : 1.0f;  // a re-projected forecast is cut more eagerly

@@ -109,13 +109,13 @@ __device__ __forceinline__ PoolGeom pool_geometry(const RenderParams &P, unsigne
 
 // Does the 8x8 block at (x0, y0) hold a pixel whose primary ray (Sensor::GetRay, camera.cc:65-69) has an exactly zero
 // direction component?  (The normalisation cannot create or remove a zero.)
-__device__ inline bool block_has_zero_component_ray(const RenderParams &P, int x0, int y0) {
+__device__ inline bool block_has_zero_component_ray(const mt_sensor &S, int x0, int y0) {
   bool any = false;
   for (int y = 0; y < 8; y++) {
     double r[3];
-    for (int k = 0; k < 3; k++) r[k] = P.sensor.start_point[k] + P.sensor.delta_scanline[k] * (double)(y0 + y);
+    for (int k = 0; k < 3; k++) r[k] = S.start_point[k] + S.delta_scanline[k] * (double)(y0 + y);
     for (int x = 0; x < 8; x++) {
-      for (int k = 0; k < 3; k++) any = any || (r[k] + P.sensor.delta_pixel[k] * (double)(x0 + x)) == 0.0;
+      for (int k = 0; k < 3; k++) any = any || (r[k] + S.delta_pixel[k] * (double)(x0 + x)) == 0.0;
     }
   }
   return any;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void probe_kernel(DevScene 
   if (have && which == 0) {
     // (a block on the pixel column or row whose primary rays have a zero direction component: among the longest)
     const PoolGeom g0 = pool_geometry(P, item, -1, 0);
-    if (block_has_zero_component_ray(P, g0.px, g0.py)) cost = max(cost, 16000u * 30u);
+    if (block_has_zero_component_ray(P.sensor, g0.px, g0.py)) cost = max(cost, 16000u * 30u);
     P.item_cost[item] = cost;
   }
 }

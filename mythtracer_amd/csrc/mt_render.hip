@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScen
 // summed costs are scaled to the state machine's whole-block scale by wq / wc.
 __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, int radius, int pool, float w1,
                                 float w2, unsigned unseen, float blend, const unsigned char *form, float wq, float wc,
-                                float step_px) {
+                                float step_px, int old_irr) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_items) return;
   auto cost_of = [&](unsigned word, unsigned idx) -> unsigned {
@@ -335,6 +335,8 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
         for (int dx = -radius; dx <= radius; dx++) {
           const double qx = ox + (double)step_px * dx, qy = oy + (double)step_px * dy;
           if (qx < P.region_x || qy < P.region_y || qx >= P.region_x + P.region_w || qy >= P.region_y + P.region_h) continue;
+          // (an old block whose rays had a zero direction component says nothing about the turned camera's rays)
+          if (old_irr && block_has_zero_component_ray(old, (int)qx & ~7, (int)qy & ~7)) continue;
           if (P.cost_map != nullptr) {  // every rank's costs of the old frame (0 = nobody reported that block)
             const int mx_ = (int)qx >> 3, my_ = (int)qy >> 3;
             if (mx_ < P.cost_map_w && my_ < P.cost_map_h) {
@@ -366,7 +368,7 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
   // pass the reference's box tests through NaN (mt_trace.h): about thirty times a block's mean cost.  Telling the
   // scheduler so lets those blocks start first and in pieces (frames of a turning camera that pass through such a
   // position: 9.0 -> ms at 1080p, 6.7 -> ms for the rank that owns the column at N = 8).
-  if (block_has_zero_component_ray(P, (int)px - 4, (int)py - 4)) best = max(best, unseen * 30u);
+  if (block_has_zero_component_ray(P.sensor, (int)px - 4, (int)py - 4)) best = max(best, unseen * 30u);
   P.item_forecast[i] = best;
 }
 
