@@ -24,9 +24,11 @@ def pan(n=48):
     a, b = abi.kernel_times(h)
     t = (a + b)[-n:]
     return float(t.mean()), float(t.max())
-abi.set_engine(h, 1)
-for radius, step in ((1, 8.0), (1, 6.0), (1, 5.0), (1, 4.0), (2, 4.0), (2, 3.0)):
-    for share in (0.7, 0.8, 0.9):
-        abi.set_tuning(h, "FORECAST_RADIUS", radius); abi.set_tuning(h, "FORECAST_STEP", step)
-        abi.set_tuning(h, "QUAD_SHARE_MOVING", share)
-        print("radius %d step %.0f px quad_share_moving %.2f: pan mean %.3f max %.3f" % ((radius, step, share) + pan()), flush=True)
+abi.set_engine(h, 0)
+for i in range(8 + 32):
+    abi.render_chunk_device(h, sens[i % 16], W, H, (0, 0, W, H), 5, ctypes.c_void_p(buf.data_ptr()))
+torch.cuda.synchronize()
+a, b = abi.kernel_times(h)
+t = (a + b)[-32:]
+print("automatic engine, defaults: pan mean %.3f max %.3f" % (t.mean(), t.max()))
+print("per frame (j = position in the 16-frame pan: 0 and 8 = golden camera): " + " ".join("%d:%.2f" % ((8 + k) % 16, t[k]) for k in range(32)))

@@ -1231,3 +1231,55 @@ def test_cost_map_exchange_between_ranks(scenes, engine):
     finally:
         for hh in hs:
             abi.scene_destroy(hh)
+
+
+def test_exact_ties_inside_long_lists(engine):
+    """A long list (more than 32 triangles in one node) is scanned through its
+    spatially SORTED copy and its hits are folded in whatever order they come,
+    by (distance ascending, list position descending) -- which must be the
+    reference's "a later equally distant hit replaces the earlier one"
+    (octtree.cc:186-195).  Here: 90 coincident copies of two triangles that
+    straddle the root's centre (they stay in the root's list), interleaved with
+    120 other straddlers, different materials so that the winner shows in the
+    pixels, plus small triangles that make the tree split; rays and a rendered
+    frame against the oracle."""
+    rnd = scenegen.SplitMix64(4242)
+    m, o = _both()
+    for s in (m, o):
+        for k in range(3):
+            s.add_material("m%d" % k, (.2 + .3 * k, .9 - .3 * k, .3), (.5, .5, .5), (.1, .1, .1), ns=4)
+    tris = []
+    n = [[0, 0, -1]] * 3
+    for k in range(90):
+        tris.append(([[-30, -30, 50], [70, -30, 50], [-30, 70, 50]], k % 3))       # coincident, through the centre
+        tris.append(([[70, 70, 50], [-30, 70, 50], [70, -30, 50]], (k + 1) % 3))
+        if k % 3 == 0:
+            z = 20.0 + float(int(rnd.rng(0, 60)))
+            tris.append(([[-20, -20, z], [60, -25, z], [-25, 60, z + 1]], k % 3))  # other straddlers, lattice depths
+    for k in range(400):                                                            # small ones: the tree splits
+        c = [float(int(rnd.rng(-40, 90))) for _ in range(3)]
+        tris.append(([[c[0], c[1], c[2]], [c[0] + 2, c[1], c[2]], [c[0], c[1] + 2, c[2] + 1]], k % 3))
+    for s in (m, o):
+        for k, (v, mt) in enumerate(tris):
+            s.add_triangle(v, n, mtl=mt, line_no=k)
+    t = m.tree()
+    assert t["prim_count"][0] > 64, "the straddlers must stay in the root's list"
+    rays = []
+    for i in range(2048):
+        org = [float(int(rnd.rng(-20, 60))), float(int(rnd.rng(-20, 60))), -40.0 if i % 2 else 140.0]
+        tgt = [float(int(rnd.rng(-10, 50))), float(int(rnd.rng(-10, 50))), 50.0]
+        d = [tgt[a] - org[a] for a in range(3)]
+        if i % 4 == 0:
+            d = [0.0, 0.0, d[2]]  # axis-parallel too (the exact descent on the same lists)
+        rays.append(org + d)
+    rays = np.array(rays)
+    want = o.intersect(rays)
+    got = M.hip_abi().intersect_rays(m.device_scene(), rays)
+    hit = want["line"] >= 0
+    assert hit.mean() > 0.5
+    assert np.array_equal(got["line"], want["line"])
+    assert np.array_equal(got["t"][hit], want["t"][hit])
+    assert (want["line"][hit] >= 170).mean() > 0.3  # late list positions win the ties
+    lights = [(20, 20, -60, .2, .2, .2, .8, .8, .8, .3, .3, .3), (30, 10, 160, .1, .1, .1, .6, .6, .6, .2, .2, .2)]
+    _render_both(m, o, (20, 20, -70, 0, 0, 0, 70), 128, 96, lights)
+    _render_both(m, o, (20, 25, 150, 0, 180, 0, 70), 96, 64, lights)
