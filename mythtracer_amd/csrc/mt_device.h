@@ -225,7 +225,10 @@ struct RenderParams {
 // (hit-set traversal, mt_trace.h) trees of up to kHsMaxDepth levels use 24-byte
 // frames for the levels that can hold a node with children, plus two
 // wave-uniform words per level; the old frames share the same bytes.
-constexpr int kHsMaxDepth = 12;    // levels of an octree the hit-set walk takes (LDS: 24-byte frames for all but the leaf level)
+// levels of an octree the hit-set walk takes: its per-level child masks hold 16 levels; LDS -- 24-byte frames per lane
+// for all but the leaf level -- is 15 KB per wave at 9 levels (8 waves per CU) and 27 KB at 16 (4 waves per CU: the
+// launch configuration halves the waves per workgroup until the budget holds).  Deeper trees take the ordered descent.
+constexpr int kHsMaxDepth = 16;
 __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
   size_t n = (size_t)depth * 64 * (packed ? 16 : 20);
 #ifdef MT_HS

@@ -11,7 +11,7 @@
 // in any order; the reference's choice among the children that hold a hit is
 // reproduced by its own rule, "the entered, acceptable child with the smallest
 // (entry distance, index)" -- see the comment there and DESIGN.md section 3.1).
-// Irregular rays, the diagnostic modes and trees deeper than kHsMaxDepth (12 levels) take
+// Irregular rays, the diagnostic modes and trees deeper than kHsMaxDepth (16 levels) take
 // the ORDERED DESCENT:
 //   * every lane keeps its own recursion state (the reference's call stack of
 //     PrimitiveIntersectRay) in an LDS-resident per-lane stack;

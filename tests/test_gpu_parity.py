@@ -339,13 +339,14 @@ def _render_both(m, o, cam, W, H, lights):
     return g
 
 
-@pytest.mark.parametrize("ext,jit,depth", [(0.08, 0.015, 10), (0.04, 0.008, 11), (0.01, 0.002, 13)])
+@pytest.mark.parametrize("ext,jit,depth", [(0.08, 0.015, 10), (0.04, 0.008, 11), (0.01, 0.002, 13), (0.005, 0.001, 14), (0.0012, 0.00025, 16), (0.0003, 0.00006, 18)])
 def test_deep_octrees(ext, jit, depth):
     """A tight cluster of small triangles in a big room makes the octree deep.  Up to
-    12 levels (kHsMaxDepth) regular rays take the hit-set walk -- levels 8 and
-    deeper in the second half of its per-lane child masks, without the LDS
-    staging of short leaf children --, deeper trees (13 here) the ordered descent
-    with its per-lane stack.  Same pixels, hit points and counters as the oracle."""
+    16 levels (kHsMaxDepth) regular rays take the hit-set walk -- levels 8 and
+    deeper in the second half of its per-lane child masks, fewer waves per
+    workgroup as its LDS frames grow --, deeper trees (18 here) the ordered
+    descent with its per-lane stack.  Same pixels, hit points and counters as the
+    oracle."""
     rnd = scenegen.SplitMix64(77)
     m, o = _both()
     tris = [[[0, 0, 0], [64, 0, 0], [0, 0, 64]], [[64, 0, 64], [0, 0, 64], [64, 0, 0]]]  # a floor
@@ -362,8 +363,20 @@ def test_deep_octrees(ext, jit, depth):
     assert o.tree()["depth"] == depth
     lights = [(30, 40, 20, .2, .2, .2, .8, .8, .8, .4, .4, .4)]
     _render_both(m, o, (19.0, 8.0, 12.0, 15.0, 0.0, 0.0, 70.0), 96, 64, lights)
-    g = _render_both(m, o, (20.0 + ext / 2, 3.0 + ext / 2, 29.9, 0.0, 0.0, 0.0, 8.0), 64, 64, lights)  # straight at the cluster
-    assert ((g["line"] >= 2) & (g["line"] < 122)).mean() > 0.2
+    g = _render_both(m, o, (20.0 + ext / 2, 3.0 + ext / 2, 29.9, 0.0, 0.0, 0.0, min(8.0, 800.0 * ext)), 64, 64, lights)  # straight at the cluster
+    if ext >= 0.005:  # (the smallest clusters hide behind one of the scattered triangles from this viewpoint)
+        assert ((g["line"] >= 2) & (g["line"] < 122)).mean() > 0.2
+    else:
+        rays = []
+        for i in range(256):  # from the +z side through a grid of points inside the cluster
+            tgt = [20.0 + ext * (0.1 + 0.8 * (i % 16) / 15.0), 3.0 + ext * (0.1 + 0.8 * (i // 16) / 15.0), 30.0 + ext * 0.5]
+            org = [tgt[0] + 0.3 * (i % 5 - 2), tgt[1] + 0.2 * (i % 3), tgt[2] + 2.0]
+            rays.append(org + [tgt[a] - org[a] for a in range(3)])
+        rays = np.array(rays)
+        want = o.intersect(rays)
+        got = M.hip_abi().intersect_rays(m.device_scene(), rays)
+        assert np.array_equal(got["line"], want["line"])
+        assert ((want["line"] >= 2) & (want["line"] < 122)).mean() > 0.2  # rays into the cluster: the deepest levels
 
 
 def test_reference_octtree_test_scenario():
