@@ -625,6 +625,24 @@ __device__ __forceinline__ void await_quad(QuadRegs &q) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.lo), "+s"(q.hi));
 }
 
+// Eight fp32 boxes (192 bytes) in ONE round trip: four scalar loads issued by one asm statement into one buffer of 48
+// SGPRs, awaited together (the sorted long lists: a block of 16 entries is two of these instead of four dependent
+// quad fetches; tools/check_asm_prefetch.py treats the statement's destinations as one set in flight).
+struct OctRegs {
+  f16v lo0;
+  f8v hi0;
+  f16v lo1;
+  f8v hi1;
+};
+__device__ __forceinline__ void issue_oct(OctRegs &q, const MT_CONST float *p) {
+  asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x60\n\ts_load_dwordx8 %3, %4, 0xa0"
+               : "=&s"(q.lo0), "=&s"(q.hi0), "=&s"(q.lo1), "=&s"(q.hi1)
+               : "s"(p));
+}
+__device__ __forceinline__ void await_oct(OctRegs &q) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.lo0), "+s"(q.hi0), "+s"(q.lo1), "+s"(q.hi1));
+}
+
 // Four boxes (stream positions k..k+3): fp32 verdicts, then the exact fp64
 // test for the boxes some lane survived, in stream order.
 template <int OCT, bool STATS>
@@ -1653,20 +1671,16 @@ __device__ __attribute__((noinline)) ScanOut scan_sorted_call(const DevScene *se
       while (bl != 0ull) {
         const int b = __builtin_ctzll(bl);
         bl &= bl - 1ull;
-        QuadRegs A, B;
+        OctRegs Q;
         const MT_CONST float *p = tb + (size_t)b * 16 * 6;
-        issue_quad(A, p);
-        await_quad(A);
-        issue_quad(B, p + 24);
-        mark_quad<OCT>(f, A, 0, 16, b * 16, lane, cand);
-        await_quad(B);
-        issue_quad(A, p + 48);
-        mark_quad<OCT>(f, B, 4, 16, b * 16 + 4, lane, cand);
-        await_quad(A);
-        issue_quad(B, p + 72);
-        mark_quad<OCT>(f, A, 8, 16, b * 16 + 8, lane, cand);
-        await_quad(B);
-        mark_quad<OCT>(f, B, 12, 16, b * 16 + 12, lane, cand);
+        issue_oct(Q, p);
+        await_oct(Q);
+        mark_quad<OCT>(f, QuadRegs{Q.lo0, Q.hi0}, 0, 16, b * 16, lane, cand);
+        mark_quad<OCT>(f, QuadRegs{Q.lo1, Q.hi1}, 4, 16, b * 16 + 4, lane, cand);
+        issue_oct(Q, p + 48);
+        await_oct(Q);
+        mark_quad<OCT>(f, QuadRegs{Q.lo0, Q.hi0}, 8, 16, b * 16 + 8, lane, cand);
+        mark_quad<OCT>(f, QuadRegs{Q.lo1, Q.hi1}, 12, 16, b * 16 + 12, lane, cand);
         if (STATS) st.bytes_scalar += 96u * 4u;
       }
       if (__ballot(cand != 0ull) != 0ull) resolve_sorted<STATS>(S, r, base, cand, o.best, o.best_t, st);
