@@ -1515,6 +1515,7 @@ int mt_render_frame_multi(mt_scene *const *scenes, int n, const mt_sensor *senso
       stats[r].total_ms = total_ms;
     }
   }
+  (void)hipSetDevice(root->device);  // (the calling thread's current device: the first replica's, as on entry to phase 2)
   return MT_OK;
 }
 

@@ -89,6 +89,8 @@ for name in (sys.argv[1:] or ["now"]):
                 comb = torch.zeros((mh, mw), dtype=torch.int32, device="cuda")
                 for hh in hs:
                     abi.set_lights(hh, sg.ROOM_LIGHTS); abi.set_stats(hh, False)
+                    for kv in [x for x in os.environ.get("TUNE", "").split(",") if x]:
+                        abi.set_tuning(hh, kv.split("=")[0], float(kv.split("=")[1]))
                 geo = [tiling.rank_tiles(W4, H4, T, T, r, world) for r in range(world)]
                 slots = [torch.zeros(max(g[2], 1) * tiling.slot_bytes(T, T), dtype=torch.uint8, device="cuda") for g in geo]
                 per = np.zeros((world, 40))
