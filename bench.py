@@ -140,7 +140,7 @@ def main():
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--scene", default="room")
     ap.add_argument("--tile", type=int, default=64)
-    ap.add_argument("--engine", type=int, default=0, help="0 automatic (default), 1 state machine, 2 ray pool")
+    ap.add_argument("--engine", type=int, default=0, help="0 automatic (default), 1 state machine, 2 ray pool, 3 hybrid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", choices=("full", "band"), default="full",
                     help="reference timed on the whole frame (about 30 s) or on a quarter-frame band")
@@ -475,7 +475,7 @@ def main():
                                   "previous frame's block costs re-projected through the camera change; the last step is the "
                                   "golden camera (extras.warm_same_frame / cold_frame_ms give the other regimes)") if args.regime == "moving" else
                                  "warm: every timed step re-renders the golden camera's frame, scheduled from its own measured block costs",
-                       "engine": {0: "automatic", 1: "state machine", 2: "ray pool"}[args.engine],
+                       "engine": {0: "automatic", 1: "state machine", 2: "ray pool", 3: "hybrid"}[args.engine],
                        "scene_sha256": info["sha256"]},
             "frame_ms_wall": elapsed / max(K, 1) * 1e3,
             "frame_ms_wall_with_work_counters_and_a_sync_per_frame": elapsed_counting * 1e3,

@@ -1296,3 +1296,32 @@ def test_exact_ties_inside_long_lists(engine):
     lights = [(20, 20, -60, .2, .2, .2, .8, .8, .8, .3, .3, .3), (30, 10, 160, .1, .1, .1, .6, .6, .6, .2, .2, .2)]
     _render_both(m, o, (20, 20, -70, 0, 0, 0, 70), 128, 96, lights)
     _render_both(m, o, (20, 25, 150, 0, 180, 0, 70), 96, 64, lights)
+
+
+@pytest.mark.parametrize("extra", [[], ["--regime", "warm", "--engine", "3"]])
+def test_bench_line_contract(extra):
+    """bench.py as the driver starts it (a child process, one GPU): exit code 0, ONE JSON line with the contract's
+    keys, the moving-camera regime as `value`, parity verdicts on the timed frame and the extras, the roofline block
+    (counter-derived fields are numbers when profiles/pmc_frame_kernel.json was measured on these kernel sources,
+    else null -- never stale)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
+                        "--crop-checks", "2"] + extra, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["unit"] == "Mray/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["parity"] == "frame identical to the reference's" and d["value"] > 100.0
+    assert d["value_regime"] == ("warm" if extra else "moving")
+    ro = d["roofline"]
+    assert ro["bound"] == "valu_issue" and ro["kernel_ms"] > 0 and ro["hbm"]["requested_GBps"] > 0
+    assert (ro["frac"] is None) == (ro["achieved"] is None) == (ro["traffic"] is None)
+    if ro["frac"] is not None:
+        assert 0.2 < ro["frac"] < 1.0 and ro["pmc_source"]["measured_at_commit"]
+    ex = d["extras"]
+    assert ex["cold_frame_parity"] == ex["warm_same_frame"]["parity"] == ex["counters_on_frame_parity"] == d["parity"]
