@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -833,8 +834,11 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     }
   }
   // Records of the hit-set traversal (mt_device.h HsRec).
+  static_assert(offsetof(HsRec, kid) == 16 && offsetof(HsRec, own) == kHsRecOwn && offsetof(HsRec, planes) == kHsRecPlanes &&
+                    offsetof(HsRec, sl_begin) == 328 && offsetof(HsRec, ll_begin) == 332, "the walk reads the record at these offsets");
   std::vector<HsRec> hsr((size_t)nn + 1);
   memset(hsr.data(), 0, hsr.size() * sizeof(HsRec));
+  std::vector<float> sl_box;  // DevScene::sl_box32
   for (int i = 0; i < nn; i++) {
     HsRec &h = hsr[i];
     const NodeRec &r = recs[i];
@@ -843,8 +847,12 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     h.prim_count = r.prim_count;
     h.child_mask = r.first_child != 0 ? (r.child_mask & 0xff) : 0;
     for (int c = 0; c < 8; c++) {
-      for (int k = 0; k < 6; k++) {
-        h.kid[c][k] = r.first_child != 0 ? subs[(size_t)(r.first_child + c) * 6 + k] : (k < 3 ? 3.0e38f : -3.0e38f);
+      for (int a = 0; a < 3; a++) {
+        const float lo = r.first_child != 0 ? subs[(size_t)(r.first_child + c) * 6 + a] : 3.0e38f;
+        const float hi = r.first_child != 0 ? subs[(size_t)(r.first_child + c) * 6 + 3 + a] : -3.0e38f;
+        h.kid[a][c] = lo;
+        h.kid[a][8 + c] = hi;
+        h.kid[a][16 + c] = lo;
       }
     }
     double u[6] = {3.0e38, 3.0e38, 3.0e38, -3.0e38, -3.0e38, -3.0e38};
@@ -856,12 +864,22 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
       }
     }
     for (int k = 0; k < 6; k++) h.own[k] = (float)u[k];
-    for (int c = 0; c < 8 && r.first_child != 0; c++) {
-      const NodeRec &k = recs[r.first_child + c];
-      h.kid_begin[c] = k.prim_begin;
-      if (k.first_child == 0 && k.prim_count >= 1 && k.prim_count <= kHsLeafTris) {
-        h.kid_leaf |= 1 << c;
-        h.kid_count[c] = (uint8_t)k.prim_count;
+    h.sl_begin = -1;
+    if (r.prim_count >= 1 && r.prim_count <= kHsShortList) {
+      h.sl_begin = (int32_t)(sl_box.size() / kSlQuadFloats);
+      for (int q = 0; q < r.prim_count; q += 4) {
+        float quad[kSlQuadFloats];
+        for (int j = 0; j < 4; j++) {
+          for (int a = 0; a < 3; a++) {
+            const bool real = q + j < r.prim_count;
+            const float lo = real ? (float)d->tri_aabb[(size_t)(r.prim_begin + q + j) * 6 + a] : 3.0e38f;
+            const float hi = real ? (float)d->tri_aabb[(size_t)(r.prim_begin + q + j) * 6 + 3 + a] : -3.0e38f;
+            quad[a * 12 + j] = lo;
+            quad[a * 12 + 4 + j] = hi;
+            quad[a * 12 + 8 + j] = lo;
+          }
+        }
+        sl_box.insert(sl_box.end(), quad, quad + kSlQuadFloats);
       }
     }
     for (int k = 0; k < 3; k++) {
@@ -986,6 +1004,8 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   if ((rc = upload(s, ll_exact.data(), ll_exact.size(), &s->dev.ll_exact)) != MT_OK) return rc;
   if ((rc = upload(s, ll_grp.data(), ll_grp.size(), &s->dev.ll_grp32)) != MT_OK) return rc;
   if ((rc = upload(s, ll_sup.data(), ll_sup.size(), &s->dev.ll_sup32)) != MT_OK) return rc;
+  sl_box.resize(sl_box.size() + 2 * kSlQuadFloats, 0.0f);  // (the copies are whole 16-byte pieces; never empty)
+  if ((rc = upload(s, sl_box.data(), sl_box.size(), &s->dev.sl_box32)) != MT_OK) return rc;
   if ((rc = upload(s, recs.data(), recs.size(), &s->dev.nodes)) != MT_OK) return rc;
   const size_t nt = (size_t)d->n_tris;
   {

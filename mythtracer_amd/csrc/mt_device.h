@@ -68,21 +68,24 @@ constexpr int kSuperMin = MT_SUPER_MIN;  // lists that touch at least this many 
 // subtree and of the node's own list (inverted when empty: every ray misses).
 struct HsRec {
   int32_t first_child, prim_begin, prim_count, child_mask;
-  float kid[8][6];
-  float own[6];
-  uint8_t kid_count[8];  // prim_count of the children that are "short leaves" (kid_leaf), else 0
-  double planes[9];      // lo xyz, centre xyz, hi xyz (NodeRec): the children's exact boxes
-  int32_t kid_leaf;      // bit c: child c is a leaf with 1..kHsLeafTris triangles (unused by the walk as shipped)
-  int32_t ll_begin;      // own list longer than kHsShortList: its position in the spatially sorted copy (DevScene::ll_*), else -1
-  int32_t kid_begin[8];  // prim_begin of the children
+  // fp32 union boxes of the eight children's subtrees, one row of 24 floats per axis: the eight lower planes, the
+  // eight upper planes, the lower planes AGAIN -- a lane reads [near x 8][far x 8] as 64 consecutive bytes that start
+  // at the row (direction component >= 0) or 32 bytes into it (< 0): no per-plane select by the direction's sign
+  float kid[3][24];
+  float own[6];       // fp32 union box of the own list
+  int32_t sl_begin;   // own list of 1..kHsShortList triangles: its first quad in DevScene::sl_box32, else -1
+  int32_t ll_begin;   // own list longer than kHsShortList: its position in the spatially sorted copy (DevScene::ll_*), else -1
+  double planes[9];   // lo xyz, centre xyz, hi xyz (NodeRec): the children's exact boxes
+  int32_t pad[2];
 };
-static_assert(sizeof(HsRec) == 352, "HsRec must be 352 bytes");
-constexpr int kHsRecLanes = 22;   // 16 bytes per lane
+static_assert(sizeof(HsRec) == 416, "HsRec must be 416 bytes");
+constexpr int kHsRecOwn = 304, kHsRecPlanes = 336;  // byte offsets the walk reads at (checked in mt_capi.hip)
+constexpr int kHsRecLanes = 26;   // 16 bytes per lane
 #ifndef MT_HS_SHORT
 #define MT_HS_SHORT 32
 #endif
 constexpr int kHsShortList = MT_HS_SHORT;  // own lists up to this length are scanned from LDS (64 fp32 boxes staged behind the frames; one candidate bit each)
-constexpr int kHsLeafTris = 16;   // 16 fp32 boxes = 384 bytes = 24 lanes of one LDS-DMA instruction
+constexpr int kSlQuadFloats = 36;  // DevScene::sl_box32: four boxes = per axis [lo x 4][hi x 4][lo x 4] (144 bytes)
 
 struct DevTexture {
   const void *texels;
@@ -111,6 +114,10 @@ struct DevScene {
   const float *ll_aabb32;    // 6 per entry
   const float *ll_grp32;     // 6 per 16 entries
   const float *ll_sup32;     // 6 per 64 entries
+  // The SHORT lists' fp32 boxes once more (1..kHsShortList triangles, list order), laid out for the walk's per-lane
+  // reads: per quad of list positions kSlQuadFloats floats = per axis [lo x 4][hi x 4][lo x 4]; a list starts at quad
+  // HsRec::sl_begin and is padded to whole quads with inverted boxes.
+  const float *sl_box32;
   double bmax[3];            // max |coordinate| of any triangle box, per axis
   const double *tri_vertex;  // 9 per triangle
   const double *tri_normal;  // 9 per triangle
@@ -243,7 +250,7 @@ __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
 }
 __host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
 #ifdef MT_HS
-  size_t n = wave_frames_bytes(depth, packed) + 64 * 24;  // the fp32 boxes of a short list (the counters are in registers)
+  size_t n = wave_frames_bytes(depth, packed) + 64 * 24;  // the fp32 boxes of a short list: (kHsShortList / 4) quads of 144 bytes = 1 152 (the counters are in registers)
 #else
   size_t n = wave_frames_bytes(depth, packed) + 5 * 64 * 4;
 #endif

@@ -598,6 +598,17 @@ __device__ __forceinline__ bool subtree_may_hit(const float *b, const Filter32 &
   return !(hi < 0.0f) && !(lo > hi);  // NaN: keep
 }
 
+// The same test with the planes already picked by the direction's signs (the hit-set walk reads them that way).
+__device__ __forceinline__ bool near_far_may_hit(float nx, float fx, float ny, float fy, float nz, float fz, const Filter32 &f) {
+  const float tnx = __builtin_fmaf(nx, f.ix, f.cnx), tfx = __builtin_fmaf(fx, f.ix, f.cfx);
+  const float tny = __builtin_fmaf(ny, f.iy, f.cny), tfy = __builtin_fmaf(fy, f.iy, f.cfy);
+  const float tnz = __builtin_fmaf(nz, f.iz, f.cnz), tfz = __builtin_fmaf(fz, f.iz, f.cfz);
+  // !(hi < 0) && !(lo > hi) with the zero folded into the entry distance: one maximum fewer
+  const float lo0 = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+  const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+  return !(lo0 > hi);  // NaN: keep
+}
+
 // keep mask of the eight subtree boxes `sub` (children fc .. fc + 7) for a ray with one zero direction component:
 // the range rule.
 __device__ __forceinline__ unsigned degenerate_children(const DevScene *self, const float *sub, int fc, double ox,
@@ -1847,6 +1858,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   S.grp_aabb32 = G->grp_aabb32;
   S.sub_aabb32 = G->sub_aabb32;
   S.hs_rec = G->hs_rec;
+  S.sl_box32 = G->sl_box32;
   S.self = uniform_ptr(scene);
   S.tri_vertex = G->tri_vertex;
   S.bmax[0] = G->bmax[0]; S.bmax[1] = G->bmax[1]; S.bmax[2] = G->bmax[2];
@@ -2068,7 +2080,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     int lane_node = 0, lane_fc = 0;
     const unsigned stage = ((unsigned)(uintptr_t)(h_node + L * 2) + 15u) & ~15u;  // the staged HsRec (room for two)
     MT_LDS double *const h_planes = (MT_LDS double *)(uintptr_t)(stage + 2u * (unsigned)sizeof(HsRec));  // [L][10] wave-uniform
-    const unsigned tstage = frames_end;                                    // 32 staged fp32 triangle boxes (768 B)
+    const unsigned tstage = frames_end;                                    // a short list's staged quads of fp32 boxes (<= 1 152 B)
     const char *const hs_bytes = (const char *)S.hs_rec;
 #ifdef MT_PROF
     const bool tl_on = S.prof != nullptr && lane == 0 && stk.base == 0u && __builtin_amdgcn_workgroup_id_x() == 0;
@@ -2142,24 +2154,26 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         default: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
       }
     };
-    // fp32 verdicts on a staged short list (boxes at lds, n of them): bit k = this lane's ray may hit box k
+    // fp32 verdicts on a staged short list (its quads at lds in the layout of DevScene::sl_box32, n boxes): bit k = this
+    // lane's ray may hit box k.  Per quad and axis the lane reads [near x 4][far x 4] as 32 consecutive bytes.
     auto list_bits = [&](unsigned lds, int n) -> unsigned long long {
       typedef float f4v_ __attribute__((ext_vector_type(4)));
-      const MT_LDS f4v_ *t4 = (const MT_LDS f4v_ *)(uintptr_t)lds;
-      unsigned long long cand = 0ull;
-      for (int k = 0; k < n; k += 4) {  // four boxes = six 16-byte reads; boxes past the list are masked off below
-        float tb[24];
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-          const f4v_ q = t4[(k >> 2) * 6 + i];
-          tb[i * 4 + 0] = q.x; tb[i * 4 + 1] = q.y; tb[i * 4 + 2] = q.z; tb[i * 4 + 3] = q.w;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          if (subtree_may_hit(tb + j * 6, f32, sxl != 0, syl != 0, szl != 0)) cand |= 1ull << (k + j);
-        }
+      const unsigned bx = lds + (sxl != 0 ? 16u : 0u), by = lds + 48u + (syl != 0 ? 16u : 0u), bz = lds + 96u + (szl != 0 ? 16u : 0u);
+      unsigned cand = 0u;  // (kHsShortList <= 32 positions)
+      for (int k = 0; k < n; k += 4) {  // boxes past the list are padding (inverted) and masked off below
+        const unsigned q = (unsigned)(k >> 2) * (unsigned)(kSlQuadFloats * 4);
+        const MT_LDS f4v_ *px = (const MT_LDS f4v_ *)(uintptr_t)(bx + q);
+        const MT_LDS f4v_ *py = (const MT_LDS f4v_ *)(uintptr_t)(by + q);
+        const MT_LDS f4v_ *pz = (const MT_LDS f4v_ *)(uintptr_t)(bz + q);
+        const f4v_ nx = px[0], fx = px[1], ny = py[0], fy = py[1], nz = pz[0], fz = pz[1];
+        // the quad's four verdicts as one nibble (select between inline constants), shifted into place once
+        const unsigned q4 = (near_far_may_hit(nx.x, fx.x, ny.x, fy.x, nz.x, fz.x, f32) ? 1u : 0u) |
+                            (near_far_may_hit(nx.y, fx.y, ny.y, fy.y, nz.y, fz.y, f32) ? 2u : 0u) |
+                            (near_far_may_hit(nx.z, fx.z, ny.z, fy.z, nz.z, fz.z, f32) ? 4u : 0u) |
+                            (near_far_may_hit(nx.w, fx.w, ny.w, fy.w, nz.w, fz.w, f32) ? 8u : 0u);
+        cand |= q4 << k;
       }
-      return cand & (n >= 64 ? ~0ull : ((1ull << n) - 1ull));
+      return (unsigned long long)(cand & (n >= 32 ? ~0u : ((1u << n) - 1u)));
     };
     // every lane resolves ITS candidates of the list starting at stream position pb_ in list order
     // (octtree.cc:177-196): exact box and vertices are fetched together, one round trip per candidate
@@ -2321,9 +2335,12 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         MT_PROF_COUNT(PROF_HS_LANES, __builtin_popcountll(m));
         MT_PROF_BEGIN(prof_t1);
 #endif
-        // a short list's fp32 boxes are copied to LDS while the children are tested
+        // a short list's fp32 boxes (DevScene::sl_box32) are copied to LDS while the children are tested
         const bool small_list = pc > 0 && pc <= kHsShortList;
-        if (small_list) dma_range((const char *)S.tri_aabb32 + (size_t)pb * 24, tstage, pc * 24);
+        if (small_list) {
+          dma_range((const char *)S.sl_box32 + (size_t)uniform_i32(ri[82]) * (size_t)(kSlQuadFloats * 4), tstage,
+                    ((pc + 3) >> 2) * (kSlQuadFloats * 4));
+        }
         // ... and the block boxes of a long list (48 at a time: the counters' bytes hold 53)
         const bool long_list = pc > kHsShortList;
         const int lb0 = pb / kGroupTris, lnb = long_list ? (pb + pc - 1) / kGroupTris - lb0 + 1 : 0;
@@ -2344,28 +2361,36 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         const MT_LDS f4v *r4 = (const MT_LDS f4v *)(uintptr_t)rec;
         unsigned bits = 0u, any = 0u;
         if (cm != 0u) {  // (most nodes a wave enters are leaves)
-          float bxs[48];
+          // per axis the lane's [near x 8][far x 8] planes: 64 consecutive bytes of the record's row (HsRec::kid)
+          const MT_LDS f4v *kx = (const MT_LDS f4v *)(uintptr_t)(rec + 16u + (sxl != 0 ? 32u : 0u));
+          const MT_LDS f4v *ky = (const MT_LDS f4v *)(uintptr_t)(rec + 112u + (syl != 0 ? 32u : 0u));
+          const MT_LDS f4v *kz = (const MT_LDS f4v *)(uintptr_t)(rec + 208u + (szl != 0 ? 32u : 0u));
+          float pnx[8], pfx[8], pny[8], pfy[8], pnz[8], pfz[8];
 #pragma unroll
-          for (int i = 0; i < 12; i++) {
-            const f4v q = r4[1 + i];
-            bxs[i * 4 + 0] = q.x; bxs[i * 4 + 1] = q.y; bxs[i * 4 + 2] = q.z; bxs[i * 4 + 3] = q.w;
+          for (int i = 0; i < 2; i++) {
+            const f4v a = kx[i], b = kx[2 + i], c = ky[i], d = ky[2 + i], e = kz[i], g = kz[2 + i];
+            pnx[i * 4 + 0] = a.x; pnx[i * 4 + 1] = a.y; pnx[i * 4 + 2] = a.z; pnx[i * 4 + 3] = a.w;
+            pfx[i * 4 + 0] = b.x; pfx[i * 4 + 1] = b.y; pfx[i * 4 + 2] = b.z; pfx[i * 4 + 3] = b.w;
+            pny[i * 4 + 0] = c.x; pny[i * 4 + 1] = c.y; pny[i * 4 + 2] = c.z; pny[i * 4 + 3] = c.w;
+            pfy[i * 4 + 0] = d.x; pfy[i * 4 + 1] = d.y; pfy[i * 4 + 2] = d.z; pfy[i * 4 + 3] = d.w;
+            pnz[i * 4 + 0] = e.x; pnz[i * 4 + 1] = e.y; pnz[i * 4 + 2] = e.z; pnz[i * 4 + 3] = e.w;
+            pfz[i * 4 + 0] = g.x; pfz[i * 4 + 1] = g.y; pfz[i * 4 + 2] = g.z; pfz[i * 4 + 3] = g.w;
           }
 #pragma unroll
           for (int c = 0; c < 8; c++) {
-            const bool pass = subtree_may_hit(bxs + c * 6, f32, sxl != 0, syl != 0, szl != 0);
+            const bool pass = near_far_may_hit(pnx[c], pfx[c], pny[c], pfy[c], pnz[c], pfz[c], f32);
             if (pass) bits |= 1u << c;
+            // (the compare's lane mask IS the ballot: which children some entering lane lets through costs no vector code)
+            if ((__ballot(pass) & m) != 0ull) any |= 1u << c;
           }
           bits = in ? (bits & cm) : 0u;  // (cm: children with an empty subtree hold an inverted box anyway)
-#pragma unroll
-          for (int c = 0; c < 8; c++) {
-            if (__ballot(((bits >> c) & 1u) != 0u) != 0ull) any |= 1u << c;
-          }
+          any &= cm;
         }
         MT_TL(4);  // child tests done
         // the own list's union box decides who scans it
         bool in_list = false;
         if (pc > 0) {
-          const f4v q0 = r4[13], q1 = r4[14];
+          const f4v q0 = r4[kHsRecOwn / 16], q1 = r4[kHsRecOwn / 16 + 1];
           const float ob[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
           in_list = in && subtree_may_hit(ob, f32, sxl != 0, syl != 0, szl != 0);
         }
@@ -2402,7 +2427,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           ScanOut o{-1, 0.0, 0u};
           if (in_list) {
             // (every list that comes here is longer than kHsShortList: it has a spatially sorted copy)
-            o = scan_sorted_dispatch<STATS>(S, oct, uniform_i32(ri[79]), ((pc + 63) >> 6) << 6, r, f32);
+            o = scan_sorted_dispatch<STATS>(S, oct, uniform_i32(ri[83]), ((pc + 63) >> 6) << 6, r, f32);
             if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
           }
           if (in_list) {
@@ -2438,7 +2463,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         h_win_p[lev * 64 + lane] = -1;
         lane_node = lane == lev ? node : lane_node;
         lane_fc = lane == lev ? fc : lane_fc;
-        if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + 240u))[lane];
+        if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + (unsigned)kHsRecPlanes))[lane];
         set8(wantA, wantB, lev, bits);
         set8(pendA, pendB, lev, any);
         ret_p = -1;  // nothing comes back yet
