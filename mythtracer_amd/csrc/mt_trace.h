@@ -587,6 +587,31 @@ __device__ __forceinline__ unsigned long long filter32_pass(const float *b, cons
   return __builtin_amdgcn_fcmpf(hi, 0.0f, kUGE) & __builtin_amdgcn_fcmpf(lo, hi, kULE);
 }
 
+// The same verdict for the lane itself (a select's condition instead of a lane mask).
+template <int OCT>
+__device__ __forceinline__ bool filter32_lane(const float *b, const Filter32 &f) {
+  static_assert(OCT >= 0 && OCT <= 8, "octant 0..7, or 8 = lanes of several octants");
+  float tnx, tny, tnz, tfx, tfy, tfz;
+  if constexpr (OCT == 8) {
+    tnx = __builtin_fminf(__builtin_fmaf(b[0], f.ix, f.cnx), __builtin_fmaf(b[3], f.ix, f.cnx));
+    tfx = __builtin_fmaxf(__builtin_fmaf(b[0], f.ix, f.cfx), __builtin_fmaf(b[3], f.ix, f.cfx));
+    tny = __builtin_fminf(__builtin_fmaf(b[1], f.iy, f.cny), __builtin_fmaf(b[4], f.iy, f.cny));
+    tfy = __builtin_fmaxf(__builtin_fmaf(b[1], f.iy, f.cfy), __builtin_fmaf(b[4], f.iy, f.cfy));
+    tnz = __builtin_fminf(__builtin_fmaf(b[2], f.iz, f.cnz), __builtin_fmaf(b[5], f.iz, f.cnz));
+    tfz = __builtin_fmaxf(__builtin_fmaf(b[2], f.iz, f.cfz), __builtin_fmaf(b[5], f.iz, f.cfz));
+  } else {
+    constexpr int NX = (OCT & 1) ? 3 : 0, FX = (OCT & 1) ? 0 : 3;
+    constexpr int NY = (OCT & 2) ? 4 : 1, FY = (OCT & 2) ? 1 : 4;
+    constexpr int NZ = (OCT & 4) ? 5 : 2, FZ = (OCT & 4) ? 2 : 5;
+    tnx = __builtin_fmaf(b[NX], f.ix, f.cnx); tfx = __builtin_fmaf(b[FX], f.ix, f.cfx);
+    tny = __builtin_fmaf(b[NY], f.iy, f.cny); tfy = __builtin_fmaf(b[FY], f.iy, f.cfy);
+    tnz = __builtin_fmaf(b[NZ], f.iz, f.cnz); tfz = __builtin_fmaf(b[FZ], f.iz, f.cfz);
+  }
+  const float lo0 = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+  const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
+  return !(lo0 > hi);  // (= !(hi < 0) && !(lo > hi); NaN: keep)
+}
+
 // One per-lane box (a child's subtree box) against the lane's own filter.
 __device__ __forceinline__ bool subtree_may_hit(const float *b, const Filter32 &f, bool sx, bool sy, bool sz) {
   const float b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3], b4 = b[4], b5 = b[5];
@@ -652,6 +677,18 @@ __device__ __forceinline__ void issue_oct(OctRegs &q, const MT_CONST float *p) {
 }
 __device__ __forceinline__ void await_oct(OctRegs &q) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.lo0), "+s"(q.hi0), "+s"(q.lo1), "+s"(q.hi1));
+}
+
+// The lane's verdicts on the four boxes of a quad as one nibble (bit j = box j may be hit): four selects between
+// inline constants and two ORs, to be shifted into a candidate word once.
+template <int OCT>
+__device__ __forceinline__ unsigned quad_nibble(const Filter32 &f, const f16v &lo, const f8v &hi) {
+  const float b0[6] = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5]};
+  const float b1[6] = {lo[6], lo[7], lo[8], lo[9], lo[10], lo[11]};
+  const float b2[6] = {lo[12], lo[13], lo[14], lo[15], hi[0], hi[1]};
+  const float b3[6] = {hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
+  return (filter32_lane<OCT>(b0, f) ? 1u : 0u) | (filter32_lane<OCT>(b1, f) ? 2u : 0u) |
+         (filter32_lane<OCT>(b2, f) ? 4u : 0u) | (filter32_lane<OCT>(b3, f) ? 8u : 0u);
 }
 
 // Four boxes (stream positions k..k+3): fp32 verdicts, then the exact fp64
@@ -1686,12 +1723,11 @@ __device__ __attribute__((noinline)) ScanOut scan_sorted_call(const DevScene *se
         const MT_CONST float *p = tb + (size_t)b * 16 * 6;
         issue_oct(Q, p);
         await_oct(Q);
-        mark_quad<OCT>(f, QuadRegs{Q.lo0, Q.hi0}, 0, 16, b * 16, lane, cand);
-        mark_quad<OCT>(f, QuadRegs{Q.lo1, Q.hi1}, 4, 16, b * 16 + 4, lane, cand);
+        unsigned w = quad_nibble<OCT>(f, Q.lo0, Q.hi0) | (quad_nibble<OCT>(f, Q.lo1, Q.hi1) << 4);
         issue_oct(Q, p + 48);
         await_oct(Q);
-        mark_quad<OCT>(f, QuadRegs{Q.lo0, Q.hi0}, 8, 16, b * 16 + 8, lane, cand);
-        mark_quad<OCT>(f, QuadRegs{Q.lo1, Q.hi1}, 12, 16, b * 16 + 12, lane, cand);
+        w |= (quad_nibble<OCT>(f, Q.lo0, Q.hi0) << 8) | (quad_nibble<OCT>(f, Q.lo1, Q.hi1) << 12);
+        cand |= (unsigned long long)w << (b * 16);  // (padding entries hold inverted boxes: never marked)
         if (STATS) st.bytes_scalar += 96u * 4u;
       }
       if (__ballot(cand != 0ull) != 0ull) resolve_sorted<STATS>(S, r, base, cand, o.best, o.best_t, st);
