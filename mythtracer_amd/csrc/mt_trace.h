@@ -1648,22 +1648,21 @@ __device__ __forceinline__ void resolve_sorted(const DevScene &S, const RayRegs 
     if (cand != 0ull) {
       const int pos = base + __builtin_ctzll(cand);
       cand &= cand - 1ull;
-      const int t = lt[pos];
       // exact box and vertices come from the sorted copy too (15 doubles per entry): one round trip per candidate,
-      // no dependence on the index load
+      // the triangle's index travelling with them (it is only needed when the candidate is a hit; padding entries
+      // hold inverted fp32 boxes and are never marked, their exact entry is all zeros and fails the determinant test)
+      const int t = lt[pos];
       const double *ep = S.ll_exact + (size_t)pos * 15;
       const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
       const double v[9] = {ep[6], ep[7], ep[8], ep[9], ep[10], ep[11], ep[12], ep[13], ep[14]};
-      if (t >= 0) {  // (padding entries hold inverted boxes and are never marked; belt and braces)
-        if (STATS) st.v[ST_BYTES_VECTOR] += 124u;
-        if (slab_pass_lane<false>(e, r)) {
-          if (STATS) st.v[ST_MT_TESTS]++;
-          double tt;
-          if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
-            if (best < 0 || tt < best_t || (tt == best_t && t > best)) {
-              best = t;
-              best_t = tt;
-            }
+      if (STATS) st.v[ST_BYTES_VECTOR] += 124u;
+      if (slab_pass_lane<false>(e, r)) {
+        if (STATS) st.v[ST_MT_TESTS]++;
+        double tt;
+        if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
+          if (t >= 0 && (best < 0 || tt < best_t || (tt == best_t && t > best))) {
+            best = t;
+            best_t = tt;
           }
         }
       }
@@ -2214,22 +2213,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // every lane resolves ITS candidates of the list starting at stream position pb_ in list order
     // (octtree.cc:177-196): exact box and vertices are fetched together, one round trip per candidate
     auto resolve_list = [&](int pb_, unsigned long long cand, int &b_, double &bt_, unsigned &mt_, unsigned &bv_) {
-      // start fetching the candidates' exact boxes and vertices now (both ends of each: they may
-      // straddle a cache line); the loop below finds them on their way.  "+v": one register for all
-      // of these loads, live until after that loop, so that a late arrival lands nowhere else
-      unsigned warm = 0u;
-      {
-        unsigned long long w = cand;
-        for (int guard = 0; guard < 4 && w != 0ull; guard++) {
-          const int k = __builtin_ctzll(w);
-          w &= w - 1ull;
-          const char *ep = (const char *)(S.tri_aabb + (size_t)(pb_ + k) * 6);
-          const char *vp = (const char *)(S.tri_vertex + (size_t)(pb_ + k) * 9);
-          asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword %0, %1, off offset:44\n\t"
-                       "global_load_dword %0, %2, off\n\tglobal_load_dword %0, %2, off offset:68"
-                       : "+v"(warm) : "v"(ep), "v"(vp));
-        }
-      }
       for (int guard = 0; guard <= 64 && __ballot(cand != 0ull) != 0ull; guard++) {
         if (cand != 0ull) {
           const int t = pb_ + __builtin_ctzll(cand);
@@ -2251,7 +2234,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           }
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(warm));  // nothing of the warming loads outlives this point
     };
     // Offers the result (rp_, rt_; rp_ < 0 = none) that the lanes brought back from child slot_ to the frame
     // on top, and lets the lanes that hold a candidate drop the children that sort behind it.
