@@ -2494,6 +2494,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         if (__ballot(ret_p >= 0) != 0ull) {
           MT_PROF_COUNT(PROF_HS_N_RETHIT, 1);
           offer(slot, ret_p, ret_t);
+          pendA = uniform_u64(pendA);  // (wave-uniform: built from ballots; said so, or picking the next child runs as vector code)
+          pendB = uniform_u64(pendB);
         }
         const unsigned todo = get8(pendA, pendB, lev);
         MT_PROF_END(PROF_HS_RET_T, prof_t1);
