@@ -835,7 +835,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   }
   // Records of the hit-set traversal (mt_device.h HsRec).
   static_assert(offsetof(HsRec, kid) == 16 && offsetof(HsRec, own) == kHsRecOwn && offsetof(HsRec, planes) == kHsRecPlanes &&
-                    offsetof(HsRec, sl_begin) == 328 && offsetof(HsRec, ll_begin) == 332, "the walk reads the record at these offsets");
+                    offsetof(HsRec, sl_begin) == kHsRecSl && offsetof(HsRec, ll_begin) == kHsRecLl, "the walk reads the record at these offsets");
   std::vector<HsRec> hsr((size_t)nn + 1);
   memset(hsr.data(), 0, hsr.size() * sizeof(HsRec));
   std::vector<float> sl_box;  // DevScene::sl_box32
@@ -863,7 +863,10 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
         u[3 + k] = std::max(u[3 + k], b[3 + k]);
       }
     }
-    for (int k = 0; k < 6; k++) h.own[k] = (float)u[k];
+    for (int a = 0; a < 3; a++) {
+      h.own[a][0] = h.own[a][2] = (float)u[a];
+      h.own[a][1] = (float)u[3 + a];
+    }
     h.sl_begin = -1;
     if (r.prim_count >= 1 && r.prim_count <= kHsShortList) {
       h.sl_begin = (int32_t)(sl_box.size() / kSlQuadFloats);

@@ -72,15 +72,16 @@ struct HsRec {
   // eight upper planes, the lower planes AGAIN -- a lane reads [near x 8][far x 8] as 64 consecutive bytes that start
   // at the row (direction component >= 0) or 32 bytes into it (< 0): no per-plane select by the direction's sign
   float kid[3][24];
-  float own[6];       // fp32 union box of the own list
+  float own[3][3];    // fp32 union box of the own list, per axis lo, hi, lo: [near][far] = two floats at the row or 4 bytes into it
   int32_t sl_begin;   // own list of 1..kHsShortList triangles: its first quad in DevScene::sl_box32, else -1
   int32_t ll_begin;   // own list longer than kHsShortList: its position in the spatially sorted copy (DevScene::ll_*), else -1
+  int32_t pad0;
   double planes[9];   // lo xyz, centre xyz, hi xyz (NodeRec): the children's exact boxes
-  int32_t pad[2];
+  int32_t pad1[2];
 };
-static_assert(sizeof(HsRec) == 416, "HsRec must be 416 bytes");
-constexpr int kHsRecOwn = 304, kHsRecPlanes = 336;  // byte offsets the walk reads at (checked in mt_capi.hip)
-constexpr int kHsRecLanes = 26;   // 16 bytes per lane
+static_assert(sizeof(HsRec) == 432, "HsRec must be 432 bytes");
+constexpr int kHsRecOwn = 304, kHsRecSl = 340, kHsRecLl = 344, kHsRecPlanes = 352;  // byte offsets the walk reads at (checked in mt_capi.hip)
+constexpr int kHsRecLanes = 27;   // 16 bytes per lane
 #ifndef MT_HS_SHORT
 #define MT_HS_SHORT 32
 #endif

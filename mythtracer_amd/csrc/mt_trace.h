@@ -2356,7 +2356,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         // a short list's fp32 boxes (DevScene::sl_box32) are copied to LDS while the children are tested
         const bool small_list = pc > 0 && pc <= kHsShortList;
         if (small_list) {
-          dma_range((const char *)S.sl_box32 + (size_t)uniform_i32(ri[82]) * (size_t)(kSlQuadFloats * 4), tstage,
+          dma_range((const char *)S.sl_box32 + (size_t)uniform_i32(ri[kHsRecSl / 4]) * (size_t)(kSlQuadFloats * 4), tstage,
                     ((pc + 3) >> 2) * (kSlQuadFloats * 4));
         }
         // ... and the block boxes of a long list (48 at a time: the counters' bytes hold 53)
@@ -2376,7 +2376,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         // which children does some lane's filter let through?  All nine boxes (eight subtrees, the
         // own list) are read in one batch and tested without branches.
         typedef float f4v __attribute__((ext_vector_type(4)));
-        const MT_LDS f4v *r4 = (const MT_LDS f4v *)(uintptr_t)rec;
         unsigned bits = 0u, any = 0u;
         if (cm != 0u) {  // (most nodes a wave enters are leaves)
           // per axis the lane's [near x 8][far x 8] planes: 64 consecutive bytes of the record's row (HsRec::kid)
@@ -2408,9 +2407,10 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         // the own list's union box decides who scans it
         bool in_list = false;
         if (pc > 0) {
-          const f4v q0 = r4[kHsRecOwn / 16], q1 = r4[kHsRecOwn / 16 + 1];
-          const float ob[6] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
-          in_list = in && subtree_may_hit(ob, f32, sxl != 0, syl != 0, szl != 0);
+          const MT_LDS float *wx = (const MT_LDS float *)(uintptr_t)(rec + (unsigned)kHsRecOwn + (sxl != 0 ? 4u : 0u));
+          const MT_LDS float *wy = (const MT_LDS float *)(uintptr_t)(rec + (unsigned)kHsRecOwn + 12u + (syl != 0 ? 4u : 0u));
+          const MT_LDS float *wz = (const MT_LDS float *)(uintptr_t)(rec + (unsigned)kHsRecOwn + 24u + (szl != 0 ? 4u : 0u));
+          in_list = in && near_far_may_hit(wx[0], wx[1], wy[0], wy[1], wz[0], wz[1], f32);
         }
         const unsigned long long lm = __ballot(in_list);
 #ifdef MT_PROF
@@ -2445,7 +2445,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           ScanOut o{-1, 0.0, 0u};
           if (in_list) {
             // (every list that comes here is longer than kHsShortList: it has a spatially sorted copy)
-            o = scan_sorted_dispatch<STATS>(S, oct, uniform_i32(ri[83]), ((pc + 63) >> 6) << 6, r, f32);
+            o = scan_sorted_dispatch<STATS>(S, oct, uniform_i32(ri[kHsRecLl / 4]), ((pc + 63) >> 6) << 6, r, f32);
             if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
           }
           if (in_list) {
