@@ -1680,7 +1680,6 @@ __device__ __attribute__((noinline)) ScanOut scan_sorted_call(const DevScene *se
   const DevScene S = scan_ctx_self(self);
   lb = uniform_i32(lb);
   n = uniform_i32(n);
-  const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
   ScanOut o{-1, 0.0, 0u};
   LaneStats st;
   st.clear();
@@ -2441,6 +2440,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           const bool one_octant = (mxs == 0 || mxs == lm) && (mys == 0 || mys == lm) && (mzs == 0 || mzs == lm);
           const int oct = one_octant ? ((mxs != 0 ? 1 : 0) | (mys != 0 ? 2 : 0) | (mzs != 0 ? 4 : 0)) : 8;
           const bool blocks_ok = pc > kHsShortList;
+          (void)blocks_ok;
           // (the triangle-parallel scan of the ordered descent for a handful of lanes was 1.3 % slower here)
           ScanOut o{-1, 0.0, 0u};
           if (in_list) {
