@@ -247,6 +247,35 @@ __device__ __forceinline__ bool moller_trumbore(const double *vtx, double ox, do
   return moller_trumbore_v(v, ox, oy, oz, dx, dy, dz, t_out);
 }
 // The same on vertices that are already in registers.
+// The same test without its early exits (primitive_triangle.cc:110-142 evaluated to the end, the four verdicts ANDed):
+// where a wave resolves candidates of many lanes at once some lane nearly always goes the whole way, and the
+// skipped arithmetic is worth less than the branches.  A rejected determinant may make the later values infinite or NaN;
+// they are never looked at.
+__device__ __forceinline__ bool moller_trumbore_flat(const double *v, double ox, double oy,
+                                                     double oz, double dx, double dy, double dz,
+                                                     double *t_out) {
+  const double v0x = v[0], v0y = v[1], v0z = v[2];
+  const double e1x = v[3] - v0x, e1y = v[4] - v0y, e1z = v[5] - v0z;
+  const double e2x = v[6] - v0x, e2y = v[7] - v0y, e2z = v[8] - v0z;
+  const double px = dy * e2z - dz * e2y;
+  const double py = dz * e2x - dx * e2z;
+  const double pz = dx * e2y - dy * e2x;
+  const double det = px * e1x + py * e1y + pz * e1z;
+  const bool det_ok = !(det >= -0.00000001 && det < 0.00000001);
+  const double inv_det = 1.0 / det;
+  const double tx = ox - v0x, ty = oy - v0y, tz = oz - v0z;
+  const double u = (px * tx + py * ty + pz * tz) * inv_det;
+  const bool u_ok = !(u < 0.0 || u > 1.0);
+  const double qx = ty * e1z - tz * e1y;
+  const double qy = tz * e1x - tx * e1z;
+  const double qz = tx * e1y - ty * e1x;
+  const double vv = (qx * dx + qy * dy + qz * dz) * inv_det;
+  const bool v_ok = !(vv < 0.0 || u + vv > 1.0);
+  const double dist = (qx * e2x + qy * e2y + qz * e2z) * inv_det;
+  const bool t_ok = !(dist < 0.0);
+  *t_out = dist;
+  return det_ok & u_ok & v_ok & t_ok;
+}
 __device__ __forceinline__ bool moller_trumbore_v(const double *v, double ox, double oy,
                                                   double oz, double dx, double dy, double dz,
                                                   double *t_out) {
@@ -1659,7 +1688,7 @@ __device__ __forceinline__ void resolve_sorted(const DevScene &S, const RayRegs 
       if (slab_pass_lane<false>(e, r)) {
         if (STATS) st.v[ST_MT_TESTS]++;
         double tt;
-        if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
+        if (moller_trumbore_flat(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
           if (t >= 0 && (best < 0 || tt < best_t || (tt == best_t && t > best))) {
             best = t;
             best_t = tt;
@@ -2224,7 +2253,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           if (slab_pass_lane<false>(e, r)) {
             mt_++;
             double tt;
-            if (moller_trumbore_v(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
+            if (moller_trumbore_flat(v, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, &tt)) {
               if (!(b_ >= 0 && tt > bt_)) {
                 b_ = t;
                 bt_ = tt;
