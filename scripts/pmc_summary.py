@@ -35,8 +35,19 @@ def by_kernel(rows, value):
     return out
 
 
+def newest_per_dir(pattern):
+    """One file per pass directory: gpurun MERGES a call's output into gpurun_out/, so an earlier run of the same tag
+    leaves its files (other process ids in their names) beside the new ones -- only the newest of each directory counts."""
+    best = {}
+    for f in glob.glob(pattern, recursive=True):
+        d = os.path.dirname(f)
+        if d not in best or os.path.getmtime(f) > os.path.getmtime(best[d]):
+            best[d] = f
+    return sorted(best.values())
+
+
 dur = {}
-for f in glob.glob(os.path.join(base, "stats", "**", "*kernel_trace.csv"), recursive=True):
+for f in newest_per_dir(os.path.join(base, "stats", "**", "*kernel_trace.csv")):
     dur = by_kernel(list(csv.DictReader(open(f))), lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
 print("kernel durations, rocprofv3 --kernel-trace (ms per launch, in launch order)")
 ms = None
@@ -50,7 +61,7 @@ for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         print("     launches [%d, %d): %s" % (args.skip, args.skip + len(t), " ".join("%.3f" % x for x in t)))
         print("     mean %.3f  min %.3f  max %.3f" % (ms, min(t), max(t)))
 cnt = collections.defaultdict(dict)
-for f in sorted(glob.glob(os.path.join(base, "pmc*", "**", "*counter_collection.csv"), recursive=True)):
+for f in newest_per_dir(os.path.join(base, "pmc*", "**", "*counter_collection.csv")):
     rows = list(csv.DictReader(open(f)))
     for c in sorted(set(r["Counter_Name"] for r in rows)):
         per = by_kernel([r for r in rows if r["Counter_Name"] == c], lambda r: float(r["Counter_Value"]))
