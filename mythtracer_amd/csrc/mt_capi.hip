@@ -941,7 +941,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
         todo.push_back({lo + left, hi});
       }
       h.ll_begin = (int32_t)ll_tri.size();
-      const int padded = ((pc + 63) / 64) * 64;
+      const int padded = ((pc + kLlPad - 1) / kLlPad) * kLlPad;
       for (int k = 0; k < padded; k++) {
         if (k < pc) {
           const int32_t t = order[(size_t)k];
@@ -1007,6 +1007,26 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   if ((rc = upload(s, ll_exact.data(), ll_exact.size(), &s->dev.ll_exact)) != MT_OK) return rc;
   if ((rc = upload(s, ll_grp.data(), ll_grp.size(), &s->dev.ll_grp32)) != MT_OK) return rc;
   if ((rc = upload(s, ll_sup.data(), ll_sup.size(), &s->dev.ll_sup32)) != MT_OK) return rc;
+  {  // the three levels once more as quads for the walk's per-lane reads (DevScene::ll_*_q; layout of sl_box32)
+    auto quads = [&](const std::vector<float> &src, size_t n_boxes) {
+      std::vector<float> q(((n_boxes + 3) / 4 + 1) * (size_t)kSlQuadFloats, 0.0f);
+      for (size_t i = 0; i < ((n_boxes + 3) / 4) * 4; i++) {
+        for (int a = 0; a < 3; a++) {
+          const float lo = i < n_boxes ? src[i * 6 + a] : 3.0e38f, hi = i < n_boxes ? src[i * 6 + 3 + a] : -3.0e38f;
+          float *d4 = &q[(i / 4) * kSlQuadFloats + (size_t)a * 12 + (i & 3)];
+          d4[0] = lo;
+          d4[4] = hi;
+          d4[8] = lo;
+        }
+      }
+      return q;
+    };
+    const size_t n_entries = ll_tri.size() - 64;  // (without the look-ahead padding of the scalar-stream scans)
+    const std::vector<float> qb = quads(ll_box, n_entries), qg = quads(ll_grp, n_entries / 16), qs = quads(ll_sup, n_entries / 64);
+    if ((rc = upload(s, qb.data(), qb.size(), &s->dev.ll_box_q)) != MT_OK) return rc;
+    if ((rc = upload(s, qg.data(), qg.size(), &s->dev.ll_grp_q)) != MT_OK) return rc;
+    if ((rc = upload(s, qs.data(), qs.size(), &s->dev.ll_sup_q)) != MT_OK) return rc;
+  }
   sl_box.resize(sl_box.size() + 2 * kSlQuadFloats, 0.0f);  // (the copies are whole 16-byte pieces; never empty)
   if ((rc = upload(s, sl_box.data(), sl_box.size(), &s->dev.sl_box32)) != MT_OK) return rc;
   if ((rc = upload(s, recs.data(), recs.size(), &s->dev.nodes)) != MT_OK) return rc;

@@ -86,6 +86,7 @@ constexpr int kHsRecLanes = 27;   // 16 bytes per lane
 #define MT_HS_SHORT 32
 #endif
 constexpr int kHsShortList = MT_HS_SHORT;  // own lists up to this length are scanned from LDS (64 fp32 boxes staged behind the frames; one candidate bit each)
+constexpr int kLlPad = 256;        // sorted long lists start at, and are padded to, multiples of this many entries (four supers = one quad of super boxes)
 constexpr int kSlQuadFloats = 36;  // DevScene::sl_box32: four boxes = per axis [lo x 4][hi x 4][lo x 4] (144 bytes)
 
 struct DevTexture {
@@ -115,6 +116,9 @@ struct DevScene {
   const float *ll_aabb32;    // 6 per entry
   const float *ll_grp32;     // 6 per 16 entries
   const float *ll_sup32;     // 6 per 64 entries
+  // the same three levels as quads in the layout of sl_box32 (kSlQuadFloats floats per four boxes): entry quad e / 4,
+  // block quad e / 64 (the four blocks of a super), super quad e / 256 -- every list starts at a multiple of kLlPad
+  const float *ll_box_q, *ll_grp_q, *ll_sup_q;
   // The SHORT lists' fp32 boxes once more (1..kHsShortList triangles, list order), laid out for the walk's per-lane
   // reads: per quad of list positions kSlQuadFloats floats = per axis [lo x 4][hi x 4][lo x 4]; a list starts at quad
   // HsRec::sl_begin and is padded to whole quads with inverted boxes.

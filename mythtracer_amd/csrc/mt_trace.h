@@ -1922,6 +1922,11 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   S.sub_aabb32 = G->sub_aabb32;
   S.hs_rec = G->hs_rec;
   S.sl_box32 = G->sl_box32;
+  S.ll_box_q = G->ll_box_q;
+  S.ll_grp_q = G->ll_grp_q;
+  S.ll_sup_q = G->ll_sup_q;
+  S.ll_tri = G->ll_tri;
+  S.ll_exact = G->ll_exact;
   S.self = uniform_ptr(scene);
   S.tri_vertex = G->tri_vertex;
   S.bmax[0] = G->bmax[0]; S.bmax[1] = G->bmax[1]; S.bmax[2] = G->bmax[2];
@@ -2238,6 +2243,99 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       }
       return (unsigned long long)(cand & (n >= 32 ? ~0u : ((1u << n) - 1u)));
     };
+    // fp32 verdicts on nq staged quads (layout of DevScene::sl_box32) at lds: nibble q of the result = this lane's ray
+    // may hit boxes 4 q .. 4 q + 3; bit 4 q + j of `any` = some lane of amask may hit box 4 q + j (read off the
+    // compares' lane masks)
+    auto quads_verdicts = [&](unsigned lds, int nq, unsigned long long amask, unsigned &any) -> unsigned {
+      typedef float f4v_ __attribute__((ext_vector_type(4)));
+      const unsigned bx = lds + (sxl != 0 ? 16u : 0u), by = lds + 48u + (syl != 0 ? 16u : 0u), bz = lds + 96u + (szl != 0 ? 16u : 0u);
+      unsigned w = 0u;
+      for (int q = 0; q < nq; q++) {
+        const unsigned o = (unsigned)q * (unsigned)(kSlQuadFloats * 4);
+        const MT_LDS f4v_ *px = (const MT_LDS f4v_ *)(uintptr_t)(bx + o);
+        const MT_LDS f4v_ *py = (const MT_LDS f4v_ *)(uintptr_t)(by + o);
+        const MT_LDS f4v_ *pz = (const MT_LDS f4v_ *)(uintptr_t)(bz + o);
+        const f4v_ nx = px[0], fx = px[1], ny = py[0], fy = py[1], nz = pz[0], fz = pz[1];
+        const bool p0 = near_far_may_hit(nx.x, fx.x, ny.x, fy.x, nz.x, fz.x, f32);
+        const bool p1 = near_far_may_hit(nx.y, fx.y, ny.y, fy.y, nz.y, fz.y, f32);
+        const bool p2 = near_far_may_hit(nx.z, fx.z, ny.z, fy.z, nz.z, fz.z, f32);
+        const bool p3 = near_far_may_hit(nx.w, fx.w, ny.w, fy.w, nz.w, fz.w, f32);
+        const unsigned q4 = (p0 ? 1u : 0u) | (p1 ? 2u : 0u) | (p2 ? 4u : 0u) | (p3 ? 8u : 0u);
+        w |= q4 << (4 * q);
+        unsigned a4 = 0u;
+        if ((__ballot(p0) & amask) != 0ull) a4 |= 1u;
+        if ((__ballot(p1) & amask) != 0ull) a4 |= 2u;
+        if ((__ballot(p2) & amask) != 0ull) a4 |= 4u;
+        if ((__ballot(p3) & amask) != 0ull) a4 |= 8u;
+        any |= a4 << (4 * q);
+      }
+      return w;
+    };
+    // Own list longer than kHsShortList through its spatially sorted copy (DevScene::ll_*), level by level through LDS:
+    // the super boxes of up to 1 024 entries by one copy; the block quads of up to six live supers GATHERED by one copy
+    // (lane 9 g + r reads piece r of the g-th live super's quad); the entry quads of two live blocks per copy; every
+    // lane marks its candidates of a super's 64 entries and resolves them in any order (resolve_sorted).  Which
+    // supers / blocks are live is wave-uniform (some lane of `act` may hit the box).
+    auto scan_long = [&](int lb, int n, bool act, int &b_, double &bt_, LaneStats &ls) {
+      const unsigned long long amask = __ballot(act);
+      const char *const supq = (const char *)S.ll_sup_q, *const grpq = (const char *)S.ll_grp_q, *const boxq = (const char *)S.ll_box_q;
+      const int n_sup = n >> 6;
+      const unsigned g9 = (unsigned)lane / 9u, r9 = (unsigned)lane - g9 * 9u;
+      const unsigned qb = (unsigned)(kSlQuadFloats * 4);  // bytes of a quad
+      for (int s0 = 0; s0 < n_sup; s0 += 16) {
+        const int nq = (n_sup - s0) >= 16 ? 4 : ((n_sup - s0 + 3) >> 2);
+        dma_range(supq + (size_t)((lb >> 8) + (s0 >> 2)) * qb, tstage, nq * (int)qb);
+        wait_vm(0);
+        unsigned sup_any = 0u;
+        (void)quads_verdicts(tstage, nq, amask, sup_any);
+        sup_any = (unsigned)uniform_i32((int)sup_any);
+        if (STATS) ls.bytes_scalar += (unsigned)nq * qb;
+        while (sup_any != 0u) {
+          // up to six live supers of this round: chunk = their bits, in ascending order
+          unsigned chunk = 0u;
+          int cnt = 0, mine = -1;
+          while (sup_any != 0u && cnt < 6) {
+            const int sj = __builtin_ctz(sup_any);
+            sup_any &= sup_any - 1u;
+            chunk |= 1u << sj;
+            if ((int)g9 == cnt) mine = sj;
+            cnt++;
+          }
+          if (mine >= 0) lds_dma16(grpq + (size_t)((lb >> 6) + s0 + mine) * qb + (size_t)r9 * 16, tstage);
+          wait_vm(0);
+          unsigned blk_any = 0u;
+          (void)quads_verdicts(tstage, cnt, amask, blk_any);
+          blk_any = (unsigned)uniform_i32((int)blk_any);
+          if (STATS) ls.bytes_scalar += (unsigned)cnt * qb;
+          for (int g = 0; chunk != 0u; g++) {
+            const int sj = __builtin_ctz(chunk);
+            chunk &= chunk - 1u;
+            unsigned ba = (blk_any >> (4 * g)) & 0xfu;
+            if (ba == 0u) continue;
+            const int base = lb + (s0 + sj) * 64;
+            unsigned long long cand = 0ull;
+            while (ba != 0u) {  // two live blocks per copy: four entry quads each
+              const int b0 = __builtin_ctz(ba);
+              ba &= ba - 1u;
+              int b1 = -1;
+              if (ba != 0u) {
+                b1 = __builtin_ctz(ba);
+                ba &= ba - 1u;
+              }
+              dma_range(boxq + (size_t)((base + b0 * 16) >> 2) * qb, tstage, 4 * (int)qb);
+              if (b1 >= 0) dma_range(boxq + (size_t)((base + b1 * 16) >> 2) * qb, tstage + 4u * qb, 4 * (int)qb);
+              wait_vm(0);
+              unsigned unused = 0u;
+              cand |= (unsigned long long)quads_verdicts(tstage, 4, amask, unused) << (b0 * 16);
+              if (b1 >= 0) cand |= (unsigned long long)quads_verdicts(tstage + 4u * qb, 4, amask, unused) << (b1 * 16);
+              if (STATS) ls.bytes_scalar += (b1 >= 0 ? 8u : 4u) * qb;
+            }
+            if (!act) cand = 0ull;
+            if (__ballot(cand != 0ull) != 0ull) resolve_sorted<STATS>(S, r, base, cand, b_, bt_, ls);
+          }
+        }
+      }
+    };
     // every lane resolves ITS candidates of the list starting at stream position pb_ in list order
     // (octtree.cc:177-196): exact box and vertices are fetched together, one round trip per candidate
     auto resolve_list = [&](int pb_, unsigned long long cand, int &b_, double &bt_, unsigned &mt_, unsigned &bv_) {
@@ -2471,6 +2569,20 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           const bool blocks_ok = pc > kHsShortList;
           (void)blocks_ok;
           // (the triangle-parallel scan of the ordered descent for a handful of lanes was 1.3 % slower here)
+#ifndef MT_LL_SCALAR
+          (void)oct;
+          {
+            // (every list that comes here is longer than kHsShortList: it has a spatially sorted copy)
+            LaneStats ls;
+            ls.clear();
+            scan_long(uniform_i32(ri[kHsRecLl / 4]), ((pc + kLlPad - 1) / kLlPad) * kLlPad, in_list, best, best_t, ls);
+            if (STATS) {
+              st.bytes_scalar += ls.bytes_scalar;
+              if (ls.v[ST_MT_TESTS]) MT_CNT_ADD(3, ls.v[ST_MT_TESTS]);
+              if (ls.v[ST_BYTES_VECTOR]) MT_CNT_ADD(4, ls.v[ST_BYTES_VECTOR]);
+            }
+          }
+#else
           ScanOut o{-1, 0.0, 0u};
           if (in_list) {
             // (every list that comes here is longer than kHsShortList: it has a spatially sorted copy)
@@ -2483,6 +2595,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
             if (STATS && o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
             if (STATS && o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
           }
+#endif
 #ifdef MT_PROF
           asm volatile("" :: "v"(best), "v"(best_t));
           if (blocks_ok) { MT_PROF_END(PROF_HS_BIG_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_BIG, 1); MT_PROF_COUNT(PROF_HS_BIG_TRIS, pc); }
