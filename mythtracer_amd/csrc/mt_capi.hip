@@ -893,7 +893,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   }
   // Spatially sorted copies of the long lists (DevScene::ll_*): a median-split tree over the boxes' centres, cut on
   // the longest axis of the centres' extent at a multiple of 64 (16 below 64) entries, so that 16 consecutive entries
-  // -- one block box -- and 64 -- one super box -- are spatial neighbours.  Every list is padded to a multiple of 64.
+  // -- one block box -- and 64 -- one super box -- are spatial neighbours.  Every list is padded to a multiple of kLlPad.
   std::vector<int32_t> ll_tri;
   std::vector<float> ll_box, ll_grp, ll_sup;
   std::vector<double> ll_exact;
@@ -972,12 +972,8 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
     };
     unions(ll_box, 16, &ll_grp);
     unions(ll_grp, 4, &ll_sup);
-    // look-ahead padding of the scalar-stream scans (four boxes ahead)
-    ll_tri.resize(ll_tri.size() + 64, -1);
-    ll_box.resize(ll_box.size() + 64 * 6, 0.0f);
+    ll_tri.resize(ll_tri.size() + 64, -1);  // (never empty)
     ll_exact.resize(ll_exact.size() + 15, 0.0);
-    ll_grp.resize(ll_grp.size() + 16 * 6, 0.0f);
-    ll_sup.resize(ll_sup.size() + 16 * 6, 0.0f);
   }
   // Second level (mt_device.h kSuperBlocks): one fp32 union box per 8 consecutive blocks, for the long lists.
   std::vector<float> supers;
@@ -1003,10 +999,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   if ((rc = upload(s, subs.data(), subs.size(), &s->dev.sub_aabb32)) != MT_OK) return rc;
   if ((rc = upload(s, hsr.data(), hsr.size(), &s->dev.hs_rec)) != MT_OK) return rc;
   if ((rc = upload(s, ll_tri.data(), ll_tri.size(), &s->dev.ll_tri)) != MT_OK) return rc;
-  if ((rc = upload(s, ll_box.data(), ll_box.size(), &s->dev.ll_aabb32)) != MT_OK) return rc;
   if ((rc = upload(s, ll_exact.data(), ll_exact.size(), &s->dev.ll_exact)) != MT_OK) return rc;
-  if ((rc = upload(s, ll_grp.data(), ll_grp.size(), &s->dev.ll_grp32)) != MT_OK) return rc;
-  if ((rc = upload(s, ll_sup.data(), ll_sup.size(), &s->dev.ll_sup32)) != MT_OK) return rc;
   {  // the three levels once more as quads for the walk's per-lane reads (DevScene::ll_*_q; layout of sl_box32)
     auto quads = [&](const std::vector<float> &src, size_t n_boxes) {
       std::vector<float> q(((n_boxes + 3) / 4 + 1) * (size_t)kSlQuadFloats, 0.0f);
@@ -1021,7 +1014,7 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
       }
       return q;
     };
-    const size_t n_entries = ll_tri.size() - 64;  // (without the look-ahead padding of the scalar-stream scans)
+    const size_t n_entries = ll_tri.size() - 64;
     const std::vector<float> qb = quads(ll_box, n_entries), qg = quads(ll_grp, n_entries / 16), qs = quads(ll_sup, n_entries / 64);
     if ((rc = upload(s, qb.data(), qb.size(), &s->dev.ll_box_q)) != MT_OK) return rc;
     if ((rc = upload(s, qg.data(), qg.size(), &s->dev.ll_grp_q)) != MT_OK) return rc;

@@ -87,6 +87,10 @@ constexpr int kHsRecLanes = 27;   // 16 bytes per lane
 #endif
 constexpr int kHsShortList = MT_HS_SHORT;  // own lists up to this length are scanned from LDS (64 fp32 boxes staged behind the frames; one candidate bit each)
 constexpr int kLlPad = 256;        // sorted long lists start at, and are padded to, multiples of this many entries (four supers = one quad of super boxes)
+#ifndef MT_LL_DIRECT
+#define MT_LL_DIRECT 6
+#endif
+constexpr int kLlDirect = MT_LL_DIRECT;  // lists of up to this many supers (x 64 entries): block quads without the super level (<= 6: one gathered copy)
 constexpr int kSlQuadFloats = 36;  // DevScene::sl_box32: four boxes = per axis [lo x 4][hi x 4][lo x 4] (144 bytes)
 
 struct DevTexture {
@@ -109,15 +113,13 @@ struct DevScene {
   // fold is the minimum under (distance ascending, list position descending), whatever the order of evaluation -- so
   // the CULLING structure over a list is free: here the list's triangles in the order of a median-split tree over
   // their boxes, 16 consecutive ones under one fp32 union box, 4 such blocks under another.  Every list starts at a
-  // multiple of 64 entries and is padded to one (ll_tri = -1, inverted boxes).  ll_tri = the triangle's stream index
+  // multiple of kLlPad entries and is padded to one (ll_tri = -1, inverted boxes).  ll_tri = the triangle's stream index
   // (= its list position: the tie rule's rank).
   const int32_t *ll_tri;
   const double *ll_exact;    // 15 per entry: the triangle's fp64 box (6) and vertices (9), for the candidates
-  const float *ll_aabb32;    // 6 per entry
-  const float *ll_grp32;     // 6 per 16 entries
-  const float *ll_sup32;     // 6 per 64 entries
-  // the same three levels as quads in the layout of sl_box32 (kSlQuadFloats floats per four boxes): entry quad e / 4,
-  // block quad e / 64 (the four blocks of a super), super quad e / 256 -- every list starts at a multiple of kLlPad
+  // the entries' fp32 boxes, a union box per 16 entries (block) and per 64 (super), as quads in the layout of sl_box32
+  // (kSlQuadFloats floats per four boxes): entry quad e / 4, block quad e / 64 (the four blocks of a super), super
+  // quad e / 256 -- every list starts at a multiple of kLlPad
   const float *ll_box_q, *ll_grp_q, *ll_sup_q;
   // The SHORT lists' fp32 boxes once more (1..kHsShortList triangles, list order), laid out for the walk's per-lane
   // reads: per quad of list positions kSlQuadFloats floats = per axis [lo x 4][hi x 4][lo x 4]; a list starts at quad

@@ -616,30 +616,6 @@ __device__ __forceinline__ unsigned long long filter32_pass(const float *b, cons
   return __builtin_amdgcn_fcmpf(hi, 0.0f, kUGE) & __builtin_amdgcn_fcmpf(lo, hi, kULE);
 }
 
-// The same verdict for the lane itself (a select's condition instead of a lane mask).
-template <int OCT>
-__device__ __forceinline__ bool filter32_lane(const float *b, const Filter32 &f) {
-  static_assert(OCT >= 0 && OCT <= 8, "octant 0..7, or 8 = lanes of several octants");
-  float tnx, tny, tnz, tfx, tfy, tfz;
-  if constexpr (OCT == 8) {
-    tnx = __builtin_fminf(__builtin_fmaf(b[0], f.ix, f.cnx), __builtin_fmaf(b[3], f.ix, f.cnx));
-    tfx = __builtin_fmaxf(__builtin_fmaf(b[0], f.ix, f.cfx), __builtin_fmaf(b[3], f.ix, f.cfx));
-    tny = __builtin_fminf(__builtin_fmaf(b[1], f.iy, f.cny), __builtin_fmaf(b[4], f.iy, f.cny));
-    tfy = __builtin_fmaxf(__builtin_fmaf(b[1], f.iy, f.cfy), __builtin_fmaf(b[4], f.iy, f.cfy));
-    tnz = __builtin_fminf(__builtin_fmaf(b[2], f.iz, f.cnz), __builtin_fmaf(b[5], f.iz, f.cnz));
-    tfz = __builtin_fmaxf(__builtin_fmaf(b[2], f.iz, f.cfz), __builtin_fmaf(b[5], f.iz, f.cfz));
-  } else {
-    constexpr int NX = (OCT & 1) ? 3 : 0, FX = (OCT & 1) ? 0 : 3;
-    constexpr int NY = (OCT & 2) ? 4 : 1, FY = (OCT & 2) ? 1 : 4;
-    constexpr int NZ = (OCT & 4) ? 5 : 2, FZ = (OCT & 4) ? 2 : 5;
-    tnx = __builtin_fmaf(b[NX], f.ix, f.cnx); tfx = __builtin_fmaf(b[FX], f.ix, f.cfx);
-    tny = __builtin_fmaf(b[NY], f.iy, f.cny); tfy = __builtin_fmaf(b[FY], f.iy, f.cfy);
-    tnz = __builtin_fmaf(b[NZ], f.iz, f.cnz); tfz = __builtin_fmaf(b[FZ], f.iz, f.cfz);
-  }
-  const float lo0 = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
-  const float hi = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
-  return !(lo0 > hi);  // (= !(hi < 0) && !(lo > hi); NaN: keep)
-}
 
 // One per-lane box (a child's subtree box) against the lane's own filter.
 __device__ __forceinline__ bool subtree_may_hit(const float *b, const Filter32 &f, bool sx, bool sy, bool sz) {
@@ -688,36 +664,6 @@ __device__ __forceinline__ void issue_quad(QuadRegs &q, const MT_CONST float *p)
 }
 __device__ __forceinline__ void await_quad(QuadRegs &q) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.lo), "+s"(q.hi));
-}
-
-// Eight fp32 boxes (192 bytes) in ONE round trip: four scalar loads issued by one asm statement into one buffer of 48
-// SGPRs, awaited together (the sorted long lists: a block of 16 entries is two of these instead of four dependent
-// quad fetches; tools/check_asm_prefetch.py treats the statement's destinations as one set in flight).
-struct OctRegs {
-  f16v lo0;
-  f8v hi0;
-  f16v lo1;
-  f8v hi1;
-};
-__device__ __forceinline__ void issue_oct(OctRegs &q, const MT_CONST float *p) {
-  asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx8 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x60\n\ts_load_dwordx8 %3, %4, 0xa0"
-               : "=&s"(q.lo0), "=&s"(q.hi0), "=&s"(q.lo1), "=&s"(q.hi1)
-               : "s"(p));
-}
-__device__ __forceinline__ void await_oct(OctRegs &q) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.lo0), "+s"(q.hi0), "+s"(q.lo1), "+s"(q.hi1));
-}
-
-// The lane's verdicts on the four boxes of a quad as one nibble (bit j = box j may be hit): four selects between
-// inline constants and two ORs, to be shifted into a candidate word once.
-template <int OCT>
-__device__ __forceinline__ unsigned quad_nibble(const Filter32 &f, const f16v &lo, const f8v &hi) {
-  const float b0[6] = {lo[0], lo[1], lo[2], lo[3], lo[4], lo[5]};
-  const float b1[6] = {lo[6], lo[7], lo[8], lo[9], lo[10], lo[11]};
-  const float b2[6] = {lo[12], lo[13], lo[14], lo[15], hi[0], hi[1]};
-  const float b3[6] = {hi[2], hi[3], hi[4], hi[5], hi[6], hi[7]};
-  return (filter32_lane<OCT>(b0, f) ? 1u : 0u) | (filter32_lane<OCT>(b1, f) ? 2u : 0u) |
-         (filter32_lane<OCT>(b2, f) ? 4u : 0u) | (filter32_lane<OCT>(b3, f) ? 8u : 0u);
 }
 
 // Four boxes (stream positions k..k+3): fp32 verdicts, then the exact fp64
@@ -1498,9 +1444,6 @@ __device__ __forceinline__ DevScene scan_ctx_self(const DevScene *self) {
   S.tri_vertex = G->tri_vertex;
   S.ll_tri = G->ll_tri;
   S.ll_exact = G->ll_exact;
-  S.ll_aabb32 = G->ll_aabb32;
-  S.ll_grp32 = G->ll_grp32;
-  S.ll_sup32 = G->ll_sup32;
   S.self = uniform_ptr(self);
   return S;
 }
@@ -1665,10 +1608,10 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
 
 
 // ---- long list through its spatially sorted copy (DevScene::ll_*; hit-set walk, NaN-free rays only) -----------------
-// lb = the list's first entry in the sorted copy, n = its padded length (multiples of 64).  Super boxes (one per 64
-// entries) -> block boxes of the live supers -> the fp32 boxes of the live blocks' entries mark per-lane candidates ->
-// every lane resolves its candidates (exact fp64 box, Moeller-Trumbore) in ANY order and keeps the minimum under
-// (distance, -stream index): the reference's fold (octtree.cc:177-196) for distances that cannot be NaN.
+// The walk's scan_long marks per-lane candidates among a super's 64 entries (super boxes -> block boxes of the live
+// supers -> the fp32 boxes of the live blocks' entries, all staged through LDS); here every lane resolves its
+// candidates (exact fp64 box, Moeller-Trumbore) in ANY order and keeps the minimum under (distance, -stream index):
+// the reference's fold (octtree.cc:177-196) for distances that cannot be NaN.
 template <bool STATS>
 __device__ __forceinline__ void resolve_sorted(const DevScene &S, const RayRegs &r, int base, unsigned long long &cand,
                                                int &best, double &best_t, LaneStats &st) {
@@ -1700,87 +1643,6 @@ __device__ __forceinline__ void resolve_sorted(const DevScene &S, const RayRegs 
   cand = 0ull;
 }
 
-template <int OCT, bool STATS>
-__device__ __attribute__((noinline)) ScanOut scan_sorted_call(const DevScene *self, int lb, int n, MT_RAY_PARAMS,
-                                                              MT_F32_PARAMS) {
-  MT_RAY_FROM_PARAMS(r);
-  MT_F32_FROM_PARAMS(f);
-  self = uniform_ptr(self);
-  const DevScene S = scan_ctx_self(self);
-  lb = uniform_i32(lb);
-  n = uniform_i32(n);
-  ScanOut o{-1, 0.0, 0u};
-  LaneStats st;
-  st.clear();
-  const MT_CONST float *sup = as_const(S.ll_sup32) + (size_t)(lb / 64) * 6;
-  const MT_CONST float *grp = as_const(S.ll_grp32) + (size_t)(lb / 16) * 6;
-  const int n_sup = n / 64;
-  for (int s0 = 0; s0 < n_sup; s0 += 16) {  // (16 supers = 64 blocks = 1 024 entries per round)
-    const int ns = (n_sup - s0) < 16 ? (n_sup - s0) : 16;
-    // which blocks of this round may some lane hit?  Short rounds (fewer than kSuperMin blocks): the block boxes
-    // directly, one dependent fetch fewer; else the super boxes first and the block boxes of the live supers
-    unsigned long long live = 0ull;
-    if (ns * 4 < kSuperMin) {
-      live = group_live_mask<OCT>(grp + (size_t)s0 * 4 * 6, ns * 4, f);
-      if (STATS) st.bytes_scalar += 96u * (unsigned)(ns + 1);
-    } else {
-      unsigned long long sl = group_live_mask<OCT>(sup + (size_t)s0 * 6, ns, f);
-      if (STATS) st.bytes_scalar += 96u * (unsigned)((ns + 3) / 4 + 1);
-      while (sl != 0ull) {
-        const int sj = __builtin_ctzll(sl);
-        sl &= sl - 1ull;
-        live |= group_live_mask<OCT>(grp + (size_t)(s0 + sj) * 4 * 6, 4, f) << (4 * sj);
-        if (STATS) st.bytes_scalar += 96u * 2u;
-      }
-    }
-    while (live != 0ull) {
-      const int sj = __builtin_ctzll(live) >> 2;
-      const int si = s0 + sj;
-      unsigned long long bl = (live >> (4 * sj)) & 0xfull;
-      live &= ~(0xfull << (4 * sj));
-      // the live blocks of this super: their entries' fp32 boxes, four per scalar fetch; candidates of the super's 64
-      // entries in one word
-      unsigned long long cand = 0ull;
-      const int base = lb + si * 64;
-      const MT_CONST float *tb = as_const(S.ll_aabb32) + (size_t)base * 6;
-      while (bl != 0ull) {
-        const int b = __builtin_ctzll(bl);
-        bl &= bl - 1ull;
-        OctRegs Q;
-        const MT_CONST float *p = tb + (size_t)b * 16 * 6;
-        issue_oct(Q, p);
-        await_oct(Q);
-        unsigned w = quad_nibble<OCT>(f, Q.lo0, Q.hi0) | (quad_nibble<OCT>(f, Q.lo1, Q.hi1) << 4);
-        issue_oct(Q, p + 48);
-        await_oct(Q);
-        w |= (quad_nibble<OCT>(f, Q.lo0, Q.hi0) << 8) | (quad_nibble<OCT>(f, Q.lo1, Q.hi1) << 12);
-        cand |= (unsigned long long)w << (b * 16);  // (padding entries hold inverted boxes: never marked)
-        if (STATS) st.bytes_scalar += 96u * 4u;
-      }
-      if (__ballot(cand != 0ull) != 0ull) resolve_sorted<STATS>(S, r, base, cand, o.best, o.best_t, st);
-    }
-  }
-  o.mt_tests = st.v[ST_MT_TESTS];
-  o.bytes_v = st.v[ST_BYTES_VECTOR];
-  o.bytes_s = st.bytes_scalar;
-  return o;
-}
-
-template <bool STATS>
-__device__ __forceinline__ ScanOut scan_sorted_dispatch(const DevScene &S, int oct, int lb, int n, const RayRegs &r,
-                                                        const Filter32 &f) {
-  switch (oct) {
-    case 0: return scan_sorted_call<0, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
-    case 1: return scan_sorted_call<1, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
-    case 2: return scan_sorted_call<2, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
-    case 3: return scan_sorted_call<3, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
-    case 4: return scan_sorted_call<4, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
-    case 5: return scan_sorted_call<5, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
-    case 6: return scan_sorted_call<6, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
-    case 7: return scan_sorted_call<7, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
-    default: return scan_sorted_call<8, STATS>(S.self, lb, n, MT_RAY_ARGS(r), MT_F32_ARGS(f));
-  }
-}
 
 template <int MODE, int OCT, bool STATS>
 __device__ __attribute__((noinline)) ScanOut scan_exact_call(const double *b64, const double *vtx, int pb,
@@ -2276,20 +2138,33 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // (lane 9 g + r reads piece r of the g-th live super's quad); the entry quads of two live blocks per copy; every
     // lane marks its candidates of a super's 64 entries and resolves them in any order (resolve_sorted).  Which
     // supers / blocks are live is wave-uniform (some lane of `act` may hit the box).
+    // (a list of up to kLlDirect supers skips the super boxes: the block quads of all its supers are one copy)
+    // (n = the list's length: (n + 63) / 64 supers hold entries, the copy is padded to a multiple of kLlPad)
+    auto long_first_copy = [&](int lb, int n) {
+      const unsigned qb = (unsigned)(kSlQuadFloats * 4);
+      const int n_sup = (n + 63) >> 6;
+      if (n_sup <= kLlDirect) dma_range((const char *)S.ll_grp_q + (size_t)(lb >> 6) * qb, tstage, n_sup * (int)qb);
+      else dma_range((const char *)S.ll_sup_q + (size_t)(lb >> 8) * qb, tstage, (n_sup >= 16 ? 4 : ((n_sup + 3) >> 2)) * (int)qb);
+    };
     auto scan_long = [&](int lb, int n, bool act, int &b_, double &bt_, LaneStats &ls) {
       const unsigned long long amask = __ballot(act);
       const char *const supq = (const char *)S.ll_sup_q, *const grpq = (const char *)S.ll_grp_q, *const boxq = (const char *)S.ll_box_q;
-      const int n_sup = n >> 6;
+      const int n_sup = (n + 63) >> 6;
       const unsigned g9 = (unsigned)lane / 9u, r9 = (unsigned)lane - g9 * 9u;
       const unsigned qb = (unsigned)(kSlQuadFloats * 4);  // bytes of a quad
+      const bool direct = n_sup <= kLlDirect;
       for (int s0 = 0; s0 < n_sup; s0 += 16) {
-        const int nq = (n_sup - s0) >= 16 ? 4 : ((n_sup - s0 + 3) >> 2);
-        dma_range(supq + (size_t)((lb >> 8) + (s0 >> 2)) * qb, tstage, nq * (int)qb);
-        wait_vm(0);
         unsigned sup_any = 0u;
-        (void)quads_verdicts(tstage, nq, amask, sup_any);
-        sup_any = (unsigned)uniform_i32((int)sup_any);
-        if (STATS) ls.bytes_scalar += (unsigned)nq * qb;
+        if (direct) {
+          sup_any = (1u << n_sup) - 1u;  // (all of them "live": their block quads are already on their way)
+        } else {
+          const int nq = (n_sup - s0) >= 16 ? 4 : ((n_sup - s0 + 3) >> 2);
+          if (s0 != 0) dma_range(supq + (size_t)((lb >> 8) + (s0 >> 2)) * qb, tstage, nq * (int)qb);  // (round 0: long_first_copy)
+          wait_vm(0);
+          (void)quads_verdicts(tstage, nq, amask, sup_any);
+          sup_any = (unsigned)uniform_i32((int)sup_any);
+          if (STATS) ls.bytes_scalar += (unsigned)nq * qb;
+        }
         while (sup_any != 0u) {
           // up to six live supers of this round: chunk = their bits, in ascending order
           unsigned chunk = 0u;
@@ -2301,7 +2176,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
             if ((int)g9 == cnt) mine = sj;
             cnt++;
           }
-          if (mine >= 0) lds_dma16(grpq + (size_t)((lb >> 6) + s0 + mine) * qb + (size_t)r9 * 16, tstage);
+          if (!direct && mine >= 0) lds_dma16(grpq + (size_t)((lb >> 6) + s0 + mine) * qb + (size_t)r9 * 16, tstage);
           wait_vm(0);
           unsigned blk_any = 0u;
           (void)quads_verdicts(tstage, cnt, amask, blk_any);
@@ -2485,10 +2360,9 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           dma_range((const char *)S.sl_box32 + (size_t)uniform_i32(ri[kHsRecSl / 4]) * (size_t)(kSlQuadFloats * 4), tstage,
                     ((pc + 3) >> 2) * (kSlQuadFloats * 4));
         }
-        // ... and the block boxes of a long list (48 at a time: the counters' bytes hold 53)
+        // ... and the first level of a long list's sorted copy (scan_long finds it on its way)
         const bool long_list = pc > kHsShortList;
-        const int lb0 = pb / kGroupTris, lnb = long_list ? (pb + pc - 1) / kGroupTris - lb0 + 1 : 0;
-        (void)lnb;
+        if (long_list) long_first_copy(uniform_i32(ri[kHsRecLl / 4]), pc);
         if (STATS) {
           st.wave_node_steps++;
           st.wave_tri_steps += (unsigned)pc;
@@ -2563,39 +2437,19 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
           MT_PROF_END(PROF_HS_SMALL_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_SMALL, 1); MT_PROF_COUNT(PROF_HS_SMALL_TRIS, pc);
 #endif
         } else if (lm != 0ull) {
-          const unsigned long long mxs = __ballot(in_list && sxl), mys = __ballot(in_list && syl), mzs = __ballot(in_list && szl);
-          const bool one_octant = (mxs == 0 || mxs == lm) && (mys == 0 || mys == lm) && (mzs == 0 || mzs == lm);
-          const int oct = one_octant ? ((mxs != 0 ? 1 : 0) | (mys != 0 ? 2 : 0) | (mzs != 0 ? 4 : 0)) : 8;
           const bool blocks_ok = pc > kHsShortList;
           (void)blocks_ok;
-          // (the triangle-parallel scan of the ordered descent for a handful of lanes was 1.3 % slower here)
-#ifndef MT_LL_SCALAR
-          (void)oct;
           {
             // (every list that comes here is longer than kHsShortList: it has a spatially sorted copy)
             LaneStats ls;
             ls.clear();
-            scan_long(uniform_i32(ri[kHsRecLl / 4]), ((pc + kLlPad - 1) / kLlPad) * kLlPad, in_list, best, best_t, ls);
+            scan_long(uniform_i32(ri[kHsRecLl / 4]), pc, in_list, best, best_t, ls);
             if (STATS) {
               st.bytes_scalar += ls.bytes_scalar;
               if (ls.v[ST_MT_TESTS]) MT_CNT_ADD(3, ls.v[ST_MT_TESTS]);
               if (ls.v[ST_BYTES_VECTOR]) MT_CNT_ADD(4, ls.v[ST_BYTES_VECTOR]);
             }
           }
-#else
-          ScanOut o{-1, 0.0, 0u};
-          if (in_list) {
-            // (every list that comes here is longer than kHsShortList: it has a spatially sorted copy)
-            o = scan_sorted_dispatch<STATS>(S, oct, uniform_i32(ri[kHsRecLl / 4]), ((pc + 63) >> 6) << 6, r, f32);
-            if (STATS) st.bytes_scalar += (unsigned)__builtin_amdgcn_readfirstlane((int)o.bytes_s);
-          }
-          if (in_list) {
-            best = o.best;
-            best_t = o.best_t;
-            if (STATS && o.mt_tests) MT_CNT_ADD(3, o.mt_tests);
-            if (STATS && o.bytes_v) MT_CNT_ADD(4, o.bytes_v);
-          }
-#endif
 #ifdef MT_PROF
           asm volatile("" :: "v"(best), "v"(best_t));
           if (blocks_ok) { MT_PROF_END(PROF_HS_BIG_T, prof_t1); MT_PROF_COUNT(PROF_HS_N_BIG, 1); MT_PROF_COUNT(PROF_HS_BIG_TRIS, pc); }
