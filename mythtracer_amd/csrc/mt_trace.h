@@ -1613,9 +1613,9 @@ __device__ __attribute__((noinline)) ScanOut scan_grouped_call(const DevScene *s
 // candidates (exact fp64 box, Moeller-Trumbore) in ANY order and keeps the minimum under (distance, -stream index):
 // the reference's fold (octtree.cc:177-196) for distances that cannot be NaN.
 template <bool STATS>
-__device__ __forceinline__ void resolve_sorted(const DevScene &S, const RayRegs &r, int base, unsigned long long &cand,
-                                               int &best, double &best_t, LaneStats &st) {
-  const MT_CONST int32_t *lt = as_const(S.ll_tri);
+__device__ __forceinline__ void resolve_sorted(const int32_t *ll_tri, const double *ll_exact, const RayRegs &r, int base,
+                                               unsigned long long &cand, int &best, double &best_t, LaneStats &st) {
+  const MT_CONST int32_t *lt = as_const(ll_tri);
   for (int guard = 0; guard < 64 && __ballot(cand != 0ull) != 0ull; guard++) {
     if (cand != 0ull) {
       const int pos = base + __builtin_ctzll(cand);
@@ -1624,7 +1624,7 @@ __device__ __forceinline__ void resolve_sorted(const DevScene &S, const RayRegs 
       // the triangle's index travelling with them (it is only needed when the candidate is a hit; padding entries
       // hold inverted fp32 boxes and are never marked, their exact entry is all zeros and fails the determinant test)
       const int t = lt[pos];
-      const double *ep = S.ll_exact + (size_t)pos * 15;
+      const __attribute__((address_space(1))) double *ep = (const __attribute__((address_space(1))) double *)ll_exact + (size_t)pos * 15;
       const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
       const double v[9] = {ep[6], ep[7], ep[8], ep[9], ep[10], ep[11], ep[12], ep[13], ep[14]};
       if (STATS) st.v[ST_BYTES_VECTOR] += 124u;
@@ -2011,7 +2011,16 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     const unsigned stage = ((unsigned)(uintptr_t)(h_node + L * 2) + 15u) & ~15u;  // the staged HsRec (room for two)
     MT_LDS double *const h_planes = (MT_LDS double *)(uintptr_t)(stage + 2u * (unsigned)sizeof(HsRec));  // [L][10] wave-uniform
     const unsigned tstage = frames_end;                                    // a short list's staged quads of fp32 boxes (<= 1 152 B)
-    const char *const hs_bytes = (const char *)S.hs_rec;
+    // The arrays the walk reads, as values of their own: read out of the scene structure where they are used, a
+    // pointer comes as part of a sixteen-register tuple that is spilled and reloaded whole.
+    const char *hs_bytes = (const char *)S.hs_rec;
+    const char *sl_bytes = (const char *)S.sl_box32;
+    const char *supq = (const char *)S.ll_sup_q, *grpq = (const char *)S.ll_grp_q, *boxq = (const char *)S.ll_box_q;
+    const int32_t *ll_tri_ = S.ll_tri;
+    const double *ll_exact_ = S.ll_exact;
+    const double *tri_aabb_ = S.tri_aabb, *tri_vertex_ = S.tri_vertex;
+    asm volatile("" : "+s"(hs_bytes), "+s"(sl_bytes), "+s"(supq), "+s"(grpq), "+s"(boxq), "+s"(ll_tri_), "+s"(ll_exact_),
+                      "+s"(tri_aabb_), "+s"(tri_vertex_));
 #ifdef MT_PROF
     const bool tl_on = S.prof != nullptr && lane == 0 && stk.base == 0u && __builtin_amdgcn_workgroup_id_x() == 0;
     unsigned long long tl_base = 0ull;  // 512 slots per traversal, reserved with ONE atomic; the stamps are plain stores
@@ -2143,12 +2152,11 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     auto long_first_copy = [&](int lb, int n) {
       const unsigned qb = (unsigned)(kSlQuadFloats * 4);
       const int n_sup = (n + 63) >> 6;
-      if (n_sup <= kLlDirect) dma_range((const char *)S.ll_grp_q + (size_t)(lb >> 6) * qb, tstage, n_sup * (int)qb);
-      else dma_range((const char *)S.ll_sup_q + (size_t)(lb >> 8) * qb, tstage, (n_sup >= 16 ? 4 : ((n_sup + 3) >> 2)) * (int)qb);
+      if (n_sup <= kLlDirect) dma_range(grpq + (size_t)(lb >> 6) * qb, tstage, n_sup * (int)qb);
+      else dma_range(supq + (size_t)(lb >> 8) * qb, tstage, (n_sup >= 16 ? 4 : ((n_sup + 3) >> 2)) * (int)qb);
     };
     auto scan_long = [&](int lb, int n, bool act, int &b_, double &bt_, LaneStats &ls) {
       const unsigned long long amask = __ballot(act);
-      const char *const supq = (const char *)S.ll_sup_q, *const grpq = (const char *)S.ll_grp_q, *const boxq = (const char *)S.ll_box_q;
       const int n_sup = (n + 63) >> 6;
       const unsigned g9 = (unsigned)lane / 9u, r9 = (unsigned)lane - g9 * 9u;
       const unsigned qb = (unsigned)(kSlQuadFloats * 4);  // bytes of a quad
@@ -2189,24 +2197,32 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
             if (ba == 0u) continue;
             const int base = lb + (s0 + sj) * 64;
             unsigned long long cand = 0ull;
-            while (ba != 0u) {  // two live blocks per copy: four entry quads each
-              const int b0 = __builtin_ctz(ba);
-              ba &= ba - 1u;
+            // the live blocks' entries, four quads each: the next block's copy runs while this one's boxes are tested
+            int b0 = __builtin_ctz(ba);
+            ba &= ba - 1u;
+            unsigned cur = tstage, nxt = tstage + 4u * qb;
+            dma_range(boxq + (size_t)((base + b0 * 16) >> 2) * qb, cur, 4 * (int)qb);
+            for (;;) {
               int b1 = -1;
               if (ba != 0u) {
                 b1 = __builtin_ctz(ba);
                 ba &= ba - 1u;
+                dma_range(boxq + (size_t)((base + b1 * 16) >> 2) * qb, nxt, 4 * (int)qb);
+                wait_vm(1);
+              } else {
+                wait_vm(0);
               }
-              dma_range(boxq + (size_t)((base + b0 * 16) >> 2) * qb, tstage, 4 * (int)qb);
-              if (b1 >= 0) dma_range(boxq + (size_t)((base + b1 * 16) >> 2) * qb, tstage + 4u * qb, 4 * (int)qb);
-              wait_vm(0);
               unsigned unused = 0u;
-              cand |= (unsigned long long)quads_verdicts(tstage, 4, amask, unused) << (b0 * 16);
-              if (b1 >= 0) cand |= (unsigned long long)quads_verdicts(tstage + 4u * qb, 4, amask, unused) << (b1 * 16);
-              if (STATS) ls.bytes_scalar += (b1 >= 0 ? 8u : 4u) * qb;
+              cand |= (unsigned long long)quads_verdicts(cur, 4, amask, unused) << (b0 * 16);
+              if (STATS) ls.bytes_scalar += 4u * qb;
+              if (b1 < 0) break;
+              b0 = b1;
+              const unsigned t_ = cur;
+              cur = nxt;
+              nxt = t_;
             }
             if (!act) cand = 0ull;
-            if (__ballot(cand != 0ull) != 0ull) resolve_sorted<STATS>(S, r, base, cand, b_, bt_, ls);
+            if (__ballot(cand != 0ull) != 0ull) resolve_sorted<STATS>(ll_tri_, ll_exact_, r, base, cand, b_, bt_, ls);
           }
         }
       }
@@ -2214,12 +2230,13 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     // every lane resolves ITS candidates of the list starting at stream position pb_ in list order
     // (octtree.cc:177-196): exact box and vertices are fetched together, one round trip per candidate
     auto resolve_list = [&](int pb_, unsigned long long cand, int &b_, double &bt_, unsigned &mt_, unsigned &bv_) {
+      typedef const __attribute__((address_space(1))) double *gdp;
       for (int guard = 0; guard <= 64 && __ballot(cand != 0ull) != 0ull; guard++) {
         if (cand != 0ull) {
           const int t = pb_ + __builtin_ctzll(cand);
           cand &= cand - 1ull;
-          const double *ep = S.tri_aabb + (size_t)t * 6;
-          const double *vp = S.tri_vertex + (size_t)t * 9;
+          const gdp ep = (gdp)tri_aabb_ + (size_t)t * 6;
+          const gdp vp = (gdp)tri_vertex_ + (size_t)t * 9;
           const double e[6] = {ep[0], ep[1], ep[2], ep[3], ep[4], ep[5]};
           const double v[9] = {vp[0], vp[1], vp[2], vp[3], vp[4], vp[5], vp[6], vp[7], vp[8]};
           bv_ += 120u;
@@ -2357,7 +2374,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
         // a short list's fp32 boxes (DevScene::sl_box32) are copied to LDS while the children are tested
         const bool small_list = pc > 0 && pc <= kHsShortList;
         if (small_list) {
-          dma_range((const char *)S.sl_box32 + (size_t)uniform_i32(ri[kHsRecSl / 4]) * (size_t)(kSlQuadFloats * 4), tstage,
+          dma_range(sl_bytes + (size_t)uniform_i32(ri[kHsRecSl / 4]) * (size_t)(kSlQuadFloats * 4), tstage,
                     ((pc + 3) >> 2) * (kSlQuadFloats * 4));
         }
         // ... and the first level of a long list's sorted copy (scan_long finds it on its way)
