@@ -1325,3 +1325,56 @@ def test_bench_line_contract(extra):
         assert 0.2 < ro["frac"] < 1.0 and ro["pmc_source"]["measured_at_commit"]
     ex = d["extras"]
     assert ex["cold_frame_parity"] == ex["warm_same_frame"]["parity"] == ex["counters_on_frame_parity"] == d["parity"]
+
+
+@pytest.mark.parametrize("n_straddlers", [450, 1100, 6000])
+def test_long_lists_of_many_supers(engine, n_straddlers):
+    """The walk stages a long list's sorted copy level by level through LDS (scan_long): super boxes in rounds of 16
+    (1 024 entries), the block quads of the live supers gathered six at a time, the entry quads of the live blocks two
+    buffers deep.  Lists of 8, 18 and 94 supers here (the room scene's longest has 25): thin triangles that straddle the
+    root's centre planes all over the box, so that rays of every octant -- mixed within a wave, intersect_rays takes them
+    as they come -- find many supers and blocks live at once; distances tie on purpose (lattice coordinates).  Rays and a
+    frame against the oracle."""
+    rnd = scenegen.SplitMix64(977 + n_straddlers)
+    m, o = _both()
+    for s in (m, o):
+        for k in range(3):
+            s.add_material("m%d" % k, (.2 + .3 * k, .9 - .3 * k, .3), (.5, .5, .5), (.1, .1, .1), ns=4)
+    tris = []
+    n = [[0, 0, -1]] * 3
+    for k in range(n_straddlers):  # each crosses one of the centre planes (50): it cannot sink into a child
+        a = k % 3
+        c = [float(int(rnd.rng(2, 98))) for _ in range(3)]
+        c[a] = 50.0
+        v0 = list(c); v1 = list(c); v2 = list(c)
+        v0[a] -= 1.0 + float(int(rnd.rng(0, 3)))
+        v1[a] += 1.0 + float(int(rnd.rng(0, 3)))
+        v1[(a + 1) % 3] += 3.0
+        v2[(a + 2) % 3] += 3.0
+        tris.append(([v0, v1, v2], k % 3))
+    for k in range(600):  # small ones in the octants: the tree splits
+        c = [float(int(rnd.rng(1, 96))) for _ in range(3)]
+        c = [x if abs(x - 50.0) > 4.0 else x + 9.0 for x in c]
+        tris.append(([[c[0], c[1], c[2]], [c[0] + 2, c[1], c[2]], [c[0], c[1] + 2, c[2] + 1]], k % 3))
+    tris.append(([[0, 0, 0], [1, 0, 0], [0, 1, 0]], 0))
+    tris.append(([[100, 100, 100], [99, 100, 100], [100, 99, 100]], 0))
+    for s in (m, o):
+        for k, (v, mt) in enumerate(tris):
+            s.add_triangle(v, n, mtl=mt, line_no=k)
+    t = m.tree()
+    assert t["prim_count"][0] >= n_straddlers, "the straddlers must stay in the root's list"
+    rays = []
+    for i in range(4096):
+        org = [float(int(rnd.rng(-30, 130))) for _ in range(3)]
+        org[i % 3] = -40.0 if (i // 3) % 2 else 140.0
+        tgt = [float(int(rnd.rng(5, 95))) for _ in range(3)]
+        rays.append(org + [tgt[a] - org[a] for a in range(3)])
+    rays = np.array(rays)
+    want = o.intersect(rays)
+    got = M.hip_abi().intersect_rays(m.device_scene(), rays)
+    hit = want["line"] >= 0
+    assert hit.mean() > 0.1 and (want["line"][hit] < n_straddlers).mean() > 0.5
+    assert np.array_equal(got["line"], want["line"])
+    assert np.array_equal(got["t"][hit], want["t"][hit])
+    lights = [(20, 20, -60, .2, .2, .2, .8, .8, .8, .3, .3, .3), (130, 110, 160, .1, .1, .1, .6, .6, .6, .2, .2, .2)]
+    _render_both(m, o, (-60, 50, -70, 0, 40, 0, 70), 128, 96, lights)
