@@ -1983,8 +1983,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   // acceptable child with the smallest (entry distance, index).  So the order
   // in which the children are LOOKED AT is free: here the whole wave walks the
   // tree depth-first in index order, every node once for all lanes whose
-  // filter does not rule its subtree out (wave-uniform boxes, scalar loads, no
-  // per-lane stack walk, no sort), each child's result is offered to its
+  // filter does not rule its subtree out (records and boxes staged in LDS by
+  // LDS-DMA, wave-uniform control flow, no per-lane stack walk, no sort), each child's result is offered to its
   // parent's frame when the wave comes back from it (exact entry test of that
   // one child, comparison with the frame's best candidate so far), and a frame
   // is closed when its last child is done.  Nodes the reference would not have
@@ -1992,7 +1992,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   // not the result.
   // (tame: magnitudes for which no Moeller-Trumbore distance can be NaN or infinite -- |d| <= 2^100, |o| and every
   // coordinate of the scene <= 2^200: all intermediate products stay below 2^700 -- so that a list's hits may be folded
-  // in any order, scan_sorted_call)
+  // in any order, scan_long / resolve_sorted)
   const bool tame = __builtin_fabs(dx) <= 0x1p100 && __builtin_fabs(dy) <= 0x1p100 && __builtin_fabs(dz) <= 0x1p100 &&
                     __builtin_fabs(ox) <= 0x1p200 && __builtin_fabs(oy) <= 0x1p200 && __builtin_fabs(oz) <= 0x1p200;
   bool hs_done = false;
