@@ -88,9 +88,9 @@ constexpr int kHsRecLanes = 27;   // 16 bytes per lane
 constexpr int kHsShortList = MT_HS_SHORT;  // own lists up to this length are scanned from LDS (64 fp32 boxes staged behind the frames; one candidate bit each)
 constexpr int kLlPad = 256;        // sorted long lists start at, and are padded to, multiples of this many entries (four supers = one quad of super boxes)
 #ifndef MT_LL_DIRECT
-#define MT_LL_DIRECT 6
+#define MT_LL_DIRECT 2
 #endif
-constexpr int kLlDirect = MT_LL_DIRECT;  // lists of up to this many supers (x 64 entries): block quads without the super level (<= 6: one gathered copy)
+constexpr int kLlDirect = MT_LL_DIRECT;  // lists of up to this many supers (x 64 entries): block quads without the super level (<= 6: one gathered copy; 0 / 1 / 2 / 3 / 4 / 6 measured: 2)
 constexpr int kSlQuadFloats = 36;  // DevScene::sl_box32: four boxes = per axis [lo x 4][hi x 4][lo x 4] (144 bytes)
 
 struct DevTexture {
