@@ -16,8 +16,8 @@ for rep in range(3):
     cold.append(abi.render_chunk(h, sens, W, H)["stats"]["kernel_ms"])
     abi.scene_destroy(h)
 print("%%s: cold frames %%s" %% (os.environ.get("TAG"), " ".join("%%.2f" %% c for c in cold)), flush=True)
-''' % ROOT
-for cut in ("0.1", "0.2", "0.3", "0.5", "0.8"):
+''' % (ROOT, ROOT)
+for cut in os.environ.get("CUTS", "0.1,0.2,0.3,0.5,0.8").split(","):
     for cf in ("2.0", "3.0"):
         env = dict(os.environ, MT_DEBUG_CUT_SHARE=cut, MT_DEBUG_CELL_FACTOR=cf, TAG="cut %s cell factor %s" % (cut, cf))
         subprocess.run([sys.executable, "-c", code], env=env)
