@@ -1378,3 +1378,23 @@ def test_long_lists_of_many_supers(engine, n_straddlers):
     assert np.array_equal(got["t"][hit], want["t"][hit])
     lights = [(20, 20, -60, .2, .2, .2, .8, .8, .8, .3, .3, .3), (130, 110, 160, .1, .1, .1, .6, .6, .6, .2, .2, .2)]
     _render_both(m, o, (-60, 50, -70, 0, 40, 0, 70), 128, 96, lights)
+
+
+def test_bench_two_ranks_rehearsal():
+    """`bench.py --gpus 2` as the driver starts it (no launcher: it starts its own ranks), in the one-GPU rehearsal mode
+    (MT_BENCH_EMULATE_RANKS=1: both ranks on GPU 0, gloo on host copies instead of RCCL -- everything else is the code
+    of the real N-GPU run): tiles k = r (mod 2) of the 3840x2160 frame with a panning camera, gather, blit, cost-map
+    all-reduce; the line must say 2 ranks and a frame identical to the golden one."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MT_BENCH_EMULATE_RANKS="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-extras"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_reported_by_backend"] == 2 and d["scaling"] == "strong"
+    assert d["parity"].startswith("even pixels identical to the 1920x1080 golden frame")
+    assert d["exchange_ms_device"]["cost_map_bytes_all_reduced"] == 4 * ((3840 + 7) // 8) * ((2160 + 7) // 8)
