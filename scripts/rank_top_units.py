@@ -13,7 +13,7 @@ m = M.MythTracer(info["obj"]); m.set_lights(sg.ROOM_LIGHTS)
 abi = M.hip_abi(); h = m.device_scene(); abi.set_lights(h, sg.ROOM_LIGHTS)
 W, H, T = 3840, 2160, 64
 world = int(os.environ.get("WORLD", "8")); rank = int(os.environ.get("RANK", "0"))
-abi.set_engine(h, int(os.environ.get("ENGINE", "0")))
+abi.set_engine(h, int(os.environ.get("ENGINE", "2")))  # (the per-unit dump is the ray pool's; the hybrid kernel's stamps have another layout)
 sens = binding.sensor(sg.ROOM_CAMERA, W, H)
 f, s, n = tiling.rank_tiles(W, H, T, T, rank, world)
 tiles_x = (W + T - 1) // T
