@@ -1,4 +1,5 @@
-"""The longest work units of one rank's share of the 3840x2160 frame (tiles k = rank mod N, ray pool by default):
+"""(STALE since round 3: the per-unit dump has the layout scripts/unit_timeline.py decodes; this decoder prints garbage.)
+The longest work units of one rank's share of the 3840x2160 frame (tiles k = rank mod N, ray pool by default):
 where they are in the picture, how many passes they take."""
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
