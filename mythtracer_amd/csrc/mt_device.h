@@ -90,6 +90,10 @@ constexpr int kLlPad = 256;        // sorted long lists start at, and are padded
 #ifndef MT_LL_DIRECT
 #define MT_LL_DIRECT 2
 #endif
+#ifndef MT_LL_ROUND
+#define MT_LL_ROUND 28
+#endif
+constexpr int kLlRound = MT_LL_ROUND;  // supers whose boxes one copy brings (a multiple of 4; 28 = 7 quads = 1 008 bytes of the 1 536 staged; one bit each in a 32-bit word)
 constexpr int kLlDirect = MT_LL_DIRECT;  // lists of up to this many supers (x 64 entries): block quads without the super level (<= 6: one gathered copy; 0 / 1 / 2 / 3 / 4 / 6 measured: 2)
 constexpr int kSlQuadFloats = 36;  // DevScene::sl_box32: four boxes = per axis [lo x 4][hi x 4][lo x 4] (144 bytes)
 

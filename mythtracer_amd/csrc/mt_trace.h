@@ -2143,7 +2143,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       return w;
     };
     // Own list longer than kHsShortList through its spatially sorted copy (DevScene::ll_*), level by level through LDS:
-    // the super boxes of up to 1 024 entries by one copy; the block quads of up to six live supers GATHERED by one copy
+    // the super boxes of up to kLlRound supers (1 792 entries) by one copy; the block quads of up to six live supers GATHERED by one copy
     // (lane 9 g + r reads piece r of the g-th live super's quad); the entry quads of two live blocks per copy; every
     // lane marks its candidates of a super's 64 entries and resolves them in any order (resolve_sorted).  Which
     // supers / blocks are live is wave-uniform (some lane of `act` may hit the box).
@@ -2153,7 +2153,7 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       const unsigned qb = (unsigned)(kSlQuadFloats * 4);
       const int n_sup = (n + 63) >> 6;
       if (n_sup <= kLlDirect) dma_range(grpq + (size_t)(lb >> 6) * qb, tstage, n_sup * (int)qb);
-      else dma_range(supq + (size_t)(lb >> 8) * qb, tstage, (n_sup >= 16 ? 4 : ((n_sup + 3) >> 2)) * (int)qb);
+      else dma_range(supq + (size_t)(lb >> 8) * qb, tstage, (n_sup >= kLlRound ? kLlRound / 4 : ((n_sup + 3) >> 2)) * (int)qb);
     };
     auto scan_long = [&](int lb, int n, bool act, int &b_, double &bt_, LaneStats &ls) {
       const unsigned long long amask = __ballot(act);
@@ -2161,12 +2161,12 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
       const unsigned g9 = (unsigned)lane / 9u, r9 = (unsigned)lane - g9 * 9u;
       const unsigned qb = (unsigned)(kSlQuadFloats * 4);  // bytes of a quad
       const bool direct = n_sup <= kLlDirect;
-      for (int s0 = 0; s0 < n_sup; s0 += 16) {
+      for (int s0 = 0; s0 < n_sup; s0 += kLlRound) {
         unsigned sup_any = 0u;
         if (direct) {
           sup_any = (1u << n_sup) - 1u;  // (all of them "live": their block quads are already on their way)
         } else {
-          const int nq = (n_sup - s0) >= 16 ? 4 : ((n_sup - s0 + 3) >> 2);
+          const int nq = (n_sup - s0) >= kLlRound ? kLlRound / 4 : ((n_sup - s0 + 3) >> 2);
           if (s0 != 0) dma_range(supq + (size_t)((lb >> 8) + (s0 >> 2)) * qb, tstage, nq * (int)qb);  // (round 0: long_first_copy)
           wait_vm(0);
           (void)quads_verdicts(tstage, nq, amask, sup_any);
