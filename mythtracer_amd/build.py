@@ -80,13 +80,13 @@ def build_diag(verbose: bool = False) -> str:
 
 def build_knobs(verbose: bool = False) -> str:
     """-DMT_DEBUG_KNOBS: the dump facilities (MT_DEBUG_ITEM_CYCLES, _PRINT_UNITS, _TIMELINE, _HEARTBEAT), read from
-    the environment once in mt_scene_create.  Replaces lib/libmythtracer_hip.so until the next normal build
-    (experiment scripts only; never what tests or bench.py measure)."""
+    the environment once in mt_scene_create.  A library of its own, lib/libmythtracer_hip_knobs.so, loaded by the
+    experiment scripts that need the dumps (HipAbi(path)); never what tests or bench.py measure."""
+    out = os.path.join(LIB, "libmythtracer_hip_knobs.so")
     cmd = [HIPCC] + HIP_FLAGS + ["-DMT_DEBUG_KNOBS"] + os.environ.get("MT_EXTRA_FLAGS", "").split() + [
-        "-I", INC, "-I", CSRC, "-o", HIP_LIB, os.path.join(CSRC, "mt_capi.hip")]
+        "-I", INC, "-I", CSRC, "-o", out, os.path.join(CSRC, "mt_capi.hip")]
     subprocess.check_call(cmd)
-    os.utime(os.path.join(CSRC, "mt_capi.hip"))  # the next build_hip() rebuilds the shipping library
-    return HIP_LIB
+    return out
 
 
 def build_host(force: bool = False, verbose: bool = False) -> str:

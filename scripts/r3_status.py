@@ -50,7 +50,7 @@ for name in (sys.argv[1:] or ["now"]):
                     mv.append(frame(binding.sensor(c, W, H)))
                 print("[%s] %-13s 1080p: camera panning 2 deg per frame within +-16 deg: mean %.3f max %.3f" % (name, ENG[e], sum(mv) / len(mv), max(mv)), flush=True)
     if "ranks" in what:
-        W4, H4, T = 3840, 2160, 64
+        W4, H4, T = 3840, 2160, int(os.environ.get("TILE", "64"))
         s4 = binding.sensor(sg.ROOM_CAMERA, W4, H4)
         for world in [int(x) for x in os.environ.get("WORLDS", "8").split(",")]:
             for e in engines:
@@ -73,7 +73,7 @@ for name in (sys.argv[1:] or ["now"]):
         # the bench's regime at N ranks: the camera pans 2 degrees per frame within +-8 degrees; every rank is a scene
         # of its own here (its cost history), frames outside, ranks inside; after every frame the ranks' cost maps are
         # combined (MAX) and imported, as bench.py does with an all-reduce.  The N-GPU frame time is the slowest rank's.
-        W4, H4, T = 3840, 2160, 64
+        W4, H4, T = 3840, 2160, int(os.environ.get("TILE", "64"))
         mw, mh = (W4 + 7) // 8, (H4 + 7) // 8
         def cam_of(j):
             j %= 16

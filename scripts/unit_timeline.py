@@ -13,7 +13,7 @@ from mythtracer_amd import scenegen as sg, binding, tiling
 torch.zeros(1, device="cuda")
 info = sg.write_scene("room", "/tmp/mt_scenes")
 m = M.MythTracer(info["obj"])
-abi = M.hip_abi(); h = abi.scene_create(m.flatten()); abi.set_lights(h, sg.ROOM_LIGHTS); abi.set_stats(h, False)
+abi = M.HipAbi(os.path.join(ROOT, "mythtracer_amd", "lib", "libmythtracer_hip_knobs.so")); h = abi.scene_create(m.flatten()); abi.set_lights(h, sg.ROOM_LIGHTS); abi.set_stats(h, False)
 abi.set_engine(h, int(os.environ.get("ENGINE", "3")))
 for k, v in [kv.split("=") for kv in os.environ.get("TUNE", "").split(",") if kv]:
     abi.set_tuning(h, k, float(v))
@@ -26,7 +26,7 @@ if what == "1080p":
     for i in range(10):
         abi.render_chunk_device(h, sens, W, H, (0, 0, W, H), 5, ctypes.c_void_p(buf.data_ptr()))
 else:
-    W, H, T = 3840, 2160, 64
+    W, H, T = 3840, 2160, int(os.environ.get("TILE", "64"))
     world = int(os.environ.get("WORLD", "8")); rank = int(os.environ.get("RANK", "5"))
     sens = binding.sensor(sg.ROOM_CAMERA, W, H)
     f, s, n = tiling.rank_tiles(W, H, T, T, rank, world)

@@ -3,7 +3,7 @@
 ITSELF (oracle/_ref/ref_driver, compiled from /root/reference/VerStarting by
 oracle/Makefile).  Run in the build container only:
 
-    make -C oracle ref && python tests/golden/make_golden.py [--big]
+    make -C oracle ref && python tests/golden/make_golden.py [--big | --big4k]
 
 Outputs are data only (inputs + what the reference returned): .npz archives
 (numpy, no pickle) and frames.json.  --big also renders the BASELINE-sized
@@ -169,6 +169,30 @@ def big_frames(td):
     json.dump(frames, open(fpath, "w"), indent=1, sort_keys=True)
 
 
+def big4k_frame(td):
+    """BASELINE configs[4]'s frame (3840x2160, room, 3 lights, depth 5) rendered ONCE by the compiled reference
+    (about four minutes on 8 threads): SHA-256 of frame and first-hit buffer + every 16th pixel."""
+    scenes = os.path.join(td, "scenes")
+    fpath = os.path.join(HERE, "frames.json")
+    frames = json.load(open(fpath))
+    info = scenegen.write_scene("room", scenes)
+    W, H = 3840, 2160
+    r = orclib.run_ref(os.path.join(td, "room_4k"), info["obj"], (W, H), cam=scenegen.ROOM_CAMERA,
+                       lights=scenegen.ROOM_LIGHTS, want_debug=True)
+    assert r["returncode"] == 0, r["stderr"]
+    key = "room_%dx%d_d5" % (W, H)
+    frames[key] = {"sha256": sha(r["rgb"]), "line_sha256": sha(r["line"].astype("<i4")),
+                   "seconds_reference_here": r["time"]["seconds"], "threads": r["time"]["threads"],
+                   "scene_sha256": info["sha256"]}
+    np.savez_compressed(os.path.join(HERE, key + "_sub16.npz"), rgb=r["rgb"][::16, ::16],
+                        line=r["line"][::16, ::16], point=r["point"][::16, ::16])
+    # odd pixels only (the even ones are the 1080p frame's): a second sub-sample, offset (5, 11), every 16th
+    np.savez_compressed(os.path.join(HERE, key + "_sub16_odd.npz"), rgb=r["rgb"][11::16, 5::16],
+                        line=r["line"][11::16, 5::16], point=r["point"][11::16, 5::16])
+    json.dump(frames, open(fpath, "w"), indent=1, sort_keys=True)
+    print(key, frames[key])
+
+
 def parse_tree_dump(raw: bytes):
     """ref_driver's `tree` dump -> arrays (see oracle/ref_driver.cc)."""
     n = int(np.frombuffer(raw, dtype="<i4", count=1)[0])
@@ -246,6 +270,10 @@ def tree_and_wire_cases(td):
 
 def main():
     assert orclib.have_ref(), "build the reference first: make -C oracle ref"
+    if "--big4k" in sys.argv:
+        with tempfile.TemporaryDirectory() as td:
+            big4k_frame(td)
+        return
     if "--tree-wire-only" in sys.argv:
         with tempfile.TemporaryDirectory() as td:
             tree_and_wire_cases(td)

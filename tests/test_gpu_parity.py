@@ -744,6 +744,12 @@ def test_4k_frame_contains_the_reference_1080p_frame(scenes):
     assert st["rays_primary"] == 2 * W * H + W * H  # two launches + the eight tile sets
     sha = hashlib.sha256(np.ascontiguousarray(tiled[::2, ::2]).tobytes()).hexdigest()
     assert sha == frames["room_1920x1080_d5"]["sha256"]
+    # ... and the WHOLE frame is the one the compiled reference rendered at 3840x2160 (tests/golden/make_golden.py
+    # --big4k: 185 s on 8 threads): SHA-256 of all 24.9 MB, and two every-16th-pixel sub-samples kept in full so that
+    # a mismatch can be located (the second one on odd rows and columns only: pixels the 1080p frame does not hold)
+    assert hashlib.sha256(tiled.tobytes()).hexdigest() == frames["room_3840x2160_d5"]["sha256"]
+    assert np.array_equal(tiled[::16, ::16], load("room_3840x2160_d5_sub16")["rgb"])
+    assert np.array_equal(tiled[11::16, 5::16], load("room_3840x2160_d5_sub16_odd")["rgb"])
 
 
 @pytest.mark.parametrize("view", ["room_view_back", "room_view_floor"])
