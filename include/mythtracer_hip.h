@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define MT_ABI_VERSION 3
+#define MT_ABI_VERSION 4
 
 enum {
   MT_OK = 0,
@@ -194,13 +194,50 @@ int mt_blit_tiles_device(mt_scene *scene, int image_w, int image_h,
                          int tile_stride, int n_tiles, const void *d_tiles,
                          void *d_image, void *stream);
 
+/* Cost-balanced ownership of a multi-GPU frame's tiles.  The reference's master hands its WorkChunks out dynamically:
+ * a worker asks for the next chunk when it is done with one (main_net_master.cc:62-80 the queue, :82-169
+ * WorkerHandler), so no worker idles while chunks wait.  Ranks that render at the same time cannot pull from one
+ * queue without a collective per tile; instead every rank computes THE SAME balanced assignment by itself from the
+ * frame-wide cost map all ranks hold after their exchange (mt_scene_export_costs_device, all-reduce MAX): the tiles
+ * sorted by the summed cost of their blocks, most expensive first (ties: lower tile number first), are dealt out in
+ * rounds of alternating direction -- 0 1 .. N-1, N-1 .. 1 0, ... -- so that every rank holds one tile of every round:
+ * the tile counts stay what the modular assignment gave (buffer sizes and the gather do not change) and the cost sums
+ * differ by less than one tile of a round.
+ *   mt_order_tiles_device: d_order[p] (int32, tiles_x * tiles_y entries) = tile at position p of that order, computed
+ *     from d_cost_map (uint32 [map_h][map_w], one word per 8x8 block of the image) on the scene's GPU.  An all-zero map
+ *     orders the tiles by number.
+ *   mt_dealt_tile_count: how many tiles rank `rank` of `world` holds (host arithmetic, no device access).
+ *   mt_deal_tiles_device: d_list[q] (int32) = the rank's tile of round q (d_order == NULL: the order by tile number);
+ *     returns the count.
+ *   mt_render_tile_list_device / mt_blit_tile_list_device: as the modular forms above with tile d_list[j] in slot j.
+ *     list_id: launches with the same non-zero list_id promise the same list -- the scene then keeps its per-block
+ *     cost history, running means included, as for any repeated launch; a launch with another list_id (or 0) takes its
+ *     forecast from the cost map imported since the previous launch (mt_scene_import_costs_device; all ranks' costs by
+ *     image position) and is a first frame without one.  The list is copied: the caller may reuse d_list at once.
+ * Nothing computed for a pixel depends on the assignment: the gathered frame is byte-identical. */
+int mt_order_tiles_device(mt_scene *scene, const void *d_cost_map, int map_w, int map_h,
+                          int image_w, int image_h, int tile_w, int tile_h, void *d_order,
+                          void *stream);
+int mt_dealt_tile_count(int image_w, int image_h, int tile_w, int tile_h, int world, int rank);
+int mt_deal_tiles_device(mt_scene *scene, const void *d_order, int image_w, int image_h,
+                         int tile_w, int tile_h, int world, int rank, void *d_list, void *stream);
+int mt_render_tile_list_device(mt_scene *scene, const mt_sensor *sensor, int image_w,
+                               int image_h, int tile_w, int tile_h, const void *d_list,
+                               int n_tiles, uint64_t list_id, int max_depth, void *d_rgb,
+                               void *stream);
+int mt_blit_tile_list_device(mt_scene *scene, int image_w, int image_h, int tile_w, int tile_h,
+                             const void *d_list, int n_tiles, const void *d_tiles, void *d_image,
+                             void *stream);
+
 /* One frame on SEVERAL GPUs of this process -- the master/worker farm of the
  * reference (main_net_master.cc:195-236: GenerateWork cuts the frame into
  * WorkChunks, every worker renders chunks with the full-image sensor from its
  * own copy of the scene, main_net_worker.cc:29-32,148-150, BlitWorkChunk puts
  * them into the frame) inside one host process: scenes[r] is a replica of the
  * scene on its own HIP device (mt_scene_desc.device; several replicas may share
- * a device), tile k of the tile_w x tile_h grid belongs to replica k mod n, all
+ * a device), the tiles of the tile_w x tile_h grid are dealt out by cost as
+ * described above (first frame of a geometry: by tile number; a camera at rest
+ * keeps its assignment from the second frame on), all
  * replicas render at the same time, the tile buffers travel to scenes[0]'s
  * device (peer copies over xGMI, 3 bytes per pixel in total), are blitted there
  * and the frame is copied to out_rgb (image_w*image_h*3 bytes, row-major, top
@@ -208,7 +245,13 @@ int mt_blit_tiles_device(mt_scene *scene, int image_w, int image_h,
  * have been set on every replica.  stats (nullable): n_scenes entries, the work
  * counters, kernel_ms = that replica's frame kernels, total_ms = wall time of
  * the whole call; stats[0].total_ms - max kernel_ms ~ exchange + blit + D2H.
- * The result is byte-identical to mt_render_chunk of the whole frame. */
+ * The result is byte-identical to mt_render_chunk of the whole frame.
+ * STATE OF TESTING: on one-GPU boxes only.  Replicas that share a device are
+ * covered by the GPU tests, including the gather-buffer offsets and the blit of
+ * the cross-device branch (forced through hipMemcpyPeerAsync on one device by
+ * MT_TUNE_MULTI_FORCE_PEER_COPY); peer access BETWEEN devices
+ * (hipDeviceCanAccessPeer / EnablePeerAccess, cross-device events) has not run
+ * on hardware yet, and no multi-GPU scaling figure has been measured. */
 int mt_render_frame_multi(mt_scene *const *scenes, int n_scenes,
                           const mt_sensor *sensor, int image_w, int image_h,
                           int tile_w, int tile_h, int max_depth,
@@ -306,6 +349,11 @@ enum {
   MT_TUNE_HYBRID_QUAD_SHARE,  /* ... above this one to the state machine as quarters, four lanes per pixel (1.0 = none) */
   MT_TUNE_HYBRID_WORK1, MT_TUNE_HYBRID_WORK2, /* pool quarters / cells: summed cost over the whole block's (1.3, 3.3) */
   MT_TUNE_FORECAST_STEP,      /* pixels between the positions a re-projected forecast takes its maximum over (8) */
+  MT_TUNE_HYBRID_STARTER_SHARE, /* engine 3: state-machine units above this share of an even split start with the launch,
+                                   on waves that skip the pool's part (0.33; a value above every unit = none) */
+  MT_TUNE_MULTI_FORCE_PEER_COPY, /* tests: mt_render_frame_multi copies every replica's tiles into the gather buffer with
+                                    hipMemcpyPeerAsync even when it shares the first replica's device (0) */
+  MT_TUNE_MULTI_BALANCE,      /* mt_render_frame_multi: 1 (default) = tiles dealt out by cost, 0 = by tile number */
   MT_TUNE_COUNT
 };
 int mt_scene_set_tuning(mt_scene *scene, int knob, double value);

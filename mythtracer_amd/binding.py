@@ -11,7 +11,7 @@ HIP_LIB = os.path.join(PKG, "lib", "libmythtracer_hip.so")
 HOST_LIB = os.path.join(PKG, "lib", "libmythtracer_host.so")
 
 MT_OK = 0
-MT_ABI_VERSION = 3
+MT_ABI_VERSION = 4
 MT_TEX_RGB8, MT_TEX_F64 = 0, 1
 
 # every symbol include/mythtracer_hip.h declares
@@ -23,6 +23,8 @@ HIP_SYMBOLS = [
     "mt_scene_kernel_times", "mt_scene_set_scheduling", "mt_scene_set_engine",
     "mt_scene_set_stats", "mt_set_default_engine", "mt_scene_set_tuning",
     "mt_render_frame_multi", "mt_scene_export_costs_device", "mt_scene_import_costs_device",
+    "mt_order_tiles_device", "mt_dealt_tile_count", "mt_deal_tiles_device",
+    "mt_render_tile_list_device", "mt_blit_tile_list_device",
 ]
 
 # mt_scene_set_tuning knobs, in the order of the enum in include/mythtracer_hip.h
@@ -30,7 +32,8 @@ TUNE = {name: i for i, name in enumerate([
     "POOL_BELOW", "POOL_CAP", "PACKED_STACK", "BLOCKS_PER_CU", "FORECAST_RADIUS", "BLEND", "FORMS",
     "POOL_CUT_SHARE", "POOL_PIECE_TIME1", "POOL_PIECE_TIME2", "POOL_PIECE_WORK1", "POOL_PIECE_WORK2",
     "POOL_CELL_FACTOR", "QUAD_SHARE", "QUAD_SHARE_MOVING", "QUAD_KEEP", "QUAD_WORK", "QUAD_WORK_MOVING",
-    "POOL_SCRATCH_MB", "HYBRID_POOL_SHARE", "HYBRID_QUAD_SHARE", "HYBRID_WORK1", "HYBRID_WORK2", "FORECAST_STEP"])}
+    "POOL_SCRATCH_MB", "HYBRID_POOL_SHARE", "HYBRID_QUAD_SHARE", "HYBRID_WORK1", "HYBRID_WORK2", "FORECAST_STEP",
+    "HYBRID_STARTER_SHARE", "MULTI_FORCE_PEER_COPY", "MULTI_BALANCE"])}
 
 STAT_NAMES = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests",
               "node_visits", "tri_tests", "mt_tests", "shaded_hits"]
@@ -140,6 +143,11 @@ class HipAbi:
         L.mt_render_frame_multi.argtypes = [vp, ci, C.POINTER(mt_sensor)] + [ci] * 5 + [vp, vp]
         L.mt_scene_export_costs_device.argtypes = [vp, vp, ci, ci, vp]
         L.mt_scene_import_costs_device.argtypes = [vp, vp, ci, ci, vp]
+        L.mt_order_tiles_device.argtypes = [vp, vp] + [ci] * 6 + [vp, vp]
+        L.mt_dealt_tile_count.argtypes = [ci] * 6
+        L.mt_deal_tiles_device.argtypes = [vp, vp] + [ci] * 6 + [vp, vp]
+        L.mt_render_tile_list_device.argtypes = [vp, C.POINTER(mt_sensor)] + [ci] * 4 + [vp, ci, C.c_uint64, ci, vp, vp]
+        L.mt_blit_tile_list_device.argtypes = [vp] + [ci] * 4 + [vp, ci, vp, vp, vp]
 
     def last_error(self) -> str:
         return self.lib.mt_last_error().decode(errors="replace")
@@ -260,6 +268,34 @@ class HipAbi:
                           n_tiles, d_tiles, d_image, stream=None):
         self.check(self.lib.mt_blit_tiles_device(h, image_w, image_h, tile_w, tile_h, first_tile,
                                                  tile_stride, n_tiles, d_tiles, d_image, stream))
+
+    # ---- cost-balanced tile ownership (include/mythtracer_hip.h, mt_order_tiles_device ff.)
+    def order_tiles_device(self, h, d_cost_map, map_w, map_h, image_w, image_h, tile_w, tile_h, d_order, stream=None):
+        self.check(self.lib.mt_order_tiles_device(h, d_cost_map, map_w, map_h, image_w, image_h, tile_w, tile_h,
+                                                  d_order, stream))
+
+    def dealt_tile_count(self, image_w, image_h, tile_w, tile_h, world, rank) -> int:
+        n = self.lib.mt_dealt_tile_count(image_w, image_h, tile_w, tile_h, world, rank)
+        if n < 0:
+            self.check(n)
+        return n
+
+    def deal_tiles_device(self, h, d_order, image_w, image_h, tile_w, tile_h, world, rank, d_list, stream=None) -> int:
+        n = self.lib.mt_deal_tiles_device(h, d_order, image_w, image_h, tile_w, tile_h, world, rank, d_list, stream)
+        if n < 0:
+            self.check(n)
+        return n
+
+    def render_tile_list_device(self, h, sensor12, image_w, image_h, tile_w, tile_h, d_list, n_tiles, list_id,
+                                max_depth, d_rgb, stream=None):
+        s = self.make_sensor(sensor12)
+        self.check(self.lib.mt_render_tile_list_device(h, C.byref(s), image_w, image_h, tile_w, tile_h, d_list,
+                                                       n_tiles, int(list_id), max_depth, d_rgb, stream))
+
+    def blit_tile_list_device(self, h, image_w, image_h, tile_w, tile_h, d_list, n_tiles, d_tiles, d_image,
+                              stream=None):
+        self.check(self.lib.mt_blit_tile_list_device(h, image_w, image_h, tile_w, tile_h, d_list, n_tiles,
+                                                     d_tiles, d_image, stream))
 
     def read_stats(self, h) -> dict:
         st = mt_stats()

@@ -68,7 +68,7 @@ struct Tuning {
     v[MT_TUNE_POOL_CUT_SHARE] = -1.0;     // < 0 = 1.0 with history, 0.3 without
     v[MT_TUNE_POOL_PIECE_TIME1] = 0.35; v[MT_TUNE_POOL_PIECE_TIME2] = 0.12;
     v[MT_TUNE_POOL_PIECE_WORK1] = 1.1;  v[MT_TUNE_POOL_PIECE_WORK2] = 3.0;
-    v[MT_TUNE_POOL_CELL_FACTOR] = 3.0;
+    v[MT_TUNE_POOL_CELL_FACTOR] = 1.0;  // (round 4, swept on the panning 4K frame at N = 8: 3.0 / 2.0 / 1.5 / 1.2 / 1.0 / 0.85 / 0.7 / 0.5 -> 3.39 / 3.41 / 3.37 / 3.35 / 3.20 / 3.11 / 3.29 / 4.37 ms for the slowest rank; with HYBRID_WORK2 2.6: 3.06)
     v[MT_TUNE_QUAD_SHARE] = 0.95; v[MT_TUNE_QUAD_SHARE_MOVING] = 0.7;
     v[MT_TUNE_QUAD_KEEP] = 1.0;
     v[MT_TUNE_QUAD_WORK] = 1.7;   v[MT_TUNE_QUAD_WORK_MOVING] = 1.5;
@@ -80,7 +80,10 @@ struct Tuning {
     v[MT_TUNE_HYBRID_POOL_SHARE] = 1.0;
     v[MT_TUNE_HYBRID_QUAD_SHARE] = 1.0;
     v[MT_TUNE_FORECAST_STEP] = 8.0;       // pixels between the old-image positions a re-projected forecast takes its maximum over
-    v[MT_TUNE_HYBRID_WORK1] = 1.3; v[MT_TUNE_HYBRID_WORK2] = 3.3;  // pool quarters / cells: summed cost over the state machine's whole-block cost
+    v[MT_TUNE_HYBRID_WORK1] = 1.3; v[MT_TUNE_HYBRID_WORK2] = 2.6;  // pool quarters / cells: summed cost over the state machine's whole-block cost
+    v[MT_TUNE_HYBRID_STARTER_SHARE] = 0.33;  // hybrid launches: state-machine units above this share of an even split start with the launch (hybrid_kernel)
+    v[MT_TUNE_MULTI_FORCE_PEER_COPY] = 0.0;
+    v[MT_TUNE_MULTI_BALANCE] = 1.0;
   }
 };
 
@@ -171,6 +174,27 @@ struct mt_scene {
   unsigned int *d_multi_maps = nullptr;   // first replica: all replicas' maps
   size_t multi_maps_bytes = 0;
   hipEvent_t multi_comb_done = nullptr;
+  // tile-list launches (mt_render_tile_list_device): the launch's own copy of the list, and tile -> slot
+  int32_t *d_tile_list = nullptr;
+  size_t tile_list_bytes = 0;
+  int32_t *d_tile_slot = nullptr;
+  size_t tile_slot_bytes = 0;
+  // mt_order_tiles_device: summed block costs per tile
+  unsigned long long *d_tile_cost = nullptr;
+  size_t tile_cost_bytes = 0;
+  // mt_render_frame_multi, cost-balanced ownership: this replica's order and list; on the first replica every replica's list
+  int32_t *d_multi_order = nullptr;
+  size_t multi_order_bytes = 0;
+  int32_t *d_multi_list = nullptr;
+  size_t multi_list_bytes = 0;
+  int32_t *d_multi_lists = nullptr;
+  size_t multi_lists_bytes = 0;
+  unsigned long long multi_geom = 0;      // geometry (image, tiles, depth, replicas) the state below belongs to
+  unsigned long long multi_list_id = 0;   // changes whenever the tiles are dealt out anew
+  bool multi_have_map = false;            // d_multi_map holds the combined costs of the previous frame of multi_geom
+  int multi_frames_at_rest = 0;
+  int multi_rank = -1;
+  mt_sensor multi_sensor{};
 };
 
 namespace {
@@ -249,7 +273,7 @@ int ensure_bytes(void **ptr, size_t *have, size_t need) {
 int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h, int rx, int ry,
                   int rw, int rh, int tile_w, int tile_h, int first_tile, int tile_stride,
                   int n_tiles, int max_depth, uint8_t *d_rgb, mt_debug_px *d_debug,
-                  hipStream_t stream) {
+                  hipStream_t stream, const int32_t *d_list = nullptr, unsigned long long list_id = 0) {
   if (max_depth < 0 || max_depth > MT_MAX_RECURSION) {
     return fail(MT_ERR_ARG, "max_depth %d outside [0, %d]", max_depth, MT_MAX_RECURSION);
   }
@@ -282,13 +306,22 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   unsigned long long sig = 1469598103934665603ull;
   {
     const long long key[] = {image_w, image_h, rx, ry, rw, rh, tile_w, tile_h, first_tile, tile_stride,
-                             n_tiles, max_depth, s->dev.n_lights};
+                             n_tiles, max_depth, s->dev.n_lights, d_list ? 1 : 0, d_list ? (long long)list_id : 0};
     for (long long v : key) {
       sig = (sig ^ (unsigned long long)v) * 1099511628211ull;
     }
     if (sig == 0) sig = 1;
   }
-  const bool have_costs = s->use_history && s->cost_signature == sig;
+  // (a tile list promises to be the previous launch's list by its non-zero list_id only)
+  bool have_costs = s->use_history && s->cost_signature == sig && !(d_list != nullptr && list_id == 0);
+  // A list launch with ANOTHER list (the tiles were dealt out anew): the slots' cost words belong to other tiles, but the
+  // frame-wide map imported since the previous launch has every block's cost by image position.
+  const bool map_ready = s->d_cost_map != nullptr && s->cost_map_for_launch == s->launches_timed &&
+                         s->cost_map_w >= (image_w + 7) / 8 && s->cost_map_h >= (image_h + 7) / 8;
+  const bool from_map = s->use_history && d_list != nullptr && !have_costs && map_ready && s->last_P_valid &&
+                        (tile_w & 7) == 0 && (tile_h & 7) == 0 && (rx & 7) == 0 && (ry & 7) == 0 &&
+                        s->last_P.image_w == image_w && s->last_P.image_h == image_h && s->last_P.max_depth == max_depth;
+  if (from_map) have_costs = true;
   // ---- which engine?  Both compute every pixel with the same operations in the
   // same order (tests render through both).  The state machine (one lane per
   // pixel, its context in registers) has the lower cost per ray and is the
@@ -375,6 +408,20 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   P.cost_map = (s->d_cost_map != nullptr && s->cost_map_for_launch == s->launches_timed) ? s->d_cost_map : nullptr;
   P.cost_map_w = s->cost_map_w;
   P.cost_map_h = s->cost_map_h;
+  P.from_map = from_map ? 1 : 0;
+  if (from_map) P.item_whole = P.item_qsum = nullptr;  // (the two measured forms of a block are kept per slot)
+  if (d_list != nullptr && n_tiles > 0) {
+    const int tiles_total = P.tiles_x * ((rh + tile_h - 1) / tile_h);
+    int rc = ensure_bytes((void **)&s->d_tile_list, &s->tile_list_bytes, (size_t)n_tiles * 4);
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_tile_slot, &s->tile_slot_bytes, (size_t)tiles_total * 4);
+    if (rc != MT_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_tile_list, d_list, (size_t)n_tiles * 4, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(tile_slot_kernel, dim3((tiles_total + 255) / 256), dim3(256), 0, stream, s->d_tile_list, n_tiles, s->d_tile_slot, tiles_total, 0);
+    hipLaunchKernelGGL(tile_slot_kernel, dim3((n_tiles + 255) / 256), dim3(256), 0, stream, s->d_tile_list, n_tiles, s->d_tile_slot, tiles_total, 1);
+    HIP_TRY(hipGetLastError());
+    P.tile_list = s->d_tile_list;
+    P.tile_slot = s->d_tile_slot;
+  }
   if (pool_engine || hybrid) {
     int rc = ensure_bytes((void **)&s->d_pool, &s->pool_bytes, pool_stride * waves);
     if (rc != MT_OK) return rc;
@@ -426,7 +473,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   // (found on the host: such a column or row runs through the whole image, so its ends are enough)?  Its blocks'
   // costs are skipped by a re-projected forecast (forecast_kernel).
   int old_irr = 0;
-  if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {
+  if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {  // (from_map: the map is the frame cost_sensor saw, on every rank)
     const mt_sensor &o = s->cost_sensor;
     for (int k = 0; k < 3 && !old_irr; k++) {
       for (int x = 0; x < image_w && !old_irr; x++) {
@@ -442,7 +489,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     radius = memcmp(s->cost_sensor.origin, sensor->origin, sizeof sensor->origin) != 0 ? 2 : 1;
     if (s->tune.v[MT_TUNE_FORECAST_RADIUS] >= 0.0) radius = (int)s->tune.v[MT_TUNE_FORECAST_RADIUS];
   }
-  if (history && !reproject && s->forecasts_in_a_row > 0) {
+  if (history && !reproject && !from_map && s->forecasts_in_a_row > 0) {
     // swept (scripts/blend_sweep.py, state machine, 64 frames): 0 -> every other frame 6 % slower (mean 7.09 ms), 0.5 -> one
     // in three (7.03), 0.9 -> one in eight (7.01); a frozen forecast (1.0) repeats its frame time to 0.2 % (scripts/alternation.py)
     // (a running mean of the measurements first -- 1/2, 2/3, ... -- so that the first frames' costs, measured under a
@@ -454,7 +501,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   if (s->forecasts_in_a_row == 0) HIP_TRY(hipMemsetAsync(s->d_item_forms, 0, (size_t)P.n_items * 8, stream));
   // (a forecast made from the OTHER engine's costs -- the frame after a first frame -- does not count: the next one
   // starts the running mean with this engine's own measurement)
-  s->forecasts_in_a_row = (history && !reproject && s->last_engine == engine) ? s->forecasts_in_a_row + 1 : 0;
+  s->forecasts_in_a_row = (history && !reproject && !from_map && s->last_engine == engine) ? s->forecasts_in_a_row + 1 : 0;
   if (pool_engine) {
     if (!history) {
       hipLaunchKernelGGL(probe_kernel, dim3((4 * P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream,
@@ -466,7 +513,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     SchedParams sp{history ? 1.0f : 0.3f, {1.0f, (float)tv[MT_TUNE_POOL_PIECE_TIME1], (float)tv[MT_TUNE_POOL_PIECE_TIME2]},
                    {1.0f, (float)tv[MT_TUNE_POOL_PIECE_WORK1], (float)tv[MT_TUNE_POOL_PIECE_WORK2]},
                    (float)tv[MT_TUNE_POOL_CELL_FACTOR],
-                   (!history || s->last_engine == 2) ? 1 : 0};  // a forecast is cut more eagerly (own_costs: granularity in bits 30-31)
+                   (!from_map && (!history || s->last_engine == 2)) ? 1 : 0};  // a forecast is cut more eagerly (own_costs: granularity in bits 30-31)
     if (tv[MT_TUNE_POOL_CUT_SHARE] >= 0.0) sp.cut_share = (float)tv[MT_TUNE_POOL_CUT_SHARE];
     hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
                        reproject, radius, (history && (s->last_engine == 1 || s->last_engine == 3)) ? 0 : 1,
@@ -503,7 +550,8 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
         hipLaunchKernelGGL(hybrid_schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
                            s->grid_blocks * s->waves_per_block, k * (float)tv[MT_TUNE_HYBRID_QUAD_SHARE],
                            k * (float)tv[MT_TUNE_HYBRID_POOL_SHARE], (float)tv[MT_TUNE_POOL_PIECE_TIME1],
-                           (float)tv[MT_TUNE_POOL_PIECE_TIME2], (float)tv[MT_TUNE_POOL_CELL_FACTOR], s->d_item_form);
+                           (float)tv[MT_TUNE_POOL_PIECE_TIME2], (float)tv[MT_TUNE_POOL_CELL_FACTOR], s->d_item_form,
+                           (float)tv[MT_TUNE_HYBRID_STARTER_SHARE], (unsigned)std::min(s->grid_blocks, (int)(0.25 * s->grid_blocks * s->waves_per_block)));
       } else {
         hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
                            s->grid_blocks * s->waves_per_block, quad_share, quad_keep);
@@ -529,7 +577,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   s->launches_timed++;
   s->last_P = P;
   s->last_P_valid = true;
-  s->cost_signature = sig;  // the costs now in d_item_cost belong to this geometry and engine
+  s->cost_signature = (d_list != nullptr && list_id == 0) ? 0 : sig;  // the costs now in d_item_cost belong to this geometry and engine
   s->last_engine = engine;
   s->cost_sensor = *sensor;
   if (s->dbg_print_units) {  // -DMT_DEBUG_KNOBS: how many work units did the order have?
@@ -650,6 +698,12 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_rgb) (void)hipFree(s->d_rgb);
   if (s->d_debug) (void)hipFree(s->d_debug);
   if (s->d_lights) (void)hipFree(s->d_lights);
+  if (s->d_tile_list) (void)hipFree(s->d_tile_list);
+  if (s->d_tile_slot) (void)hipFree(s->d_tile_slot);
+  if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
+  if (s->d_multi_order) (void)hipFree(s->d_multi_order);
+  if (s->d_multi_list) (void)hipFree(s->d_multi_list);
+  if (s->d_multi_lists) (void)hipFree(s->d_multi_lists);
   if (s->d_multi_tiles) (void)hipFree(s->d_multi_tiles);
   if (s->d_multi_map) (void)hipFree(s->d_multi_map);
   if (s->d_multi_maps) (void)hipFree(s->d_multi_maps);
@@ -1181,7 +1235,34 @@ int mt_set_default_engine(int engine) {
 }
 
 int mt_scene_set_tuning(mt_scene *s, int knob, double value) {
-  if (!s || knob < 0 || knob >= MT_TUNE_COUNT || !(value == value)) return fail(MT_ERR_ARG, "bad tuning argument");
+  if (!s || knob < 0 || knob >= MT_TUNE_COUNT || !std::isfinite(value)) return fail(MT_ERR_ARG, "bad tuning argument");
+  // The kernels divide by the work factors and scale an even share by the shares: those must be positive (and small
+  // enough for their products to stay finite in float); counts and budgets must not be negative or beyond what the
+  // conversions to integers hold.
+  switch (knob) {
+    case MT_TUNE_POOL_PIECE_TIME1: case MT_TUNE_POOL_PIECE_TIME2: case MT_TUNE_POOL_PIECE_WORK1: case MT_TUNE_POOL_PIECE_WORK2:
+    case MT_TUNE_POOL_CELL_FACTOR: case MT_TUNE_QUAD_SHARE: case MT_TUNE_QUAD_SHARE_MOVING: case MT_TUNE_QUAD_KEEP:
+    case MT_TUNE_QUAD_WORK: case MT_TUNE_QUAD_WORK_MOVING: case MT_TUNE_HYBRID_POOL_SHARE: case MT_TUNE_HYBRID_QUAD_SHARE:
+    case MT_TUNE_HYBRID_WORK1: case MT_TUNE_HYBRID_WORK2: case MT_TUNE_FORECAST_STEP: case MT_TUNE_HYBRID_STARTER_SHARE:
+      if (!(value >= 1e-6 && value <= 1e6)) return fail(MT_ERR_ARG, "tuning knob %d must lie in [1e-6, 1e6]", knob);
+      break;
+    case MT_TUNE_POOL_BELOW: case MT_TUNE_POOL_CAP: case MT_TUNE_BLOCKS_PER_CU:
+      if (!(value >= 0.0 && value <= 1e9)) return fail(MT_ERR_ARG, "tuning knob %d must lie in [0, 1e9]", knob);
+      break;
+    case MT_TUNE_POOL_SCRATCH_MB:
+      if (!(value >= 1.0 && value <= 1e9)) return fail(MT_ERR_ARG, "the ray pool's scratch budget must lie in [1, 1e9] MB");
+      break;
+    case MT_TUNE_BLEND:
+      if (!(value >= 0.0 && value <= 1.0)) return fail(MT_ERR_ARG, "the forecast's damping must lie in [0, 1]");
+      break;
+    case MT_TUNE_FORECAST_RADIUS:
+      if (!(value <= 8.0)) return fail(MT_ERR_ARG, "the forecast's radius must be at most 8 blocks (< 0 = automatic)");
+      break;
+    case MT_TUNE_POOL_CUT_SHARE:
+      if (!(value < 0.0 || (value >= 1e-6 && value <= 1e6))) return fail(MT_ERR_ARG, "the pool's cutting share must be negative (automatic) or lie in [1e-6, 1e6]");
+      break;
+    default: break;  // switches: any finite value (0 / non-zero)
+  }
   s->tune.v[knob] = value;
   s->cost_signature = 0;  // other constants, other order: start from a first frame
   if (knob == MT_TUNE_PACKED_STACK || knob == MT_TUNE_BLOCKS_PER_CU) {
@@ -1344,8 +1425,80 @@ int mt_blit_tiles_device(mt_scene *s, int image_w, int image_h, int tile_w, int 
   if (n_tiles == 0) return MT_OK;
   HIP_TRY(hipSetDevice(s->device));
   hipLaunchKernelGGL(blit_tiles_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, image_w,
-                     image_h, tile_w, tile_h, tiles_x, first_tile, tile_stride, n_tiles,
+                     image_h, tile_w, tile_h, tiles_x, first_tile, tile_stride, n_tiles, (const int32_t *)nullptr,
                      (const uint8_t *)d_tiles, (uint8_t *)d_image);
+  HIP_TRY(hipGetLastError());
+  return MT_OK;
+}
+
+int mt_order_tiles_device(mt_scene *s, const void *d_cost_map, int map_w, int map_h, int image_w, int image_h,
+                          int tile_w, int tile_h, void *d_order, void *stream) {
+  if (!s || !d_cost_map || !d_order || map_w <= 0 || map_h <= 0 || image_w <= 0 || image_h <= 0 || tile_w <= 0 || tile_h <= 0 ||
+      image_w > 100000 || image_h > 100000) {
+    return fail(MT_ERR_ARG, "bad tile order arguments");
+  }
+  if (map_w < (image_w + 7) / 8 || map_h < (image_h + 7) / 8) return fail(MT_ERR_ARG, "cost map smaller than the image's 8x8 blocks");
+  const int tiles_x = (image_w + tile_w - 1) / tile_w;
+  const long long total = (long long)tiles_x * ((image_h + tile_h - 1) / tile_h);
+  if (total > (1ll << 20)) return fail(MT_ERR_ARG, "too many tiles to order (%lld)", total);
+  HIP_TRY(hipSetDevice(s->device));
+  int rc = ensure_bytes((void **)&s->d_tile_cost, &s->tile_cost_bytes, (size_t)total * 8);
+  if (rc != MT_OK) return rc;
+  const int n = (int)total;
+  hipLaunchKernelGGL(tile_cost_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const unsigned *)d_cost_map,
+                     map_w, map_h, image_w, image_h, tile_w, tile_h, tiles_x, n, s->d_tile_cost);
+  hipLaunchKernelGGL(tile_order_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, s->d_tile_cost, n, (int32_t *)d_order);
+  HIP_TRY(hipGetLastError());
+  return MT_OK;
+}
+
+int mt_dealt_tile_count(int image_w, int image_h, int tile_w, int tile_h, int world, int rank) {
+  if (image_w <= 0 || image_h <= 0 || tile_w <= 0 || tile_h <= 0 || world < 1 || rank < 0 || rank >= world) {
+    return fail(MT_ERR_ARG, "bad tile count arguments");
+  }
+  const long long total = (long long)((image_w + tile_w - 1) / tile_w) * ((image_h + tile_h - 1) / tile_h);
+  if (total > 0x7fffffffll) return fail(MT_ERR_ARG, "too many tiles");
+  return dealt_tile_count((int)total, world, rank);
+}
+
+int mt_deal_tiles_device(mt_scene *s, const void *d_order, int image_w, int image_h, int tile_w, int tile_h, int world,
+                         int rank, void *d_list, void *stream) {
+  if (!s || !d_list) return fail(MT_ERR_ARG, "bad deal arguments");
+  const int n = mt_dealt_tile_count(image_w, image_h, tile_w, tile_h, world, rank);
+  if (n <= 0) return n;
+  const int total = ((image_w + tile_w - 1) / tile_w) * ((image_h + tile_h - 1) / tile_h);
+  HIP_TRY(hipSetDevice(s->device));
+  hipLaunchKernelGGL(deal_tiles_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const int32_t *)d_order, total,
+                     world, rank, n, (int32_t *)d_list);
+  HIP_TRY(hipGetLastError());
+  return n;
+}
+
+int mt_render_tile_list_device(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h, int tile_w, int tile_h,
+                               const void *d_list, int n_tiles, uint64_t list_id, int max_depth, void *d_rgb,
+                               void *stream) {
+  int rc = check_image_args(s, sensor, image_w, image_h);
+  if (rc != MT_OK) return rc;
+  if (tile_w <= 0 || tile_h <= 0 || n_tiles < 0) return fail(MT_ERR_ARG, "bad tiling arguments");
+  const long long tiles_total = (long long)((image_w + tile_w - 1) / tile_w) * ((image_h + tile_h - 1) / tile_h);
+  if (n_tiles > tiles_total) return fail(MT_ERR_ARG, "%d tiles listed, the image has %lld", n_tiles, tiles_total);
+  if (n_tiles > 0 && (!d_rgb || !d_list)) return fail(MT_ERR_ARG, "d_rgb or d_list is NULL");
+  HIP_TRY(hipSetDevice(s->device));
+  return launch_render(s, sensor, image_w, image_h, 0, 0, image_w, image_h, tile_w, tile_h, 0, 1, n_tiles, max_depth,
+                       (uint8_t *)d_rgb, nullptr, (hipStream_t)stream, n_tiles > 0 ? (const int32_t *)d_list : nullptr,
+                       (unsigned long long)list_id);
+}
+
+int mt_blit_tile_list_device(mt_scene *s, int image_w, int image_h, int tile_w, int tile_h, const void *d_list,
+                             int n_tiles, const void *d_tiles, void *d_image, void *stream) {
+  if (!s || !d_tiles || !d_image || !d_list || image_w <= 0 || image_h <= 0 || tile_w <= 0 || tile_h <= 0 || n_tiles < 0) {
+    return fail(MT_ERR_ARG, "bad blit arguments");
+  }
+  if (n_tiles == 0) return MT_OK;
+  HIP_TRY(hipSetDevice(s->device));
+  hipLaunchKernelGGL(blit_tiles_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, image_w, image_h, tile_w, tile_h,
+                     (image_w + tile_w - 1) / tile_w, 0, 1, n_tiles, (const int32_t *)d_list, (const uint8_t *)d_tiles,
+                     (uint8_t *)d_image);
   HIP_TRY(hipGetLastError());
   return MT_OK;
 }
@@ -1392,10 +1545,11 @@ int mt_render_chunk(mt_scene *s, const mt_sensor *sensor, int image_w, int image
 }
 
 // ---- one frame on several GPUs of this process (main_net_master.cc:195-236) --------------------------
-// Replica r renders tiles r, r + n, ... into its own tile buffer on its own device and stream (the launches are
-// made from one host thread per replica, so that no device waits for another's launch calls); the first replica's
-// stream then waits for each replica's event, pulls its buffer over xGMI (hipMemcpyPeerAsync; the buffers of
-// replicas on the SAME device are read in place) and blits it into the frame; one D2H copy ends the call.
+// Replica r renders ITS tiles -- dealt out by cost, see mt_order_tiles_device; by tile number while no frame of this
+// geometry has been measured -- into its own tile buffer on its own device and stream (the launches are made from one
+// host thread per replica, so that no device waits for another's launch calls); the first replica's stream then waits
+// for each replica's event, pulls its buffer over xGMI (hipMemcpyPeerAsync; the buffers of replicas on the SAME device
+// are read in place) and blits it into the frame; one D2H copy ends the call.
 int mt_render_frame_multi(mt_scene *const *scenes, int n, const mt_sensor *sensor, int image_w, int image_h,
                           int tile_w, int tile_h, int max_depth, uint8_t *out_rgb, mt_stats *stats) {
   if (!scenes || n < 1 || n > 1024) return fail(MT_ERR_ARG, "bad scene list");
@@ -1410,16 +1564,52 @@ int mt_render_frame_multi(mt_scene *const *scenes, int n, const mt_sensor *senso
   if (rc != MT_OK) return rc;
   if (tile_w <= 0 || tile_h <= 0) return fail(MT_ERR_ARG, "bad tile size");
   const auto w0 = std::chrono::steady_clock::now();
-  const long long tiles_total = (long long)((image_w + tile_w - 1) / tile_w) * ((image_h + tile_h - 1) / tile_h);
+  const long long tiles_total_ll = (long long)((image_w + tile_w - 1) / tile_w) * ((image_h + tile_h - 1) / tile_h);
+  if (tiles_total_ll > (1ll << 20)) return fail(MT_ERR_ARG, "too many tiles (%lld)", tiles_total_ll);
+  const int tiles_total = (int)tiles_total_ll;
   const size_t slot = (size_t)tile_w * tile_h * 3;
-  const long long n_max = (tiles_total + n - 1) / n;
-  auto tiles_of = [&](int r) -> int { return r >= tiles_total ? 0 : (int)((tiles_total - r + n - 1) / n); };
+  const int n_max = (tiles_total + n - 1) / n;
+  auto tiles_of = [&](int r) -> int { return dealt_tile_count(tiles_total, n, r); };
   mt_scene *root = scenes[0];
   // the replicas' block costs are exchanged after every frame (mt_scene_export_costs_device: a moving camera's next
-  // frame is ordered by the costs of ALL tiles of this one)
+  // frame is ordered by the costs of ALL tiles of this one, and the tiles are dealt out by them)
   const bool share_costs = n > 1 && (tile_w & 7) == 0 && (tile_h & 7) == 0;
   const int map_w = (image_w + 7) / 8, map_h = (image_h + 7) / 8;
   const size_t map_bytes = (size_t)map_w * map_h * sizeof(unsigned);
+
+  // ---- who renders what.  State of the previous call (kept on every replica, decided on the first one's): the same
+  // geometry and replica list?  Then the tiles are dealt out anew by the combined costs of the previous frame -- every
+  // replica holds that map and orders it by itself -- unless the camera has been at rest for two frames: from then on
+  // the assignment is kept, and with it the per-slot cost history (running means, the blocks' two measured forms).
+  unsigned long long geom = 1469598103934665603ull;
+  for (long long v : {(long long)image_w, (long long)image_h, (long long)tile_w, (long long)tile_h, (long long)max_depth, (long long)n}) {
+    geom = (geom ^ (unsigned long long)v) * 1099511628211ull;
+  }
+  if (geom == 0) geom = 1;
+  bool same_geom = true;
+  for (int r = 0; r < n; r++) {
+    same_geom = same_geom && scenes[r]->multi_geom == geom && scenes[r]->multi_rank == r &&
+                scenes[r]->multi_list_id == root->multi_list_id;
+  }
+  const bool balance = share_costs && root->tune.v[MT_TUNE_MULTI_BALANCE] != 0.0;
+  const bool at_rest = same_geom && memcmp(&root->multi_sensor, sensor, sizeof(mt_sensor)) == 0;
+  const int frames_at_rest = at_rest ? root->multi_frames_at_rest + 1 : 0;
+  const bool by_map = same_geom && balance && root->multi_have_map && (!at_rest || frames_at_rest < 2);
+  const bool redeal = !same_geom || by_map;
+  static std::atomic<unsigned long long> next_list_id{1};
+  const unsigned long long list_id = redeal ? next_list_id.fetch_add(1) : root->multi_list_id;
+  auto forget = [&]() {
+    for (int q = 0; q < n; q++) scenes[q]->multi_geom = 0;
+  };
+  auto drain = [&]() {  // let whatever was launched finish before the caller touches its buffers or the scenes again
+    for (int q = 0; q < n; q++) {
+      if (scenes[q]->multi_stream) {
+        (void)hipSetDevice(scenes[q]->device);
+        (void)hipStreamSynchronize(scenes[q]->multi_stream);
+      }
+    }
+    (void)hipSetDevice(root->device);
+  };
 
   // ---- phase 1: every replica renders its tiles
   std::vector<int> rcs((size_t)n, MT_OK);
@@ -1433,12 +1623,24 @@ int mt_render_frame_multi(mt_scene *const *scenes, int n, const mt_sensor *senso
         HIP_TRY(hipEventCreateWithFlags(&s->multi_done, hipEventDisableTiming));
       }
       int rc2 = ensure_bytes((void **)&s->d_multi_tiles, &s->multi_tiles_bytes, (size_t)n_max * slot);
+      if (rc2 == MT_OK) rc2 = ensure_bytes((void **)&s->d_multi_list, &s->multi_list_bytes, (size_t)n_max * 4);
       if (rc2 != MT_OK) return rc2;
+      if (redeal) {
+        const int32_t *order = nullptr;
+        if (by_map) {
+          if ((rc2 = ensure_bytes((void **)&s->d_multi_order, &s->multi_order_bytes, (size_t)tiles_total * 4)) != MT_OK) return rc2;
+          if ((rc2 = mt_order_tiles_device(s, s->d_multi_map, map_w, map_h, image_w, image_h, tile_w, tile_h,
+                                           s->d_multi_order, s->multi_stream)) != MT_OK) return rc2;
+          order = s->d_multi_order;
+        }
+        if ((rc2 = mt_deal_tiles_device(s, order, image_w, image_h, tile_w, tile_h, n, r, s->d_multi_list, s->multi_stream)) < 0) return rc2;
+      }
       if (stats) HIP_TRY(hipMemsetAsync(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long), s->multi_stream));
       const bool counters_were = s->stats_enabled;
       if (stats) s->stats_enabled = true;
-      rc2 = launch_render(s, sensor, image_w, image_h, 0, 0, image_w, image_h, tile_w, tile_h, r, n, tiles_of(r),
-                          max_depth, s->d_multi_tiles, nullptr, s->multi_stream);
+      rc2 = launch_render(s, sensor, image_w, image_h, 0, 0, image_w, image_h, tile_w, tile_h, 0, 1, tiles_of(r),
+                          max_depth, s->d_multi_tiles, nullptr, s->multi_stream, tiles_of(r) > 0 ? s->d_multi_list : nullptr,
+                          list_id);
       s->stats_enabled = counters_were;
       if (rc2 != MT_OK) return rc2;
       if (share_costs) {
@@ -1462,95 +1664,132 @@ int mt_render_frame_multi(mt_scene *const *scenes, int n, const mt_sensor *senso
   }
   for (int r = 0; r < n; r++) {
     if (rcs[(size_t)r] != MT_OK) {
-      for (int q = 0; q < n; q++) {  // let whatever was launched finish before the buffers are touched again
-        if (scenes[q]->multi_stream) {
-          (void)hipSetDevice(scenes[q]->device);
-          (void)hipStreamSynchronize(scenes[q]->multi_stream);
-        }
-      }
+      drain();
+      forget();
       return fail(rcs[(size_t)r], "replica %d: %s", r, errs[(size_t)r].c_str());
     }
   }
 
-  // ---- phase 2: gather on the first replica's device, blit, one copy to the host
-  HIP_TRY(hipSetDevice(root->device));
-  if ((rc = ensure_bytes((void **)&root->d_multi_frame, &root->multi_frame_bytes, (size_t)image_w * image_h * 3)) != MT_OK) return rc;
-  if ((rc = ensure_bytes((void **)&root->d_multi_gather, &root->multi_gather_bytes, (size_t)n * (size_t)n_max * slot)) != MT_OK) return rc;
-  for (int r = 0; r < n; r++) {
-    mt_scene *s = scenes[r];
-    const int n_r = tiles_of(r);
-    if (n_r == 0) continue;
-    if (r != 0) HIP_TRY(hipStreamWaitEvent(root->multi_stream, s->multi_done, 0));
-    const uint8_t *src = s->d_multi_tiles;
-    if (s->device != root->device) {
-      {  // direct xGMI reads where the platform offers them (once per pair; the copy works without, staged)
-        static std::mutex mu;
-        static std::map<std::pair<int, int>, bool> tried;
-        std::lock_guard<std::mutex> lock(mu);
-        bool &done = tried[std::make_pair(root->device, s->device)];
-        if (!done) {
-          done = true;
-          int can = 0;
-          if (hipDeviceCanAccessPeer(&can, root->device, s->device) == hipSuccess && can) {
-            if (hipDeviceEnablePeerAccess(s->device, 0) != hipSuccess) (void)hipGetLastError();  // (already enabled)
-          } else {
-            (void)hipGetLastError();
-          }
-        }
+  // ---- phase 2: gather on the first replica's device, blit, one copy to the host.  (One exit: a failure half way
+  // must not return while copies into out_rgb or kernels on the replicas' buffers are still queued.)
+  const bool force_peer = root->tune.v[MT_TUNE_MULTI_FORCE_PEER_COPY] != 0.0;
+  auto phase2 = [&]() -> int {
+    HIP_TRY(hipSetDevice(root->device));
+    int rc2 = ensure_bytes((void **)&root->d_multi_frame, &root->multi_frame_bytes, (size_t)image_w * image_h * 3);
+    if (rc2 == MT_OK) rc2 = ensure_bytes((void **)&root->d_multi_gather, &root->multi_gather_bytes, (size_t)n * (size_t)n_max * slot);
+    if (rc2 == MT_OK) rc2 = ensure_bytes((void **)&root->d_multi_lists, &root->multi_lists_bytes, (size_t)n * (size_t)n_max * 4);
+    if (rc2 != MT_OK) return rc2;
+    if (redeal) {  // every replica's list, for the blit: the same order, dealt out for every rank
+      for (int r = 0; r < n; r++) {
+        if ((rc2 = mt_deal_tiles_device(root, by_map ? root->d_multi_order : nullptr, image_w, image_h, tile_w, tile_h, n, r,
+                                        root->d_multi_lists + (size_t)r * n_max, root->multi_stream)) < 0) return rc2;
       }
-      uint8_t *dst = root->d_multi_gather + (size_t)r * (size_t)n_max * slot;
-      HIP_TRY(hipMemcpyPeerAsync(dst, root->device, s->d_multi_tiles, s->device, (size_t)n_r * slot, root->multi_stream));
-      src = dst;
     }
-    if ((rc = mt_blit_tiles_device(root, image_w, image_h, tile_w, tile_h, r, n, n_r, src, root->d_multi_frame,
-                                   root->multi_stream)) != MT_OK) {
-      return rc;
-    }
-  }
-  HIP_TRY(hipMemcpyAsync(out_rgb, root->d_multi_frame, (size_t)image_w * image_h * 3, hipMemcpyDeviceToHost, root->multi_stream));
-  if (share_costs) {
-    // all maps to the first replica's device, element-wise maximum, and back to every replica -- behind the frame's
-    // copy on the same streams, so that it is done before the next call's launches without anybody waiting for it
-    if ((rc = ensure_bytes((void **)&root->d_multi_maps, &root->multi_maps_bytes, (size_t)n * map_bytes)) != MT_OK) return rc;
-    if (!root->multi_comb_done) HIP_TRY(hipEventCreateWithFlags(&root->multi_comb_done, hipEventDisableTiming));
+    for (int r = 1; r < n; r++) HIP_TRY(hipStreamWaitEvent(root->multi_stream, scenes[r]->multi_done, 0));  // (every replica: also one without tiles has a map on its way)
     for (int r = 0; r < n; r++) {
       mt_scene *s = scenes[r];
-      unsigned *dst = root->d_multi_maps + (size_t)r * map_w * map_h;
-      if (s->device != root->device) HIP_TRY(hipMemcpyPeerAsync(dst, root->device, s->d_multi_map, s->device, map_bytes, root->multi_stream));
-      else HIP_TRY(hipMemcpyAsync(dst, s->d_multi_map, map_bytes, hipMemcpyDeviceToDevice, root->multi_stream));
+      const int n_r = tiles_of(r);
+      if (n_r == 0) continue;
+      const uint8_t *src = s->d_multi_tiles;
+      if (s->device != root->device || force_peer) {
+        if (s->device != root->device) {  // direct xGMI reads where the platform offers them (once per pair; the copy works without, staged)
+          static std::mutex mu;
+          static std::map<std::pair<int, int>, bool> tried;
+          std::lock_guard<std::mutex> lock(mu);
+          bool &done = tried[std::make_pair(root->device, s->device)];
+          if (!done) {
+            done = true;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, root->device, s->device) == hipSuccess && can) {
+              if (hipDeviceEnablePeerAccess(s->device, 0) != hipSuccess) (void)hipGetLastError();  // (already enabled)
+            } else {
+              (void)hipGetLastError();
+            }
+          }
+        }
+        uint8_t *dst = root->d_multi_gather + (size_t)r * (size_t)n_max * slot;
+        HIP_TRY(hipMemcpyPeerAsync(dst, root->device, s->d_multi_tiles, s->device, (size_t)n_r * slot, root->multi_stream));
+        src = dst;
+      }
+      if ((rc2 = mt_blit_tile_list_device(root, image_w, image_h, tile_w, tile_h, root->d_multi_lists + (size_t)r * n_max, n_r,
+                                          src, root->d_multi_frame, root->multi_stream)) != MT_OK) return rc2;
     }
-    hipLaunchKernelGGL(max_maps_kernel, dim3(256), dim3(256), 0, root->multi_stream, root->d_multi_maps, n, (size_t)map_w * map_h);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(root->multi_comb_done, root->multi_stream));
+    HIP_TRY(hipMemcpyAsync(out_rgb, root->d_multi_frame, (size_t)image_w * image_h * 3, hipMemcpyDeviceToHost, root->multi_stream));
+    if (share_costs) {
+      // all maps to the first replica's device, element-wise maximum, and back to every replica -- behind the frame's
+      // copy on the same streams
+      if ((rc2 = ensure_bytes((void **)&root->d_multi_maps, &root->multi_maps_bytes, (size_t)n * map_bytes)) != MT_OK) return rc2;
+      if (!root->multi_comb_done) HIP_TRY(hipEventCreateWithFlags(&root->multi_comb_done, hipEventDisableTiming));
+      for (int r = 0; r < n; r++) {
+        mt_scene *s = scenes[r];
+        unsigned *dst = root->d_multi_maps + (size_t)r * map_w * map_h;
+        if (s->device != root->device || force_peer) HIP_TRY(hipMemcpyPeerAsync(dst, root->device, s->d_multi_map, s->device, map_bytes, root->multi_stream));
+        else HIP_TRY(hipMemcpyAsync(dst, s->d_multi_map, map_bytes, hipMemcpyDeviceToDevice, root->multi_stream));
+      }
+      hipLaunchKernelGGL(max_maps_kernel, dim3(256), dim3(256), 0, root->multi_stream, root->d_multi_maps, n, (size_t)map_w * map_h);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipEventRecord(root->multi_comb_done, root->multi_stream));
+      for (int r = 0; r < n; r++) {
+        mt_scene *s = scenes[r];
+        HIP_TRY(hipSetDevice(s->device));
+        HIP_TRY(hipStreamWaitEvent(s->multi_stream, root->multi_comb_done, 0));
+        if (s->device != root->device || force_peer) HIP_TRY(hipMemcpyPeerAsync(s->d_multi_map, s->device, root->d_multi_maps, root->device, map_bytes, s->multi_stream));
+        else HIP_TRY(hipMemcpyAsync(s->d_multi_map, root->d_multi_maps, map_bytes, hipMemcpyDeviceToDevice, s->multi_stream));
+        if ((rc2 = mt_scene_import_costs_device(s, s->d_multi_map, map_w, map_h, s->multi_stream)) != MT_OK) return rc2;
+      }
+      HIP_TRY(hipSetDevice(root->device));
+    }
+    HIP_TRY(hipStreamSynchronize(root->multi_stream));
+    return MT_OK;
+  };
+  if ((rc = phase2()) != MT_OK) {
+    const std::string text = g_err;
+    drain();
+    forget();
+    return fail(rc, "%s", text.c_str());
+  }
+  const double total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+  // every replica's launch has completed (the root's stream waited for their events); its device status and counters
+  auto phase3 = [&]() -> int {
+    int worst = MT_OK;
+    std::string text;
     for (int r = 0; r < n; r++) {
       mt_scene *s = scenes[r];
       HIP_TRY(hipSetDevice(s->device));
-      HIP_TRY(hipStreamWaitEvent(s->multi_stream, root->multi_comb_done, 0));
-      if (s->device != root->device) HIP_TRY(hipMemcpyPeerAsync(s->d_multi_map, s->device, root->d_multi_maps, root->device, map_bytes, s->multi_stream));
-      else HIP_TRY(hipMemcpyAsync(s->d_multi_map, root->d_multi_maps, map_bytes, hipMemcpyDeviceToDevice, s->multi_stream));
-      if ((rc = mt_scene_import_costs_device(s, s->d_multi_map, map_w, map_h, s->multi_stream)) != MT_OK) return rc;
+      HIP_TRY(hipStreamSynchronize(s->multi_stream));
+      unsigned long long c[ST_COUNT];
+      HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+      const int st_rc = check_status(c);
+      if (st_rc != MT_OK && worst == MT_OK) {  // (keep going: every replica is synchronised and read)
+        worst = st_rc;
+        text = g_err;
+      }
+      if (stats) {
+        HIP_TRY(hipMemset(s->d_counters, 0, sizeof c));
+        memset(&stats[r], 0, sizeof(mt_stats));
+        fill_stats(c, &stats[r]);
+        double a = 0.0, b = 0.0;
+        if (tiles_of(r) > 0 && mt_scene_kernel_times(s, 1, &a, &b) == 1) stats[r].kernel_ms = a + b;
+        stats[r].total_ms = total_ms;
+      }
     }
-    HIP_TRY(hipSetDevice(root->device));
+    if (worst != MT_OK) return fail(worst, "%s", text.c_str());
+    return MT_OK;
+  };
+  if ((rc = phase3()) != MT_OK) {
+    const std::string text = g_err;
+    drain();
+    forget();
+    return fail(rc, "%s", text.c_str());
   }
-  HIP_TRY(hipStreamSynchronize(root->multi_stream));
-  const double total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
-  // every replica's launch has completed (the root's stream waited for their events); its device status and counters
   for (int r = 0; r < n; r++) {
-    mt_scene *s = scenes[r];
-    HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamSynchronize(s->multi_stream));
-    unsigned long long c[ST_COUNT];
-    HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
-    if ((rc = check_status(c)) != MT_OK) return rc;
-    if (stats) {
-      HIP_TRY(hipMemset(s->d_counters, 0, sizeof c));
-      memset(&stats[r], 0, sizeof(mt_stats));
-      fill_stats(c, &stats[r]);
-      double a = 0.0, b = 0.0;
-      if (tiles_of(r) > 0 && mt_scene_kernel_times(s, 1, &a, &b) == 1) stats[r].kernel_ms = a + b;
-      stats[r].total_ms = total_ms;
-    }
+    scenes[r]->multi_geom = geom;
+    scenes[r]->multi_rank = r;
+    scenes[r]->multi_list_id = list_id;
   }
+  root->multi_have_map = share_costs;
+  root->multi_sensor = *sensor;
+  root->multi_frames_at_rest = frames_at_rest;
   (void)hipSetDevice(root->device);  // (the calling thread's current device: the first replica's, as on entry to phase 2)
   return MT_OK;
 }

@@ -235,7 +235,23 @@ struct RenderParams {
   // forecast reads it instead of item_cost: the old-image position of a block mostly lies in another rank's tile.
   const unsigned int *cost_map;
   int32_t cost_map_w, cost_map_h;
+  // Tile LIST launches (mt_render_tile_list_device: ownership of the frame's tiles balanced by cost): slot j holds tile
+  // tile_list[j]; nullptr = the modular form, first_tile + j * tile_stride.  tile_slot[t] = slot of tile t or -1.
+  const int32_t *tile_list;
+  const int32_t *tile_slot;
+  int32_t from_map;  // 1: forecast_kernel reads the costs from cost_map by image position even when the camera is at rest
 };
+
+// slot j of a launch -> tile of the region's grid, and back (-1: not this launch's)
+__device__ __forceinline__ int tile_of_slot(const RenderParams &P, int j) {
+  return P.tile_list != nullptr ? P.tile_list[j] : P.first_tile + j * P.tile_stride;
+}
+__device__ __forceinline__ int slot_of_tile(const RenderParams &P, int t) {
+  if (P.tile_list != nullptr) return P.tile_slot[t];
+  if (t < P.first_tile || (t - P.first_tile) % P.tile_stride != 0) return -1;
+  const int j = (t - P.first_tile) / P.tile_stride;
+  return j < P.n_tiles ? j : -1;
+}
 
 // Bytes of LDS one wave needs for its traversal stack: 20-byte frames, or 16-byte
 // ones when a node index and a triangle index fit one word together

@@ -77,7 +77,7 @@ __device__ __forceinline__ PoolGeom pool_geometry(const RenderParams &P, unsigne
   const int items_per_tile = P.blocks_x * P.blocks_y;
   const int j = (int)(item / (unsigned)items_per_tile);
   const int b = (int)(item % (unsigned)items_per_tile);
-  const int tile = P.first_tile + j * P.tile_stride;
+  const int tile = tile_of_slot(P, j);
   const int tx0 = P.region_x + (tile % P.tiles_x) * P.tile_w;
   const int ty0 = P.region_y + (tile / P.tiles_x) * P.tile_h;
   const int cw = min(P.tile_w, P.region_x + P.region_w - tx0);  // edge clipping as
@@ -306,9 +306,10 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
 // the pixel store.  Persistent waves pull work units in pool_schedule_kernel's
 // order; the first ones (the longest) run at raised wave priority.
 // pool_engine is the body shared by pool_kernel (all units of the launch) and hybrid_kernel (mt_render.hip; MIXED: the
-// order holds units of both engines, the pool's marked by kHybridPoolSub in order_sub).  `carry`: a unit index this
-// wave has fetched already, or kCarryNone.  Returns kCarryDone when the order is exhausted, kCarryFail after a
-// failure, else (MIXED) the first fetched unit that belongs to the other engine.
+// order holds units of both engines -- the pool's first, n_work[1] of them, marked by kHybridPoolSub in order_sub and
+// handed out through work_counter[1]; the state machine's behind them through work_counter[2]).  `carry`: a unit index
+// this wave has fetched already, or kCarryNone.  Returns kCarryDone when its units are exhausted, kCarryFail after a
+// failure.
 constexpr unsigned kCarryNone = 0xffffffffu, kCarryDone = 0xfffffffeu, kCarryFail = 0xfffffffdu;
 constexpr int kHybridPoolSub = 32;
 template <bool STATS, bool MIXED>
@@ -343,7 +344,7 @@ __device__ __forceinline__ unsigned pool_engine(const DevScene &S, const RenderP
   const V3 s_start = v3_load(P.sensor.start_point);
   const V3 s_ds = v3_load(P.sensor.delta_scanline);
   const V3 s_dp = v3_load(P.sensor.delta_pixel);
-  const unsigned n_work = *P.n_work;
+  const unsigned n_work = MIXED ? P.n_work[1] : *P.n_work;
   unsigned result = kCarryDone;
   // Records a pass may need on top of those its rays already have, kept back
   // while the free ones run low (see the throttle below).
@@ -360,13 +361,7 @@ __device__ __forceinline__ unsigned pool_engine(const DevScene &S, const RenderP
     if (w >= n_work) break;
     const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane((int)P.order_item[w]);
     int sub = __builtin_amdgcn_readfirstlane((int)P.order_sub[w]);
-    if (MIXED) {
-      if (sub < kHybridPoolSub) {  // the state machine's
-        result = w;
-        break;
-      }
-      sub -= kHybridPoolSub;
-    }
+    if (MIXED) sub -= kHybridPoolSub;
     // The longest units run at raised priority: one per SIMD at most (more
     // would only compete with each other), so that they get a SIMD's issue
     // slots ahead of the two short-unit waves that share it.

@@ -69,7 +69,7 @@ __device__ __forceinline__ ItemGeom item_geometry(const RenderParams &P, unsigne
   const int items_per_tile = P.blocks_x * P.blocks_y;
   const int j = (int)(item / (unsigned)items_per_tile);
   const int b = (int)(item % (unsigned)items_per_tile);
-  const int tile = P.first_tile + j * P.tile_stride;
+  const int tile = tile_of_slot(P, j);
   const int tx0 = P.region_x + (tile % P.tiles_x) * P.tile_w;
   const int ty0 = P.region_y + (tile / P.tiles_x) * P.tile_h;
   const int cw = min(P.tile_w, P.region_x + P.region_w - tx0);  // edge clipping as
@@ -265,6 +265,23 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
     const float c = (float)(word & 0x7fffffffu);
     return (unsigned)((word >> 31) ? c / w1 : c);
   };
+  if (!reproject && P.from_map) {
+    // A tile-list launch whose list differs from the previous launch's (the ownership of the tiles was re-balanced):
+    // the slots' own cost words belong to other tiles; the block's cost comes from the frame-wide map (all ranks' costs
+    // of the previous frame, mt_scene_import_costs_device) at its own position.  0 = nobody reported it.
+    const int per_tile_ = P.blocks_x * P.blocks_y;
+    const int j_ = (int)(i / (unsigned)per_tile_), b_ = (int)(i % (unsigned)per_tile_);
+    const int tile_ = tile_of_slot(P, j_);
+    const int bx_ = (P.region_x + (tile_ % P.tiles_x) * P.tile_w + (b_ % P.blocks_x) * 8) >> 3;
+    const int by_ = (P.region_y + (tile_ / P.tiles_x) * P.tile_h + (b_ / P.blocks_x) * 8) >> 3;
+    unsigned f = unseen;
+    if (bx_ < P.cost_map_w && by_ < P.cost_map_h) {
+      const unsigned c = P.cost_map[(size_t)by_ * P.cost_map_w + bx_];
+      if (c != 0u) f = c;
+    }
+    P.item_forecast[i] = f;
+    return;
+  }
   if (!reproject) {
     // (bit 31, state machine only: the block was rendered as quarters -- schedule_kernel's hysteresis)
     // blend > 0 (the camera stands still and the previous launch made a forecast too): the new forecast is a mix
@@ -290,7 +307,7 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
   }
   const int per_tile = P.blocks_x * P.blocks_y;
   const int j = (int)(i / (unsigned)per_tile), b = (int)(i % (unsigned)per_tile);
-  const int tile = P.first_tile + j * P.tile_stride;
+  const int tile = tile_of_slot(P, j);
   const int tx0 = P.region_x + (tile % P.tiles_x) * P.tile_w, ty0 = P.region_y + (tile / P.tiles_x) * P.tile_h;
   const double px = tx0 + (b % P.blocks_x) * 8 + 4.0, py = ty0 + (b / P.blocks_x) * 8 + 4.0;  // block centre
   double d[3], m[3][3];
@@ -350,9 +367,8 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
           }
           const int tx = ((int)qx - P.region_x) / P.tile_w, ty = ((int)qy - P.region_y) / P.tile_h;
           const int t = ty * P.tiles_x + tx;
-          if (t < P.first_tile || (t - P.first_tile) % P.tile_stride != 0) continue;  // another rank's tile
-          const int jj = (t - P.first_tile) / P.tile_stride;
-          if (jj >= P.n_tiles) continue;
+          const int jj = slot_of_tile(P, t);
+          if (jj < 0) continue;  // another rank's tile
           const int lx = ((int)qx - P.region_x) % P.tile_w, ly = ((int)qy - P.region_y) % P.tile_h;
           const unsigned nb = (unsigned)((size_t)jj * per_tile + (size_t)(ly / 8) * P.blocks_x + lx / 8);
           mxc = max(mxc, cost_of(P.item_cost[nb], nb));
@@ -392,7 +408,7 @@ __global__ void export_costs_kernel(RenderParams P, int engine, float wq1, float
   }
   const int per_tile = P.blocks_x * P.blocks_y;
   const int j = (int)(i / (unsigned)per_tile), b = (int)(i % (unsigned)per_tile);
-  const int tile = P.first_tile + j * P.tile_stride;
+  const int tile = tile_of_slot(P, j);
   const int px = P.region_x + (tile % P.tiles_x) * P.tile_w + (b % P.blocks_x) * 8;
   const int py = P.region_y + (tile / P.tiles_x) * P.tile_h + (b / P.blocks_x) * 8;
   const int bx = px >> 3, by = py >> 3;
@@ -407,6 +423,73 @@ __global__ void max_maps_kernel(unsigned *maps, int n, size_t words) {
     unsigned m = maps[i];
     for (int r = 1; r < n; r++) m = max(m, maps[(size_t)r * words + i]);
     maps[i] = m;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Ownership of a multi-GPU frame's tiles, balanced by cost.  The reference's master hands its WorkChunks out
+// dynamically: a worker asks for the next one when it is done (main_net_master.cc:62-80), so no worker idles while
+// another has chunks queued.  Ranks that render at the same time cannot pull from one queue without a collective per
+// tile; what they can do is compute THE SAME balanced assignment, each by itself, from the frame-wide cost map every
+// rank holds after the all-reduce (RenderParams::cost_map): tiles sorted by the cost of their blocks, most expensive
+// first (ties: lower tile number first -- the order is a pure function of the map), and dealt out in rounds that
+// change direction (0 1 .. N-1, N-1 .. 1 0, 0 1 ..), so that every rank holds one tile of every round: equal tile
+// counts -- buffer sizes and the gather stay what they were -- and cost sums that differ by less than one tile of a round.
+// tile_cost_kernel: cost[t] = sum over the tile's 8x8 blocks of the map (an all-zero map -- no frame measured yet --
+// orders the tiles by number).
+__global__ void tile_cost_kernel(const unsigned *map, int map_w, int map_h, int image_w, int image_h, int tile_w,
+                                 int tile_h, int tiles_x, int n_tiles, unsigned long long *cost) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_tiles) return;
+  const int x0 = (t % tiles_x) * tile_w, y0 = (t / tiles_x) * tile_h;
+  const int x1 = min(x0 + tile_w, image_w), y1 = min(y0 + tile_h, image_h);
+  unsigned long long sum = 0ull;
+  for (int by = y0 >> 3; by <= ((y1 - 1) >> 3) && by < map_h; by++) {
+    for (int bx = x0 >> 3; bx <= ((x1 - 1) >> 3) && bx < map_w; bx++) sum += map[(size_t)by * map_w + bx];
+  }
+  cost[t] = sum;
+}
+// order[p] = the tile at position p of the descending order (rank by counting: n <= a few thousand tiles).
+__global__ void tile_order_kernel(const unsigned long long *cost, int n_tiles, int32_t *order) {
+  __shared__ unsigned long long s_c[256];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long mine = t < n_tiles ? cost[t] : 0ull;
+  int rank = 0;
+  for (int base = 0; base < n_tiles; base += 256) {
+    __syncthreads();
+    if (base + (int)threadIdx.x < n_tiles) s_c[threadIdx.x] = cost[base + threadIdx.x];
+    __syncthreads();
+    const int m = min(256, n_tiles - base);
+    for (int k = 0; k < m; k++) {
+      const unsigned long long c = s_c[k];
+      rank += (c > mine || (c == mine && base + k < t)) ? 1 : 0;
+    }
+  }
+  if (t < n_tiles) order[rank] = t;
+}
+// The tiles of `rank` in slot order: slot q = the rank's tile of round q.  n = dealt_tile_count(n_tiles, world, rank).
+__host__ __device__ inline int dealt_position(int q, int world, int rank) { return q * world + ((q & 1) ? world - 1 - rank : rank); }
+__host__ inline int dealt_tile_count(int n_tiles, int world, int rank) {
+  int n = 0;
+  for (int q = n_tiles / world - 1; q <= n_tiles / world; q++) {  // full rounds hold every rank; the last, partial one may
+    if (q >= 0 && dealt_position(q, world, rank) < n_tiles) n = q + 1;
+  }
+  return n;
+}
+__global__ void deal_tiles_kernel(const int32_t *order, int n_tiles, int world, int rank, int n, int32_t *list) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const int p = dealt_position(q, world, rank);
+  list[q] = order != nullptr ? order[p] : p;  // (no order yet: positions = tile numbers)
+}
+// tile_slot[t] = -1 for all t, then slot j for the tiles of the list
+__global__ void tile_slot_kernel(const int32_t *list, int n, int32_t *tile_slot, int n_tiles_total, int phase) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (phase == 0) {
+    if (i < n_tiles_total) tile_slot[i] = -1;
+  } else if (i < n) {
+    const int t = list[i];
+    if (t >= 0 && t < n_tiles_total) tile_slot[t] = i;  // (a tile outside the grid has no pixels: its slot stays unwritten)
   }
 }
 
@@ -485,12 +568,14 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
 __global__ __launch_bounds__(kSchedThreads) void hybrid_schedule_kernel(RenderParams P, int n_waves, float quad_share,
                                                                         float pool_share, float piece_time1,
                                                                         float piece_time2, float cell_factor,
-                                                                        unsigned char *form) {
+                                                                        unsigned char *form, float starter_share,
+                                                                        unsigned max_starters) {
   __shared__ unsigned long long s_sum;
+  __shared__ unsigned s_starters;
   __shared__ unsigned s_count[2][kSchedBuckets];
   __shared__ unsigned s_start[2][kSchedBuckets];
   const int tid = threadIdx.x;
-  if (tid == 0) s_sum = 0ull;
+  if (tid == 0) { s_sum = 0ull; s_starters = 0u; }
   for (int b = tid; b < 2 * kSchedBuckets; b += kSchedThreads) (&s_count[0][0])[b] = 0u;
   __syncthreads();
   const float kQuarterTime = 0.45f;
@@ -512,11 +597,14 @@ __global__ __launch_bounds__(kSchedThreads) void hybrid_schedule_kernel(RenderPa
       f = 0; unit = c; n = 1u;
     }
   };
+  unsigned my_starters = 0u;
   for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
     int f; unsigned unit, n;
     decide(i, f, unit, n);
     atomicAdd(&s_count[f >= 2 ? 0 : 1][cost_bucket(unit)], n);
+    if (f < 2 && (float)unit > share * starter_share) my_starters += n;
   }
+  if (my_starters) atomicAdd(&s_starters, my_starters);
   __syncthreads();
   if (tid == 0) {
     unsigned acc = 0u;
@@ -525,8 +613,11 @@ __global__ __launch_bounds__(kSchedThreads) void hybrid_schedule_kernel(RenderPa
         s_start[g][b] = acc;
         acc += s_count[g][b];
       }
+      if (g == 0) P.n_work[1] = acc;  // the pool's part: units [0, n_work[1])
     }
     P.n_work[0] = acc;
+    // (no pool part: nobody needs to skip it)
+    P.n_work[2] = P.n_work[1] == 0u ? 0u : (s_starters < max_starters ? s_starters : max_starters);
   }
   __syncthreads();
   for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
@@ -584,10 +675,12 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
   const bool from_primary = P.from_primary != 0;
   const unsigned n2 = P.class_count[2], n1 = P.class_count[1], n0 = P.class_count[0];
   const unsigned n_work = from_primary ? 4u * n2 + n1 + n0 : *P.n_work;
+  // (hybrid launches: the state machine's units lie behind the pool's n_work[1] and have a counter of their own)
+  const unsigned w_base = MIXED ? P.n_work[1] : 0u;
 
   for (;;) {
     unsigned w = carry;
-    if (carry == kCarryNone) w = fetch_work(P.work_counter + 1, lane);
+    if (carry == kCarryNone) w = w_base + fetch_work(P.work_counter + (MIXED ? 2 : 1), lane);
     carry = kCarryNone;
     if (S.hb) {
       const unsigned long long ex = __builtin_amdgcn_read_exec();
@@ -601,10 +694,6 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
       // (schedule_kernel); the longest blocks come as four quarters.
       item = P.order_item[w];
       sub = (int)P.order_sub[w];
-      if (MIXED && __builtin_amdgcn_readfirstlane(sub) >= kHybridPoolSub) {  // the ray pool's
-        result = w;
-        break;
-      }
       if (w < (n_work >> 4)) __builtin_amdgcn_s_setprio(3);
       else if (w < (n_work >> 2)) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(0);
@@ -1048,11 +1137,17 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
 // wave with the first unit it fetches that is not the pool's.  (One merged order with waves changing over in both
 // directions was measured too: 1.5 % slower on a frame without pool units, no better at N = 8.)  Same arithmetic per
 // pixel in either part, as in the two kernels above.
+// STARTERS (round 4): the two parts have a counter each, and n_work[2] waves -- one per workgroup, as many as the state
+// machine has units expected to take more than a third of an even share -- skip the pool's part: the state machine's
+// longest blocks start with the launch instead of behind the pool's part (which lasts a quarter of a rank's share of
+// the 4K frame at N = 8; a block of 26-32 passes that starts there ends 20-30 % after everybody else).
 template <bool STATS>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void hybrid_kernel(DevScene S, RenderParams P) {
-  const unsigned carry = pool_engine<STATS, true>(S, P, kCarryNone);
-  if (carry >= kCarryFail) return;  // the order is exhausted, or a device-side bound tripped (status is set)
-  (void)sm_engine<STATS, false>(S, P, carry);
+  const bool starter = (threadIdx.x >> 6) == 3 && blockIdx.x < P.n_work[2];
+  if (!starter) {
+    if (pool_engine<STATS, true>(S, P, kCarryNone) == kCarryFail) return;  // a device-side bound tripped (status is set)
+  }
+  (void)sm_engine<STATS, true>(S, P, kCarryNone);
 }
 
 // OctTree::IntersectRay for a batch of arbitrary rays: lane i of the grid
@@ -1110,7 +1205,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void intersect_kernel(DevSc
 
 // BlitWorkChunk (main_net_master.cc:223-236) for a buffer of tile slots.
 __global__ void blit_tiles_kernel(int image_w, int image_h, int tile_w, int tile_h, int tiles_x,
-                                  int first_tile, int tile_stride, int n_tiles,
+                                  int first_tile, int tile_stride, int n_tiles, const int32_t *tile_list,
                                   const uint8_t *tiles, uint8_t *image) {
   const size_t slot_bytes = (size_t)tile_w * tile_h * 3;
   const size_t total = (size_t)n_tiles * tile_w * tile_h;
@@ -1118,7 +1213,7 @@ __global__ void blit_tiles_kernel(int image_w, int image_h, int tile_w, int tile
        p += (size_t)gridDim.x * blockDim.x) {
     const int j = (int)(p / ((size_t)tile_w * tile_h));
     const int q = (int)(p % ((size_t)tile_w * tile_h));
-    const int tile = first_tile + j * tile_stride;
+    const int tile = tile_list != nullptr ? tile_list[j] : first_tile + j * tile_stride;
     const int x0 = (tile % tiles_x) * tile_w, y0 = (tile / tiles_x) * tile_h;
     const int cw = min(tile_w, image_w - x0), ch = min(tile_h, image_h - y0);
     if (q >= cw * ch) continue;

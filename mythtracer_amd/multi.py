@@ -17,3 +17,13 @@ def gather_and_blit(dist, mine, gathered, rank, world, image_w, image_h, tile_w,
         for r in range(world):
             first, stride, n = tiling.rank_tiles(image_w, image_h, tile_w, tile_h, r, world)
             blit(gathered[r], first, stride, n)
+
+
+def gather_and_blit_lists(dist, mine, gathered, rank, world, list_of, blit):
+    """The same exchange for cost-balanced ownership (tiling.deal_tiles / mt_deal_tiles_device): every rank holds
+    the tiles of ITS list, slot j = tile list[j]; list_of(r) gives rank r's list on rank 0 (every rank can compute
+    all of them: the order is a function of the all-reduced cost map); blit(slots, tile_list) writes them."""
+    dist.gather(mine, gathered, dst=0)
+    if rank == 0:
+        for r in range(world):
+            blit(gathered[r], list_of(r))

@@ -896,9 +896,41 @@ static void sort_children(child_hit *a, int n) {
 
 /* OctTree::Node::PrimitiveIntersectRay, octtree.cc:169-257.  Returns triangle
  * index or -1. */
+#ifdef ORC_F2_PROBE
+/* Diagnostic build only (scripts/f2_bound.py; never part of liboracle.so): what would the PROVABLE early-out of a
+ * shadow-loop iteration (mythtracer.cc:94-156) save?  The iteration's outcome is "in shadow" as soon as
+ * a node visited in the reference's order has an own-list hit that is opaque and not farther than the light, and no
+ * transparent triangle lives in the subtree below it: whatever the children return replaces that hit only by a closer
+ * one, which is opaque too.  The probe lets the traversal run on and counts the work below such nodes.
+ * g_f2: [0] node visits of shadow rays, [1] of them below a deciding node, [2] / [3] the same for triangle tests,
+ * [4] deciding nodes, [5] shadow rays, [6] shadow rays that end on an opaque hit within the light distance. */
+static __thread double g_ld = -1.0;
+static __thread int g_inskip = 0;
+uint64_t g_f2[8];
+static int subtree_transparent(const orc_scene *s, const node *n) {
+  for (int i = 0; i < n->n_prims; i++) {
+    const int m = s->tris[n->prims[i]].mtl;
+    if (m >= 0 && s->mtls[m].tr != 0.0) return 1;
+  }
+  if (n->kids) {
+    for (int k = 0; k < 8; k++) {
+      if (subtree_transparent(s, &n->kids[k])) return 1;
+    }
+  }
+  return 0;
+}
+#endif
+
 static int node_intersect(const orc_scene *s, const node *n, const ray_t *r,
                           v3 *point, double *distance, uint64_t *cnt) {
   cnt[ORC_CNT_NODE_VISITS]++;
+#ifdef ORC_F2_PROBE
+  if (g_ld >= 0.0) {
+    __sync_fetch_and_add(&g_f2[0], 1);
+    if (g_inskip) __sync_fetch_and_add(&g_f2[1], 1);
+  }
+  const uint64_t f2_tri0 = cnt[ORC_CNT_TRI_TESTS];
+#endif
   int closest = -1;
   double closest_d = 0.0;
   v3 closest_p = v3_make(0, 0, 0);
@@ -911,6 +943,20 @@ static int node_intersect(const orc_scene *s, const node *n, const ray_t *r,
     closest_d = d;
     closest_p = p;
   }
+#ifdef ORC_F2_PROBE
+  int f2_mine = 0;
+  if (g_ld >= 0.0) {
+    __sync_fetch_and_add(&g_f2[2], cnt[ORC_CNT_TRI_TESTS] - f2_tri0);
+    if (g_inskip) __sync_fetch_and_add(&g_f2[3], cnt[ORC_CNT_TRI_TESTS] - f2_tri0);
+    if (!g_inskip && closest != -1 && closest_d <= g_ld && n->kids) {
+      const int m = s->tris[closest].mtl;
+      if ((m < 0 || s->mtls[m].tr == 0.0) && !subtree_transparent(s, n)) {
+        f2_mine = g_inskip = 1;
+        __sync_fetch_and_add(&g_f2[4], 1);
+      }
+    }
+  }
+#endif
   child_hit cons[8];
   int n_cons = 0;
   if (n->kids) { /* :204-211 */
@@ -935,6 +981,9 @@ static int node_intersect(const orc_scene *s, const node *n, const ray_t *r,
     closest_p = p;
     break;
   }
+#ifdef ORC_F2_PROBE
+  if (f2_mine) g_inskip = 0;
+#endif
   if (closest == -1) return -1;
   *point = closest_p;
   *distance = closest_d;
@@ -1083,7 +1132,15 @@ static v3 trace_ray_worker(const orc_scene *s, v3 origin, v3 direction,
       v3 sp;
       double sd;
       cnt[ORC_CNT_RAYS_SHADOW]++;
+#ifdef ORC_F2_PROBE
+      g_ld = light_distance;
+      __sync_fetch_and_add(&g_f2[5], 1);
+#endif
       int sprim = tree_intersect(s, so, light_direction, &sp, &sd, cnt);
+#ifdef ORC_F2_PROBE
+      g_ld = -1.0;
+      if (sprim != -1 && sd <= light_distance && (s->tris[sprim].mtl < 0 || s->mtls[s->tris[sprim].mtl].tr == 0.0)) __sync_fetch_and_add(&g_f2[6], 1);
+#endif
       if (sprim == -1) break;
       if (sd > light_distance) break;
       /* :121 dereferences shadow_primitive->mtl unconditionally (segfault on

@@ -38,6 +38,37 @@ def main():
     dist.barrier()
     if rank == 0:
         np.save(out_path, frame)
+    if len(sys.argv) > 6 and sys.argv[6] == "balanced":
+        # Second frame with COST-BALANCED ownership, as bench.py --gpus N does it: every rank writes a cost per 8x8
+        # block of its tiles into a frame-wide map (here: the block's summed pixel values, standing in for measured
+        # wave cycles), the maps are all-reduced (MAX), every rank orders the tiles by that map and takes its deal.
+        mw, mh = (W + 7) // 8, (H + 7) // 8
+        cmap = torch.zeros((mh, mw), dtype=torch.int32)
+        for j in range(n):
+            x, y, cw, ch = tiling.tile_rect(first + j * stride, W, H, T, T)
+            rgb = mine[j * sb: j * sb + cw * ch * 3].numpy().reshape(ch, cw, 3).astype(np.int64)
+            for by in range(0, ch, 8):
+                for bx in range(0, cw, 8):
+                    cmap[(y + by) // 8, (x + bx) // 8] = 1 + int(rgb[by:by + 8, bx:bx + 8].sum())
+        dist.all_reduce(cmap, op=dist.ReduceOp.MAX)
+        tx, ty = tiling.tile_grid(W, H, T, T)
+        order = tiling.order_tiles(cmap.numpy().astype(np.uint32), W, H, T, T)
+        lst = tiling.deal_tiles(order, tx * ty, world, rank)
+        assert len(lst) <= n_max
+        mine2 = torch.zeros(n_max * sb, dtype=torch.uint8)
+        for j, t in enumerate(lst):
+            x, y, cw, ch = tiling.tile_rect(int(t), W, H, T, T)
+            rgb = o.render(cam, W, H, chunk=(x, y, cw, ch), nthreads=1)["rgb"]
+            mine2[j * sb: j * sb + cw * ch * 3] = torch.from_numpy(rgb.reshape(-1).copy())
+        frame2 = np.zeros((H, W, 3), dtype=np.uint8)
+        gathered2 = [torch.zeros_like(mine2) for _ in range(world)] if rank == 0 else None
+        multi.gather_and_blit_lists(dist, mine2, gathered2, rank, world,
+                                    lambda r: tiling.deal_tiles(order, tx * ty, world, r),
+                                    lambda slots, tl: tiling.blit_tile_list(frame2, slots.numpy(), T, T, tl))
+        dist.barrier()
+        if rank == 0:
+            np.save(out_path + ".balanced.npy", frame2)
+            np.save(out_path + ".order.npy", order)
     dist.destroy_process_group()
 
 

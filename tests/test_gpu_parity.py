@@ -750,6 +750,34 @@ def test_4k_frame_contains_the_reference_1080p_frame(scenes):
     assert hashlib.sha256(tiled.tobytes()).hexdigest() == frames["room_3840x2160_d5"]["sha256"]
     assert np.array_equal(tiled[::16, ::16], load("room_3840x2160_d5_sub16")["rgb"])
     assert np.array_equal(tiled[11::16, 5::16], load("room_3840x2160_d5_sub16_odd")["rgb"])
+    # ... and once more with the tiles dealt out BY COST (what bench.py --gpus 8 does from the second frame on): the
+    # eight ranks' cost maps of a frame rendered that way, combined, order the tiles; every rank takes its deal
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    mw, mh = (W + 7) // 8, (H + 7) // 8
+    total = tiling.tile_grid(W, H, T, T)[0] * tiling.tile_grid(W, H, T, T)[1]
+    order = None
+    for frame_no in range(2):
+        frame.zero_()
+        maps = []
+        for rank in range(world):
+            n = abi.dealt_tile_count(W, H, T, T, world, rank)
+            lst = torch.zeros(n, dtype=torch.int32, device="cuda")
+            assert abi.deal_tiles_device(h, vp(order) if order is not None else None, W, H, T, T, world, rank, vp(lst)) == n
+            slots = torch.zeros(n * tiling.slot_bytes(T, T), dtype=torch.uint8, device="cuda")
+            if order is not None:
+                abi.import_costs_device(h, vp(comb), mw, mh)
+            abi.render_tile_list_device(h, sens, W, H, T, T, vp(lst), n, 0, 5, vp(slots))
+            abi.blit_tile_list_device(h, W, H, T, T, vp(lst), n, vp(slots), vp(frame))
+            cm = torch.zeros((mh, mw), dtype=torch.int32, device="cuda")
+            abi.export_costs_device(h, vp(cm), mw, mh)
+            maps.append(cm)
+        torch.cuda.synchronize()
+        abi.read_stats(h)
+        assert hashlib.sha256(frame.cpu().numpy().tobytes()).hexdigest() == frames["room_3840x2160_d5"]["sha256"], frame_no
+        comb = torch.stack(maps).max(dim=0).values.contiguous()
+        order = torch.zeros(total, dtype=torch.int32, device="cuda")
+        abi.order_tiles_device(h, vp(comb), mw, mh, W, H, T, T, vp(order))
+    assert order.cpu().numpy().tolist() != list(range(total))
 
 
 @pytest.mark.parametrize("view", ["room_view_back", "room_view_floor"])
@@ -1144,8 +1172,8 @@ def test_texture_files_end_to_end(tmp_path, engine):
 
 def test_render_frame_multi_virtual_devices(scenes, engine):
     """mt_render_frame_multi (main_net_master.cc:195-236): N scene
-    replicas -- all on GPU 0 here, one per GPU in production -- render the tiles
-    k = r (mod N) of ONE frame side by side, the tile buffers are gathered on the
+    replicas -- all on GPU 0 here, one per GPU in production -- render their tiles
+    (dealt out by number at first, then by cost) of ONE frame side by side, the tile buffers are gathered on the
     first replica's device and blitted; the frame must be byte-identical to the
     single launch, every ray counted once."""
     abi = M.hip_abi()
@@ -1176,6 +1204,25 @@ def test_render_frame_multi_virtual_devices(scenes, engine):
             assert np.array_equal(got, want), frame
         r = abi.render_frame_multi(hs, sens, W, H, 256, 256, 5, want_stats=False)  # fewer tiles (2) than replicas
         assert np.array_equal(r["rgb"], single["rgb"])
+        # The cross-device branch on ONE device (a one-GPU box): every replica's tiles and cost map go through the gather
+        # buffer with hipMemcpyPeerAsync, as they would from another GPU -- its offsets and the blit from it, byte for
+        # byte.  (Peer ACCESS between two devices still has not run anywhere: include/mythtracer_hip.h says so.)
+        abi.set_tuning(hs[0], "MULTI_FORCE_PEER_COPY", 1.0)
+        cam = list(scenegen.ROOM_CAMERA)
+        for frame in range(5):  # at rest, at rest (lists kept), then turning
+            cam[4] += 0.0 if frame < 2 else 2.0
+            s_f = binding.sensor(cam, W, H)
+            want = abi.render_chunk(hs[3], s_f, W, H)["rgb"]
+            got = abi.render_frame_multi(hs[:3], s_f, W, H, 32, 32, 5, want_stats=False)["rgb"]
+            assert np.array_equal(got, want), ("peer copies", frame)
+        abi.set_tuning(hs[0], "MULTI_FORCE_PEER_COPY", 0.0)
+        abi.set_tuning(hs[0], "MULTI_BALANCE", 0.0)  # tiles by number, every frame
+        for frame in range(3):
+            cam[4] += 2.0
+            s_f = binding.sensor(cam, W, H)
+            want = abi.render_chunk(hs[3], s_f, W, H)["rgb"]
+            assert np.array_equal(abi.render_frame_multi(hs[:3], s_f, W, H, 64, 64, 5, want_stats=False)["rgb"], want), ("by number", frame)
+        abi.set_tuning(hs[0], "MULTI_BALANCE", 1.0)
         with pytest.raises(RuntimeError):
             abi.render_frame_multi([hs[0], hs[0]], sens, W, H)
     finally:
@@ -1247,6 +1294,105 @@ def test_cost_map_exchange_between_ranks(scenes, engine):
             cam[4] += 2.0
         with pytest.raises(RuntimeError):
             abi.export_costs_device(hs[0], ctypes.c_void_p(comb.data_ptr()), 3, 3)
+    finally:
+        for hh in hs:
+            abi.scene_destroy(hh)
+
+
+def test_cost_balanced_tile_ownership(scenes, engine):
+    """Tiles dealt out by cost (mt_order_tiles_device / mt_deal_tiles_device / mt_render_tile_list_device /
+    mt_blit_tile_list_device; the static counterpart of the master's pull queue, main_net_master.cc:62-80): three
+    virtual ranks on one GPU, a scene each.  Frame 0 by tile number, from then on by the combined cost map of the
+    previous frame -- camera at rest twice (the second time the lists are kept, list_id unchanged: per-slot history),
+    then turning (new lists every frame, forecast from the imported map by image position), then at rest again.  The
+    device's order and lists equal their numpy restatement (mythtracer_amd/tiling.py), every tile has exactly one
+    owner, the summed costs per rank lie closer together than with k mod N, and every frame equals the oracle's."""
+    import torch
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["mini"])
+    flat = m.flatten()
+    o = orclib.OracleScene(scenes["mini"])
+    o.set_lights(scenegen.ROOM_LIGHTS)
+    W, H, T, world = 264, 150, 16, 3  # ragged edge tiles (264 = 16.5 tiles, 150 = 9.4)
+    mw, mh = (W + 7) // 8, (H + 7) // 8
+    tx, ty = tiling.tile_grid(W, H, T, T)
+    total = tx * ty
+    hs = [abi.scene_create(flat) for _ in range(world)]
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    try:
+        for hh in hs:
+            abi.set_lights(hh, scenegen.ROOM_LIGHTS)
+        comb, lists, list_id = None, None, 0
+        cam = list(scenegen.ROOM_CAMERA)
+        plan = ["number", "deal", "keep", "deal", "deal", "deal", "keep"]
+        turn = [0.0, 0.0, 0.0, 2.0, 2.0, 2.0, 0.0]
+        worst = []
+        for frame_no, (what, dyaw) in enumerate(zip(plan, turn)):
+            cam[4] += dyaw
+            sens = binding.sensor(cam, W, H)
+            if what != "keep":
+                list_id += 1
+                order_d = None
+                if what == "deal":
+                    order_d = torch.zeros(total, dtype=torch.int32, device="cuda")
+                    abi.order_tiles_device(hs[0], vp(comb), mw, mh, W, H, T, T, vp(order_d))
+                    want_order = tiling.order_tiles(comb.cpu().numpy().astype(np.uint32), W, H, T, T)
+                    assert np.array_equal(order_d.cpu().numpy(), want_order), frame_no
+                lists = []
+                for r in range(world):
+                    lst = torch.full((total,), -7, dtype=torch.int32, device="cuda")
+                    n = abi.deal_tiles_device(hs[r], vp(order_d) if order_d is not None else None, W, H, T, T, world, r, vp(lst))
+                    assert n == abi.dealt_tile_count(W, H, T, T, world, r) == tiling.dealt_tile_count(total, world, r)
+                    got = lst.cpu().numpy()
+                    assert (got[n:] == -7).all()
+                    assert np.array_equal(got[:n], tiling.deal_tiles(None if order_d is None else want_order, total, world, r))
+                    lists.append(lst[:n].contiguous())
+                assert sorted(torch.cat(lists).cpu().numpy().tolist()) == list(range(total))
+                if what == "deal":  # balance by the map the deal was made from
+                    tc = np.array([comb.cpu().numpy()[y // 8:(y + ch + 7) // 8, x // 8:(x + cw + 7) // 8].astype(np.int64).sum()
+                                   for (x, y, cw, ch) in (tiling.tile_rect(t, W, H, T, T) for t in range(total))])
+                    dealt = np.array([tc[l.cpu().numpy()].sum() for l in lists], dtype=np.float64)
+                    modular = np.array([tc[r::world].sum() for r in range(world)], dtype=np.float64)
+                    worst.append((dealt.max() / dealt.mean(), modular.max() / modular.mean()))
+            frame = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
+            maps = []
+            for r in range(world):
+                n = int(lists[r].numel())
+                slots = torch.zeros(n * tiling.slot_bytes(T, T), dtype=torch.uint8, device="cuda")
+                if comb is not None:
+                    abi.import_costs_device(hs[r], vp(comb), mw, mh)
+                abi.render_tile_list_device(hs[r], sens, W, H, T, T, vp(lists[r]), n, list_id, 5, vp(slots))
+                lists[r] += 0  # (the call copied the list: the caller's buffer may be reused at once)
+                abi.blit_tile_list_device(hs[r], W, H, T, T, vp(lists[r]), n, vp(slots), vp(frame))
+                cm = torch.zeros((mh, mw), dtype=torch.int32, device="cuda")
+                abi.export_costs_device(hs[r], vp(cm), mw, mh)
+                torch.cuda.synchronize()
+                abi.read_stats(hs[r])
+                own = np.zeros((mh, mw), dtype=bool)
+                for t in lists[r].cpu().numpy():
+                    x, y, cw, ch = tiling.tile_rect(int(t), W, H, T, T)
+                    own[y // 8:(y + ch + 7) // 8, x // 8:(x + cw + 7) // 8] = True
+                assert np.array_equal(cm.cpu().numpy() != 0, own), (frame_no, r)
+                maps.append(cm)
+            comb = torch.stack(maps).max(dim=0).values.contiguous()
+            assert (comb.cpu().numpy() != 0).all()
+            want = o.render(cam, W, H)["rgb"]
+            assert_rgb_close(frame.cpu().numpy(), want, "%s frame %d (%s)" % (engine, frame_no, what))
+            assert np.array_equal(frame.cpu().numpy(), want)
+        print("max / mean of the ranks' summed tile costs, dealt vs k mod N:", ["%.3f vs %.3f" % w for w in worst])
+        assert np.mean([w[0] for w in worst]) < np.mean([w[1] for w in worst])
+        # argument checks of the new entry points
+        with pytest.raises(RuntimeError):
+            abi.order_tiles_device(hs[0], vp(comb), 3, 3, W, H, T, T, vp(order_d))
+        with pytest.raises(RuntimeError):
+            abi.dealt_tile_count(W, H, T, T, 3, 3)
+        with pytest.raises(RuntimeError):
+            abi.render_tile_list_device(hs[0], sens, W, H, T, T, vp(lists[0]), total + 1, 0, 5, vp(slots))
+        # the tuning knobs refuse values the kernels would divide by or overflow on (mt_scene_set_tuning)
+        for knob, bad in (("QUAD_SHARE", 0.0), ("HYBRID_WORK1", 0.0), ("POOL_PIECE_WORK1", -1.0), ("POOL_SCRATCH_MB", float("inf")),
+                          ("BLEND", 1.5), ("HYBRID_POOL_SHARE", float("nan"))):
+            with pytest.raises(RuntimeError):
+                abi.set_tuning(hs[0], knob, bad)
     finally:
         for hh in hs:
             abi.scene_destroy(hh)
