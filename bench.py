@@ -21,11 +21,16 @@ MAX_RECURSION_LEVEL = 5):
   N = 1   BASELINE configs[2]: 1920x1080, one launch for the whole frame.
   N > 1   BASELINE configs[4]: 3840x2160, STRONG scaling: every rank holds a
           scene replica (as every worker does in the reference,
-          main_net_worker.cc:29-32), renders the 64x64 tiles k = rank (mod N) of
-          the ONE frame, and the tile buffers are gathered to rank 0 over RCCL
-          and blitted into the frame (main_net_master.cc:223-236) -- the
-          reference's only exchange step.  `--scaling weak` grows the frame with
-          N instead (16k x 9k pixels, k = round(120 sqrt(N))).
+          main_net_worker.cc:29-32), renders ITS 64x64 tiles of the ONE frame, and
+          the tile buffers are gathered to rank 0 over RCCL and blitted into the
+          frame (main_net_master.cc:223-236) -- the reference's only exchange
+          step.  Which tiles: dealt out by cost (--ownership dealt, the default:
+          every rank orders the tiles by the all-reduced cost map of the previous
+          frame and takes its deal -- the static counterpart of the master's pull
+          queue, main_net_master.cc:62-80; include/mythtracer_hip.h,
+          mt_order_tiles_device) or k = rank (mod N) (--ownership modular).
+          `--scaling weak` grows the frame with N instead (16k x 9k pixels,
+          k = round(120 sqrt(N))).
   --width/--height/--max-depth/--scene select the other BASELINE configurations.
 
 Regime of the timed steps (--regime):
@@ -140,6 +145,8 @@ def main():
     ap.add_argument("--max-depth", type=int, default=5)
     ap.add_argument("--scene", default="room")
     ap.add_argument("--tile", type=int, default=64)
+    ap.add_argument("--ownership", choices=("dealt", "modular"), default="dealt",
+                    help="N > 1: tiles dealt out by the previous frame's costs (default) or k = rank (mod N)")
     ap.add_argument("--engine", type=int, default=0, help="0 automatic (default), 1 state machine, 2 ray pool, 3 hybrid")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", choices=("full", "band"), default="full",
@@ -234,6 +241,18 @@ def main():
     first, stride, n_mine = tiling.rank_tiles(W, H, tw, th, rank, world)
     n_max = tiling.max_tiles_per_rank(W, H, tw, th, world)   # equal slot counts on every rank
     frame = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    dealt = world > 1 and args.ownership == "dealt" and tw % 8 == 0 and th % 8 == 0
+    vp = lambda t: ctypes.c_void_p(t.data_ptr())
+    if dealt:
+        # cost-balanced ownership: the order of the tiles (a function of the all-reduced cost map: the same on every
+        # rank), this rank's list, and on rank 0 every rank's list for the blit
+        n_tiles_total = tiling.tile_grid(W, H, tw, th)[0] * tiling.tile_grid(W, H, tw, th)[1]
+        n_of = [abi.dealt_tile_count(W, H, tw, th, world, r) for r in range(world)]
+        n_mine = n_of[rank]
+        order = torch.zeros(n_tiles_total, dtype=torch.int32, device=dev)
+        lists = [torch.zeros(max(n_of[r], 1), dtype=torch.int32, device=dev) for r in (range(world) if rank == 0 else [rank])]
+        my_list = lists[rank] if rank == 0 else lists[0]
+        deal_state = {"have_map": False, "list_id": 0, "last_sensor": None, "at_rest": 0}
     if world > 1:
         mine = torch.zeros(n_max * tiling.slot_bytes(tw, th), dtype=torch.uint8, device=dev)
         gathered = ([torch.zeros_like(mine, device=xdev) for _ in range(world)] if rank == 0 else None)
@@ -241,7 +260,7 @@ def main():
         # camera's next frame is ordered by them (include/mythtracer_hip.h, mt_scene_export_costs_device)
         map_w, map_h = (W + 7) // 8, (H + 7) // 8
         cost_map = torch.zeros((map_h, map_w), dtype=torch.int32, device=dev)
-        exchange_costs = args.regime == "moving" and tw % 8 == 0 and th % 8 == 0
+        exchange_costs = (args.regime == "moving" or dealt) and tw % 8 == 0 and th % 8 == 0
 
     def E():
         return torch.cuda.Event(enable_timing=True)
@@ -254,6 +273,20 @@ def main():
         if world == 1:
             abi.render_chunk_device(h, s12, W, H, (0, 0, W, H), args.max_depth,
                                     ctypes.c_void_p(out.data_ptr()), None, stream)
+        elif dealt:
+            # new lists whenever the camera moved (and for the first two frames of a camera at rest: by number, then by
+            # the first measured costs); a camera at rest keeps its lists -- and with them the per-slot cost history
+            st = deal_state
+            key = bytes(np.asarray(s12, dtype=np.float64).tobytes())
+            st["at_rest"] = st["at_rest"] + 1 if st["last_sensor"] == key else 0
+            st["last_sensor"] = key
+            if st["list_id"] == 0 or st["at_rest"] < 2:
+                st["list_id"] += 1
+                if st["have_map"]:
+                    abi.order_tiles_device(h, vp(cost_map), map_w, map_h, W, H, tw, th, vp(order), stream)
+                for k, r in enumerate(range(world) if rank == 0 else [rank]):
+                    abi.deal_tiles_device(h, vp(order) if st["have_map"] else None, W, H, tw, th, world, r, vp(lists[k]), stream)
+            abi.render_tile_list_device(h, s12, W, H, tw, th, vp(my_list), n_mine, st["list_id"], args.max_depth, vp(mine), stream)
         else:
             abi.render_tiles_device(h, s12, W, H, tw, th, first, stride, n_mine, args.max_depth,
                                     ctypes.c_void_p(mine.data_ptr()), stream)
@@ -266,7 +299,16 @@ def main():
                                       ctypes.c_void_p(out.data_ptr()), stream)
                 if emulate:
                     torch.cuda.synchronize()  # `slots` is a temporary here
-            multi.gather_and_blit(dist, mine.to(xdev), gathered, rank, world, W, H, tw, th, blit)
+
+            def blit_list(slots, r):
+                slots = slots.to(dev)
+                abi.blit_tile_list_device(h, W, H, tw, th, vp(lists[r]), n_of[r], vp(slots), vp(out), stream)
+                if emulate:
+                    torch.cuda.synchronize()
+            if dealt:
+                multi.gather_and_blit_lists(dist, mine.to(xdev), gathered, rank, world, lambda r: r, blit_list)
+            else:
+                multi.gather_and_blit(dist, mine.to(xdev), gathered, rank, world, W, H, tw, th, blit)
             if exchange_costs:
                 # second exchange step: every rank's costs into one map (element-wise MAX: a block belongs to one rank)
                 cost_map.zero_()
@@ -278,6 +320,8 @@ def main():
                 else:
                     dist.all_reduce(cost_map, op=dist.ReduceOp.MAX)
                 abi.import_costs_device(h, ctypes.c_void_p(cost_map.data_ptr()), map_w, map_h, stream)
+                if dealt:
+                    deal_state["have_map"] = True
         if i is not None:
             ev[i][2].record()
 
@@ -336,7 +380,7 @@ def main():
     last_counters = None
     orc = None
     crops_ok, crops_n = True, 0
-    n_checks = 0 if (args.no_extras or world > 1 or rank != 0 or args.regime != "moving") else min(args.crop_checks, K)
+    n_checks = 0 if (args.no_extras or rank != 0 or args.regime != "moving") else min(args.crop_checks, K)
     check_at = set(int(round(j * (K - 1) / max(n_checks - 1, 1))) for j in range(n_checks))
     if n_checks:
         sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -468,7 +512,9 @@ def main():
                                       " = BASELINE configs[2]" if (W, H, args.max_depth, world) == (1920, 1080, 5, 1)
                                       else (" = BASELINE configs[4]" if (W, H, args.max_depth) == (3840, 2160, 5) and world > 1
                                             else "")),
-                       "tile": "%dx%d tiles interleaved over %d ranks, gathered to rank 0 (%s) and blitted" % (tw, th, world, backend)
+                       "tile": ("%dx%d tiles, %s, over %d ranks, gathered to rank 0 (%s) and blitted" % (
+                                    tw, th, "dealt out by the all-reduced cost map of the previous frame (most expensive first, rounds of "
+                                    "alternating direction)" if dealt else "tile k to rank k mod N", world, backend))
                                if world > 1 else "whole frame per launch, 8x8-pixel work items",
                        "regime": ("moving camera: yaw changes by 2 degrees per step as in the reference's loop (main_local.cc:51-76), "
                                   "panning within +-8 degrees of the golden camera; every step is a NEW frame scheduled from the "
@@ -510,6 +556,25 @@ def main():
             a, b = abi.kernel_times(h)
             return float(a[-1] + b[-1])
 
+        # (0) what the DROP-IN CALLER waits for: the frame loop of main_local.cc:51-132 through the facade -- lights pushed
+        # again, a Camera, RayTrace(W, H, &cam, &bitmap) into one vector, per frame -- wall-clocked around each RayTrace
+        # call: light upload (skipped when unchanged), work order, frame kernel, the copy of the frame into the caller's
+        # vector (through page-locked staging, in pieces under each other's DMA), the device status.  Same panning regime, the
+        # last frame is the golden camera's and is compared with the reference's.
+        try:
+            mt.frame_loop(cam, W, H, 20, 2.0 if args.regime == "moving" else 0.0)   # warm-up: registration, first frames
+            e2e_ms, e2e_rgb = mt.frame_loop(cam, W, H, 32, 2.0 if args.regime == "moving" else 0.0)
+            ka, kb = abi.kernel_times(h, 32)
+            _, p_e2e, bad = verdict(torch.from_numpy(e2e_rgb))
+            mismatch = mismatch or bad
+            out["frame_ms_end_to_end"] = float(e2e_ms.mean())
+            extras["end_to_end"] = {"frames": int(len(e2e_ms)), "ms_mean": float(e2e_ms.mean()), "ms_min": float(e2e_ms.min()),
+                                    "ms_max": float(e2e_ms.max()), "kernels_ms_mean": float((ka + kb).mean()),
+                                    "beyond_the_kernels_ms": float(e2e_ms.mean() - (ka + kb).mean()), "parity": p_e2e,
+                                    "what": "MythTracer::RayTrace(W, H, &cam, &bitmap) per frame as main_local.cc calls it "
+                                            "(host_capi.cc mth_frame_loop): lights, sensor, launch, D2H into the caller's vector, sync"}
+        except Exception as e:  # the bench line must still come out
+            extras["end_to_end"] = {"error": repr(e)}
         # (1) cold frame: no cost history (first frame of a geometry); counter-free kernels like the timed
         # steps; the frame it wrote is compared with the golden too
         abi.set_stats(h, False)
@@ -526,6 +591,8 @@ def main():
                                      "ms_first_after_cold": same[0], "parity": p_same,
                                      "Mray_s": sum(last_counters[k] for k in RAY_KEYS) / (sum(same[-16:]) / 16.0 * 1e-3) / 1e6}
         extras["work_counters"] = "off for cold_frame_ms and warm_same_frame, as in the timed steps"
+        # (rounds 1-2 reported this regime as `value`: kept at top level so that the rounds stay comparable)
+        out["value_warm"] = extras["warm_same_frame"]["Mray_s"]
         # (3) the same frame with the counters ON must be the same bytes (the kernels differ only in the counting)
         abi.set_stats(h, True)
         abi.read_stats(h)
@@ -558,6 +625,9 @@ def main():
             try:
                 out["cpu_baseline"] = cpu_baseline(info["obj"], cam, lights, W, H, chunk, args.max_depth, rc)
                 out["cpu_baseline"]["gpu_same_sample_Mray_s"] = rc / (g["stats"]["kernel_ms"] * 1e-3) / 1e6
+                out["cpu_baseline"]["gpu_same_sample_note"] = ("one mt_render_chunk call (host buffers) of the golden camera's frame WITH the work "
+                                                              "counters on (that is where the ray count comes from): kernels about a tenth slower "
+                                                              "than the timed, counter-free ones -- not comparable with `value`")
             except Exception as e:  # the bench line must still come out
                 out["cpu_baseline"] = {"error": repr(e)}
     if rank == 0:

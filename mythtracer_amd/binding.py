@@ -420,6 +420,7 @@ def host_lib():
     L.mth_sensor_ray.restype = None
     L.mth_render_chunk.argtypes = [vp, vp] + [ci] * 6 + [vp] * 5
     L.mth_render_image.argtypes = [vp, vp, ci, ci, vp]
+    L.mth_frame_loop.argtypes = [vp, vp, ci, ci, ci, cd, ci, vp, vp]
     L.mth_intersect.argtypes = [vp, ci, vp, vp, vp, vp, vp]
     L.mth_chunk_serialize_input.argtypes = [vp, vp]
     L.mth_chunk_deserialize_input.argtypes = [vp, ci, vp]
@@ -607,6 +608,18 @@ class MythTracer:
         if not self.L.mth_render_image(self.h, _ptr(cam), image_w, image_h, _ptr(rgb)):
             raise RuntimeError("RayTrace failed: " + self.last_error())
         return rgb
+
+    def frame_loop(self, cam, image_w, image_h, n_frames, dyaw=2.0, collect_stats=False):
+        """The frame loop of main_local.cc:51-132 through the facade (host_capi.cc mth_frame_loop): lights pushed again
+        every frame, a Camera per frame, RayTrace(W, H, &cam, &bitmap) into ONE vector.  Returns (wall ms per frame,
+        the last frame)."""
+        rgb = np.zeros((image_h, image_w, 3), dtype=np.uint8)
+        ms = np.zeros(n_frames, dtype=np.float64)
+        cam = _f64(cam)
+        if not self.L.mth_frame_loop(self.h, _ptr(cam), image_w, image_h, n_frames, float(dyaw),
+                                     1 if collect_stats else 0, _ptr(ms), _ptr(rgb)):
+            raise RuntimeError("RayTrace failed: " + self.last_error())
+        return ms, rgb
 
     def intersect(self, rays):
         rays = _f64(rays).reshape(-1, 6)

@@ -174,6 +174,13 @@ struct mt_scene {
   unsigned int *d_multi_maps = nullptr;   // first replica: all replicas' maps
   size_t multi_maps_bytes = 0;
   hipEvent_t multi_comb_done = nullptr;
+  // mt_render_chunk (host buffers): page-locked staging for the frame on its way to the caller's buffer (copied in
+  // pieces, each piece's host copy under the next piece's DMA), pinned words for the counters
+  uint8_t *h_stage = nullptr;
+  size_t stage_bytes = 0;
+  static constexpr int kStagePieces = 16;
+  hipEvent_t ev_stage[kStagePieces] = {};
+  unsigned long long *h_counters = nullptr;
   // tile-list launches (mt_render_tile_list_device): the launch's own copy of the list, and tile -> slot
   int32_t *d_tile_list = nullptr;
   size_t tile_list_bytes = 0;
@@ -698,6 +705,11 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_rgb) (void)hipFree(s->d_rgb);
   if (s->d_debug) (void)hipFree(s->d_debug);
   if (s->d_lights) (void)hipFree(s->d_lights);
+  if (s->h_stage) (void)hipHostFree(s->h_stage);
+  for (hipEvent_t e : s->ev_stage) {
+    if (e) (void)hipEventDestroy(e);
+  }
+  if (s->h_counters) (void)hipHostFree(s->h_counters);
   if (s->d_tile_list) (void)hipFree(s->d_tile_list);
   if (s->d_tile_slot) (void)hipFree(s->d_tile_slot);
   if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
@@ -1191,9 +1203,12 @@ int mt_scene_set_lights(mt_scene *s, const mt_light *lights, int n) {
     HIP_TRY(hipMalloc((void **)&s->d_lights, (size_t)cap * sizeof(mt_light)));
     s->lights_cap = cap;
   }
-  if (n) HIP_TRY(hipMemcpy(s->d_lights, lights, (size_t)n * sizeof(mt_light), hipMemcpyHostToDevice));
-  // other lights, other costs: the damped forecast starts over (the old costs remain its first guess)
-  if ((size_t)n != s->lights_host.size() || (n && memcmp(s->lights_host.data(), lights, (size_t)n * sizeof(mt_light)) != 0)) {
+  // The reference's drivers push the same lights again before every frame (main_local.cc:79-110): what the device
+  // holds already is not uploaded again.  Other lights, other costs: the damped forecast starts over (the old costs
+  // remain its first guess).
+  if ((size_t)n != s->lights_host.size() || s->dev.lights != s->d_lights ||
+      (n && memcmp(s->lights_host.data(), lights, (size_t)n * sizeof(mt_light)) != 0)) {
+    if (n) HIP_TRY(hipMemcpy(s->d_lights, lights, (size_t)n * sizeof(mt_light), hipMemcpyHostToDevice));
     s->lights_host.assign(lights, lights + n);
     s->forecasts_in_a_row = 0;
   }
@@ -1518,29 +1533,75 @@ int mt_render_chunk(mt_scene *s, const mt_sensor *sensor, int image_w, int image
       return rc;
     }
   }
-  HIP_TRY(hipMemset(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long)));
-  HIP_TRY(hipEventRecord(s->ev0, nullptr));
+  if (!s->h_counters) HIP_TRY(hipHostMalloc((void **)&s->h_counters, ST_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
+  // How the frame reaches the caller's (pageable) buffer, measured on the box (scripts/ubench/d2h_paths.hip, 6.2 MB of
+  // a 1080p frame / 24.9 MB of a 4K one): plain hipMemcpy 1.17 / 1.22 ms; a page-locked staging buffer + memcpy 0.42 /
+  // 1.72 (the memcpy alone 0.30 / 1.28); registering the caller's buffer per call 0.82 / 1.22 (the registration 0.7);
+  // a copy into memory that IS registered 0.12 / 0.45 -- but keeping a caller's buffer registered across calls is not
+  // safe (a vector freed and allocated again at the same address would receive its frame in the OLD pages).  So: the
+  // staging buffer, in pieces, every piece's memcpy under the next piece's DMA: about the memcpy's time.
+  const size_t out_bytes = npx * 3;
+  if (s->stage_bytes < out_bytes) {
+    if (s->h_stage) HIP_TRY(hipHostFree(s->h_stage));
+    s->h_stage = nullptr;
+    s->stage_bytes = 0;
+    HIP_TRY(hipHostMalloc((void **)&s->h_stage, out_bytes, hipHostMallocDefault));
+    s->stage_bytes = out_bytes;
+  }
+  for (hipEvent_t &e : s->ev_stage) {
+    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  hipStream_t stream = nullptr;
+  HIP_TRY(hipMemsetAsync(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long), stream));
+  HIP_TRY(hipEventRecord(s->ev0, stream));
   const bool counters_were = s->stats_enabled;
   if (stats) s->stats_enabled = true;  // the caller asked for them
   rc = mt_render_chunk_device(s, sensor, image_w, image_h, chunk_x, chunk_y, chunk_w, chunk_h,
-                              max_depth, s->d_rgb, out_debug ? s->d_debug : nullptr, nullptr);
+                              max_depth, s->d_rgb, out_debug ? s->d_debug : nullptr, stream);
   s->stats_enabled = counters_were;
   if (rc != MT_OK) return rc;
-  HIP_TRY(hipEventRecord(s->ev1, nullptr));
-  HIP_TRY(hipMemcpy(out_rgb, s->d_rgb, npx * 3, hipMemcpyDeviceToHost));
-  if (out_debug) {
-    HIP_TRY(hipMemcpy(out_debug, s->d_debug, npx * sizeof(mt_debug_px), hipMemcpyDeviceToHost));
+  HIP_TRY(hipEventRecord(s->ev1, stream));
+  // everything that comes back is queued behind the kernels: the counters (device status), the frame in pieces
+  HIP_TRY(hipMemcpyAsync(s->h_counters, s->d_counters, ST_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipMemsetAsync(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long), stream));
+  const int n_pieces = out_bytes < (1u << 20) ? 1 : (out_bytes < (8u << 20) ? 4 : mt_scene::kStagePieces);
+  const size_t piece = ((out_bytes + n_pieces - 1) / n_pieces + 4095) & ~(size_t)4095;
+  for (int k = 0; k < n_pieces; k++) {
+    const size_t off = (size_t)k * piece;
+    if (off < out_bytes) {
+      HIP_TRY(hipMemcpyAsync(s->h_stage + off, s->d_rgb + off, std::min(piece, out_bytes - off), hipMemcpyDeviceToHost, stream));
+    }
+    HIP_TRY(hipEventRecord(s->ev_stage[k], stream));
   }
-  mt_stats local;
-  if ((rc = mt_scene_read_stats(s, &local)) != MT_OK) return rc;  // also checks the device status
+  if (out_debug) {
+    HIP_TRY(hipMemcpyAsync(out_debug, s->d_debug, npx * sizeof(mt_debug_px), hipMemcpyDeviceToHost, stream));
+  }
+  for (int k = 0; k < n_pieces; k++) {
+    const size_t off = (size_t)k * piece;
+    HIP_TRY(hipEventSynchronize(s->ev_stage[k]));
+    if (k == 0 && check_status(s->h_counters) != MT_OK) {  // (the counters came first: no frame of a failed launch)
+      (void)hipStreamSynchronize(stream);
+      return check_status(s->h_counters);
+    }
+    if (off < out_bytes) memcpy(out_rgb + off, s->h_stage + off, std::min(piece, out_bytes - off));
+  }
+  HIP_TRY(hipStreamSynchronize(stream));
+  if ((rc = check_status(s->h_counters)) != MT_OK) return rc;
   if (stats) {
-    *stats = local;
+    memset(stats, 0, sizeof *stats);
+    fill_stats(s->h_counters, stats);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     stats->kernel_ms = ms;
     stats->total_ms =
         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
   }
+#ifdef MT_PROF
+  {  // (the phase profile is printed by mt_scene_read_stats)
+    mt_stats dummy;
+    (void)mt_scene_read_stats(s, &dummy);
+  }
+#endif
   return MT_OK;
 }
 

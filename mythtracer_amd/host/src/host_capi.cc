@@ -3,6 +3,7 @@
 // behaviour of its own; every call forwards to the raytracer:: classes.
 #include <cstdint>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -296,6 +297,39 @@ int mth_render_image(void* p, const double* cam7, int iw, int ih, uint8_t* rgb) 
   std::vector<uint8_t> bmp;
   if (!h->mt.RayTrace(iw, ih, &cam, &bmp)) return 0;
   memcpy(rgb, bmp.data(), bmp.size());
+  return 1;
+}
+
+// The frame loop of main_local.cc:51-132 as a driver written against the facade runs it: per frame the lights are
+// cleared and pushed again (:79-110), a Camera is aggregate-initialised with the frame's yaw (:72-76, `dyaw` degrees
+// per frame, a triangular pan of +-4 steps around cam7's yaw that ends on it) and RayTrace(W, H, &cam, &bitmap)
+// fills ONE vector that lives outside the loop (:122).  ms[i] = wall time of frame i's RayTrace call including the
+// light upload and the copy of the frame into `bitmap` -- what the drop-in caller waits for; rgb = the last frame.
+int mth_frame_loop(void* p, const double* cam7, int iw, int ih, int n_frames, double dyaw, int collect_stats,
+                   double* ms, uint8_t* rgb) {
+  Handle* h = static_cast<Handle*>(p);
+  h->mt.SetCollectStats(collect_stats != 0);
+  const std::vector<raytracer::Light> lights = h->mt.GetScene()->lights;
+  std::vector<uint8_t> bitmap;
+  for (int i = 0; i < n_frames; i++) {
+    auto& L = h->mt.GetScene()->lights;
+    L.clear();
+    for (const raytracer::Light& l : lights) L.push_back(l);
+    const int j = ((n_frames - 1 - i) % 16 + 16) % 16;
+    const int tri = j <= 4 ? j : (j <= 12 ? 8 - j : j - 16);
+    double c[7];
+    memcpy(c, cam7, sizeof c);
+    c[4] += dyaw * tri;
+    Camera cam = MakeCamera(c);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!h->mt.RayTrace(iw, ih, &cam, &bitmap)) {
+      h->mt.SetCollectStats(true);
+      return 0;
+    }
+    ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  h->mt.SetCollectStats(true);
+  if (rgb && !bitmap.empty()) memcpy(rgb, bitmap.data(), bitmap.size());
   return 1;
 }
 

@@ -251,11 +251,15 @@ bool MythTracer::RayTrace(int image_width, int image_height, Camera* camera,
     if (!quiet_) printf("%.3fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return true;
   }
+  // (mythtracer.cc:258-278 wraps a full-frame WorkChunk and resizes the caller's vector.)  The chunk borrows the caller's
+  // vector: a frame loop that hands the same vector in again (main_local.cc:51-132) keeps its storage -- no 6 MB
+  // allocation with its page faults per frame.
   WorkChunk chunk{image_width, image_height, 0, 0, image_width, image_height, *camera, {}, {}};
+  chunk.output_bitmap.swap(*output_bitmap);
   chunk.output_bitmap.resize((size_t)image_width * image_height * 3);
-  if (!RayTrace(&chunk)) return false;
-  *output_bitmap = std::move(chunk.output_bitmap);
-  return true;
+  const bool ok = RayTrace(&chunk);
+  output_bitmap->swap(chunk.output_bitmap);
+  return ok;
 }
 
 bool MythTracer::RayTrace(WorkChunk* chunk) {
@@ -294,9 +298,12 @@ bool MythTracer::RayTrace(WorkChunk* chunk) {
     dbg.resize(npx);
   }
   mt_stats st;
+  memset(&st, 0, sizeof st);
+  (void)mt_scene_set_stats(dev_, collect_stats_ ? 1 : 0);
   if (mt_render_chunk(dev_, &ms, chunk->image_width, chunk->image_height, chunk->chunk_x,
                       chunk->chunk_y, chunk->chunk_width, chunk->chunk_height, max_level_,
-                      chunk->output_bitmap.data(), want_debug ? dbg.data() : nullptr, &st) != MT_OK) {
+                      chunk->output_bitmap.data(), want_debug ? dbg.data() : nullptr,
+                      collect_stats_ ? &st : nullptr) != MT_OK) {
     error_ = mt_last_error();
     fprintf(stderr, "error: render failed: %s\n", error_.c_str());
     return false;

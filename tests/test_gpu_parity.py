@@ -1548,5 +1548,5 @@ def test_bench_two_ranks_rehearsal():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_reported_by_backend"] == 2 and d["scaling"] == "strong"
-    assert d["parity"].startswith("even pixels identical to the 1920x1080 golden frame")
+    assert d["parity"].startswith("frame identical to the reference's")  # (the whole 3840x2160 frame: tests/golden/frames.json holds the reference's since round 4)
     assert d["exchange_ms_device"]["cost_map_bytes_all_reduced"] == 4 * ((3840 + 7) // 8) * ((2160 + 7) // 8)
