@@ -39,7 +39,7 @@ def scenes(tmp_path_factory):
     from mythtracer_amd import scenegen
     d = str(tmp_path_factory.mktemp("scenes"))
     want = json.load(open(os.path.join(GOLDEN, "scene_hashes.json")))
-    out = {"cornell": CORNELL}
+    out = {"cornell": CORNELL, "f2_decal": os.path.join(ROOT, "tests", "scenes", "f2_decal.obj")}
     for name in ("mini", "mini_nomtl", "room", "room_nomtl"):
         info = scenegen.write_scene(name, d)
         if name in want:

@@ -32,6 +32,11 @@ CORNELL_CAM = (50, 50, -120, 0, 0, 0, 60)
 CORNELL_LIGHTS = [(50, 90, 50, .3, .3, .3, 1, 1, 1, 1, 1, 1)]
 # second camera: inside the box, rolled and pitched, two lights
 CORNELL_CAM2 = (20, 70, 10, 25, 35, 10, 95)
+# a pane of glass with an opaque decal 5e-6 above it (tests/scenes/f2_decal.obj): the shadow loop crosses the
+# pane and restarts 1.01e-5 further on (mythtracer.cc:137, :95-99) -- BEYOND the decal, which it never sees
+F2_DECAL = os.path.join(ROOT, "tests", "scenes", "f2_decal.obj")
+F2_CAM = (50.0, 6.0, -30.0, 12.0, 0.0, 0.0, 70.0)
+F2_LIGHTS = [(50.0, 60.0, 50.0, .1, .1, .1, 1, 1, 1, 0, 0, 0)]
 CORNELL_LIGHTS2 = [(50, 90, 50, .2, .2, .2, .8, .8, .8, 1, 1, 1), (10, 20, 90, 0, 0, .1, .3, .3, .6, .2, .2, .2)]
 
 
@@ -270,6 +275,10 @@ def tree_and_wire_cases(td):
 
 def main():
     assert orclib.have_ref(), "build the reference first: make -C oracle ref"
+    if "--f2" in sys.argv:
+        with tempfile.TemporaryDirectory() as td:
+            render_case(td, "f2_decal_96x64", F2_DECAL, 96, 64, F2_CAM, F2_LIGHTS)
+        return
     if "--big4k" in sys.argv:
         with tempfile.TemporaryDirectory() as td:
             big4k_frame(td)
@@ -285,6 +294,7 @@ def main():
         render_case(td, "cornell_256", CORNELL, 256, 256, CORNELL_CAM, CORNELL_LIGHTS)
         render_case(td, "cornell_cam2_96x64", CORNELL, 96, 64, CORNELL_CAM2, CORNELL_LIGHTS2)
         render_case(td, "cornell_nolights_64", CORNELL, 64, 64, CORNELL_CAM, [])
+        render_case(td, "f2_decal_96x64", F2_DECAL, 96, 64, F2_CAM, F2_LIGHTS)
         render_case(td, "mini_320x180", mini["obj"], 320, 180, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS)
         render_case(td, "mini_nomtl_320x180", mini_n["obj"], 320, 180, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS)
         render_case(td, "mini_chunk_101x67", mini["obj"], 320, 180, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS,

@@ -83,7 +83,10 @@ RENDER_CASES = [("cornell_256", "cornell"), ("cornell_cam2_96x64", "cornell"),
                 ("mini_nomtl_320x180", "mini_nomtl"), ("mini_chunk_101x67", "mini"),
                 ("mini_1x1", "mini"), ("room_240x135", "room"),
                 ("room_view_back", "room"), ("room_view_floor", "room"), ("room_view_down", "room"),
-                ("room_view_axis", "room")]
+                ("room_view_axis", "room"),
+                # the shadow loop restarts BEYOND an opaque decal 5e-6 behind a pane of glass -- the frame the
+                # reference renders has no shadow there (tests/test_oracle_golden.py says why that rules the early-out out)
+                ("f2_decal_96x64", "f2_decal")]
 
 
 @pytest.mark.parametrize("case,scene", RENDER_CASES)

@@ -9,7 +9,7 @@ import pytest
 
 import orclib
 import quirk_files
-from conftest import GOLDEN, CORNELL
+from conftest import GOLDEN, CORNELL, ROOT
 
 RENDER_CASES = [("cornell_256", "cornell"), ("cornell_cam2_96x64", "cornell"),
                 ("cornell_nolights_64", "cornell"), ("mini_320x180", "mini"),
@@ -141,3 +141,59 @@ def test_live_reference_agrees(scenes, tmp_path):
     assert np.array_equal(r["rgb"], ref["rgb"])
     assert np.array_equal(r["line"], ref["line"])
     assert np.array_equal(r["point"], ref["point"], equal_nan=True)
+
+
+def test_shadow_loop_any_hit_early_out_is_not_the_reference(tmp_path):
+    """SURVEY 8f-2, closed with evidence.  The tempting acceleration of the shadow loop (mythtracer.cc:94-156) -- "any
+    opaque hit not farther than the light puts the point in shadow, stop there" -- is NOT the loop's outcome, and the
+    reference's own frame shows it: tests/scenes/f2_decal.obj has a pane of glass at y = 10 with an opaque decal
+    5e-6 above it.  The loop's first ray (from the floor towards the light) meets the pane first, takes its filter,
+    and RESTARTS 1e-7 + 1e-5 beyond the hit point (:137, :95-99) -- beyond the decal, which the restarted ray never
+    sees: the floor under the decal is lit through the glass.  The shortcut, evaluated here with the reference's own
+    Moeller-Trumbore arithmetic for every floor pixel of the reference-made golden, finds the decal within the light's
+    distance on the FIRST ray and would paint those pixels dark.  (The other reason the row stays exact is measured
+    by scripts/f2_bound.py: five shadow rays in six are lit -- no early-out applies to them -- and the provable form
+    of the early-out for the rest saves 0.2 % of their triangle tests.)"""
+    g = load("f2_decal_96x64")
+    obj = os.path.join(ROOT, "tests", "scenes", "f2_decal.obj")
+    o = orclib.OracleScene(obj)
+    lights = g["lights"].reshape(-1, 12)
+    o.set_lights(lights)
+    r = o.render(g["cam"], 96, 64, debug=True)
+    assert np.array_equal(r["rgb"], g["rgb"]) and np.array_equal(r["line"], g["line"])  # oracle == reference here too
+    floor_line = int(g["line"][g["line"] >= 0].min())
+    light = lights[0, :3]
+    decal = [np.array(v, dtype=np.float64) for v in ((40, 10.000005, 40), (60, 10.000005, 40), (60, 10.000005, 60), (40, 10.000005, 60))]
+    tris = [(decal[0], decal[1], decal[2]), (decal[2], decal[3], decal[0])]  # quad -> (0 1 2) (2 3 0), objreader.cc:141-151
+
+    def moller_trumbore(o_, d_, v0, v1, v2):  # primitive_triangle.cc:110-142
+        e1, e2 = v1 - v0, v2 - v0
+        pvec = np.cross(d_, e2)
+        det = e1 @ pvec
+        if -1e-8 <= det < 1e-8:
+            return None
+        inv = 1.0 / det
+        tvec = o_ - v0
+        u = (tvec @ pvec) * inv
+        if u < 0.0 or u > 1.0:
+            return None
+        qvec = np.cross(tvec, e1)
+        v = (d_ @ qvec) * inv
+        if v < 0.0 or u + v > 1.0:
+            return None
+        t = (e2 @ qvec) * inv
+        return None if t < 0.0 else t
+
+    would_be_dark, lit_in_reference = 0, 0
+    for y, x in zip(*np.nonzero(g["line"] == floor_line)):
+        P = g["point"][y, x]
+        L = (light - P) / np.sqrt(((light - P) ** 2).sum())
+        origin, ld = P + L * 0.00001, np.sqrt(((P - light) ** 2).sum())  # :96-102
+        hit = [moller_trumbore(origin, L, *t) for t in tris]
+        if any(t is not None and t <= ld for t in hit):  # "an opaque triangle within the light's distance"
+            would_be_dark += 1
+            # what the reference painted: well above the in-shadow value (ambient 0.1: 0.8 * 0.1 + 0.64 * 0.1 = 37 of 255)
+            if g["rgb"][y, x, 1] > 100:
+                lit_in_reference += 1
+    assert would_be_dark >= 20, would_be_dark
+    assert lit_in_reference == would_be_dark
