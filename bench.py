@@ -509,8 +509,8 @@ def main():
             "config": {"workload": "%s scene (%d triangles, synthetic stand-in for the living-room "
                                    ".obj), %dx%d, %d lights with shadow rays, max recursion %d%s"
                                    % (args.scene, info["triangles"], W, H, len(lights), args.max_depth,
-                                      " = BASELINE configs[2]" if (W, H, args.max_depth, world) == (1920, 1080, 5, 1)
-                                      else (" = BASELINE configs[4]" if (W, H, args.max_depth) == (3840, 2160, 5) and world > 1
+                                      " = BASELINE configs[2]" if (W, H, args.max_depth, world, args.scene) == (1920, 1080, 5, 1, "room")
+                                      else (" = BASELINE configs[4]" if (W, H, args.max_depth, args.scene) == (3840, 2160, 5, "room") and world > 1
                                             else "")),
                        "tile": ("%dx%d tiles, %s, over %d ranks, gathered to rank 0 (%s) and blitted" % (
                                     tw, th, "dealt out by the all-reduced cost map of the previous frame (most expensive first, rounds of "

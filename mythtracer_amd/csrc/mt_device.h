@@ -5,22 +5,11 @@
 #include <stdint.h>
 #include "mythtracer_hip.h"
 
-// The hit-set traversal (mt_trace.h) is the default for regular rays in the automatic
-// traversal mode; -DMT_NO_HS builds the library with the ordered per-lane descent only
-// (round 1's traversal, still used for irregular rays and the diagnostic modes 1-7).
-#if !defined(MT_NO_HS) && !defined(MT_HS)
-#define MT_HS 1
-#endif
-
-// Waves per SIMD the frame kernels are compiled for (register budget 512 / n per
-// lane: 3 -> 168 VGPRs).  Swept: 2 (256 VGPRs, no spills) and 4 (128) are both
-// slower than 3.
+// Waves per SIMD the frame kernels are compiled for (register budget 512 / n per lane: 2 -> 256 VGPRs, nothing of
+// the frame engines' context spilled).  The hit-set walk hides its latencies itself and wants the registers and the
+// LDS: 3 (168 VGPRs) measured 6 % slower in rounds 2 and 3, 4 (128) slower still.
 #ifndef MT_WAVES_PER_SIMD
-#ifdef MT_HS
-#define MT_WAVES_PER_SIMD 2  // the hit-set traversal hides its latencies itself and wants the registers and the LDS
-#else
-#define MT_WAVES_PER_SIMD 3
-#endif
+#define MT_WAVES_PER_SIMD 2
 #endif
 
 namespace mt {
@@ -61,7 +50,7 @@ constexpr int kSuperBlocks = MT_SUPER_BLOCKS;   // blocks per second-level box
 #endif
 constexpr int kSuperMin = MT_SUPER_MIN;  // lists that touch at least this many blocks are scanned through the second level
 
-// Everything the hit-set traversal (-DMT_HS, mt_trace.h) needs to know about a
+// Everything the hit-set traversal (mt_trace.h) needs to know about a
 // node before it looks at triangles, in one 256-byte record that a wave
 // stages in LDS with ONE load instruction (16 lanes x 16 bytes), one node ahead
 // of its use: the list, the children, the fp32 union box of every child's
@@ -253,34 +242,26 @@ __device__ __forceinline__ int slot_of_tile(const RenderParams &P, int t) {
   return j < P.n_tiles ? j : -1;
 }
 
-// Bytes of LDS one wave needs for its traversal stack: 20-byte frames, or 16-byte
-// ones when a node index and a triangle index fit one word together
-// (DevScene::pack_shift != 0), plus five per-lane work counters.  With -DMT_HS
-// (hit-set traversal, mt_trace.h) trees of up to kHsMaxDepth levels use 24-byte
-// frames for the levels that can hold a node with children, plus two
-// wave-uniform words per level; the old frames share the same bytes.
+// Bytes of LDS one wave needs for its traversal stack.  Ordered descent: 20-byte frames, or 16-byte ones when a node
+// index and a triangle index fit one word together (DevScene::pack_shift != 0).  Hit-set walk (mt_trace.h): trees of
+// up to kHsMaxDepth levels use 24-byte frames for the levels that can hold a node with children, plus two
+// wave-uniform words per level; the two traversals' frames share the same bytes.
 // levels of an octree the hit-set walk takes: its per-level child masks hold 16 levels; LDS -- 24-byte frames per lane
 // for all but the leaf level -- is 15 KB per wave at 9 levels (8 waves per CU) and 27 KB at 16 (4 waves per CU: the
 // launch configuration halves the waves per workgroup until the budget holds).  Deeper trees take the ordered descent.
 constexpr int kHsMaxDepth = 16;
 __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
   size_t n = (size_t)depth * 64 * (packed ? 16 : 20);
-#ifdef MT_HS
   if (depth <= kHsMaxDepth && depth > 1) {
     // frames, (node, first child) per level, room for two staged records (16-byte aligned), per level the nine
     // planes of the frame's node (80 bytes)
     size_t hs = (((size_t)(depth - 1) * (64 * 24 + 8) + 15) & ~(size_t)15) + 2 * sizeof(HsRec) + (size_t)(depth - 1) * 80;
     if (hs > n) n = hs;
   }
-#endif
   return n;
 }
 __host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
-#ifdef MT_HS
   size_t n = wave_frames_bytes(depth, packed) + 64 * 24;  // the fp32 boxes of a short list: (kHsShortList / 4) quads of 144 bytes = 1 152 (the counters are in registers)
-#else
-  size_t n = wave_frames_bytes(depth, packed) + 5 * 64 * 4;
-#endif
   return n;
 }
 

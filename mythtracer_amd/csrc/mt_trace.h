@@ -53,19 +53,11 @@
 namespace mt {
 
 #define MT_CONST __attribute__((address_space(4)))
-// Per-lane work counters of one traversal (STATS instantiations only).  Default:
-// in LDS behind the stack -- four ds_add per node step instead of live VGPRs.
-// -DMT_HS: in registers (the LDS behind the frames stages node records there;
-// the timed kernels are the ones without counters).
-#ifdef MT_HS
+// Per-lane work counters of one traversal (STATS instantiations only): in registers (the LDS behind the frames
+// stages node records; the timed kernels are the ones without counters).
 #define MT_CNT_ADD(i, v) (cntr[i] += (v))
 #define MT_CNT_SET(i, v) (cntr[i] = (v))
 #define MT_CNT_GET(i) (cntr[i])
-#else
-#define MT_CNT_ADD(i, v) __hip_atomic_fetch_add(&cnt[(i) * 64 + lane], (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT)
-#define MT_CNT_SET(i, v) (cnt[(i) * 64 + lane] = (v))
-#define MT_CNT_GET(i) (cnt[(i) * 64 + lane])
-#endif
 
 #ifndef MT_PACK_SMALL
 #define MT_PACK_SMALL 8  // at most this many lanes with exact scans: their small nodes packed over the wave (0: off; 16: a pass of 16 such rays 3.2 -> 4.2 M cycles)
@@ -1815,12 +1807,8 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
   MT_LDS int *const stk_fc = stk.fc();
   MT_LDS int *const stk_bp = stk.bp();
   MT_LDS unsigned *const stk_ord = stk.ord();
-  // per-lane work counters of this traversal live in LDS (behind the stack),
-  // not in registers: four ds_add per node step instead of four live VGPRs
   const unsigned frames_end = stk.base + (unsigned)wave_frames_bytes(stk.depth, stk.pack_shift != 0);
-  MT_LDS unsigned *const cnt = (MT_LDS unsigned *)(uintptr_t)frames_end;
-  (void)cnt;
-  unsigned cntr[5] = {0u, 0u, 0u, 0u, 0u};
+  unsigned cntr[5] = {0u, 0u, 0u, 0u, 0u};  // per-lane work counters of this traversal (STATS only)
   (void)cntr;
   const int pack_shift = stk.pack_shift;  // wave-uniform
   if (STATS) {
@@ -1971,7 +1959,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
 #ifdef MT_DIAG
   unsigned diag_a_trips = 0, diag_transposed = 0;
 #endif
-#ifdef MT_HS
   // ---- hit-set traversal (regular rays, automatic mode) ---------------------
   // What PrimitiveIntersectRay returns for a node is a function of three things
   // only (octtree.cc:169-257): the best hit of the node's own list; for every
@@ -2542,7 +2529,6 @@ __device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, 
     cur = -1;
   }
   if (!hs_done)
-#endif
   // Main loop of the ordered descent.  (A) every lane works through the small nodes on its path by itself.
   // (B) When all lanes wait at big nodes, the wave takes the LOWEST-NUMBERED one (breadth-first numbering: the top
   // of the tree first, so that lanes above catch up with lanes waiting deeper) and scans it for the lanes that wait

@@ -250,25 +250,53 @@ ROOM_LIGHTS = [
 ]
 
 
+def texture_ppm(kind: str, size: int = 128) -> bytes:
+    """A procedural RGB texture as a binary PPM (P6), integer arithmetic only: "planks" (floor boards with a grain),
+    "plaster" (a pale wall with speckles), "tiles" (two-tone checker with dark joints)."""
+    rnd = SplitMix64({"planks": 11, "plaster": 12, "tiles": 13}[kind])
+    px = bytearray()
+    for y in range(size):
+        for x in range(size):
+            n = rnd.next() & 31
+            if kind == "planks":
+                board = (x * 8) // size
+                joint = (x * 8) % size < 2 or (y + board * 37) % (size // 2) < 1
+                g = 150 + ((board * 53) % 40) + (((y * 7 + board * 13) % 23) - 11) + (n >> 2)
+                c = (40, 28, 20) if joint else (min(g + 40, 255), g, max(g - 60, 0))
+            elif kind == "plaster":
+                g = 215 + (n >> 1) - ((x ^ y) & 7)
+                c = (g, g, max(g - 12, 0))
+            else:
+                t = ((x * 4) // size + (y * 4) // size) & 1
+                joint = (x * 4) % size < 2 or (y * 4) % size < 2
+                c = (60, 60, 60) if joint else ((225, 215, 190) if t else (120, 140, 170))
+            px += bytes(c)
+    return b"P6\n%d %d\n255\n" % (size, size) + bytes(px)
+
+
 def room_text(name: str, wall_div: int, spheres, n_boxes: int, box_div: int,
-              with_materials: bool, seed: int = 2017):
+              with_materials: bool, seed: int = 2017, textured: bool = False, clusters=()):
     """Returns (obj_text, mtl_text|None, n_triangles).
 
-    spheres: list of (icosphere level, count)."""
+    spheres: list of (icosphere level, count).  textured: floor, ceiling and walls carry texture coordinates and
+    map_Ka materials (the textures are written by write_scene).  clusters: list of (count, icosphere level, smallest
+    radius, largest radius) -- tight groups of small spheres on a few shelves: the fine detail that makes the
+    reference's octree deep."""
     w = ObjWriter((name + ".mtl") if with_materials else None)
     W, H, D = 400.0, 250.0, 400.0
     rnd = SplitMix64(seed)
+    uv = textured
     # walls, normals facing inwards
     w.usemtl("floor")
-    add_grid(w, (0, 0, 0), (W, 0, 0), (0, 0, D), wall_div, wall_div, (0, 1, 0))
+    add_grid(w, (0, 0, 0), (W, 0, 0), (0, 0, D), wall_div, wall_div, (0, 1, 0), with_uv=uv)
     w.usemtl("white")
-    add_grid(w, (0, H, 0), (W, 0, 0), (0, 0, D), wall_div, wall_div, (0, -1, 0))
-    add_grid(w, (0, 0, D), (W, 0, 0), (0, H, 0), wall_div, wall_div, (0, 0, -1))
-    add_grid(w, (0, 0, 0), (W, 0, 0), (0, H, 0), wall_div, wall_div, (0, 0, 1))
+    add_grid(w, (0, H, 0), (W, 0, 0), (0, 0, D), wall_div, wall_div, (0, -1, 0), with_uv=uv)
+    add_grid(w, (0, 0, D), (W, 0, 0), (0, H, 0), wall_div, wall_div, (0, 0, -1), with_uv=uv)
+    add_grid(w, (0, 0, 0), (W, 0, 0), (0, H, 0), wall_div, wall_div, (0, 0, 1), with_uv=uv)
     w.usemtl("red")
-    add_grid(w, (0, 0, 0), (0, 0, D), (0, H, 0), wall_div, wall_div, (1, 0, 0))
+    add_grid(w, (0, 0, 0), (0, 0, D), (0, H, 0), wall_div, wall_div, (1, 0, 0), with_uv=uv)
     w.usemtl("green")
-    add_grid(w, (W, 0, 0), (0, 0, D), (0, H, 0), wall_div, wall_div, (-1, 0, 0))
+    add_grid(w, (W, 0, 0), (0, 0, D), (0, H, 0), wall_div, wall_div, (-1, 0, 0), with_uv=uv)
     # a mirror panel slightly in front of the back wall
     w.usemtl("mirror")
     add_grid(w, (120, 60, D - 2.0), (160, 0, 0), (0, 120, 0), 4, 4, (0, 0, -1))
@@ -292,7 +320,20 @@ def room_text(name: str, wall_div: int, spheres, n_boxes: int, box_div: int,
         z0 = rnd.rng(80.0, D - 10.0 - sz)
         w.usemtl(box_mtls[b % len(box_mtls)])
         add_box(w, (x0, 0.5, z0), (x0 + sx, 0.5 + sy, z0 + sz), box_div)
-    return w.text(), (ROOM_MTL if with_materials else None), w.ntris
+    # shelves of small things: every cluster sits in a box of 6 x 3 x 6 units somewhere in view
+    for c, (count, level, r_lo, r_hi) in enumerate(clusters):
+        bx = rnd.rng(60.0, W - 60.0)
+        by = rnd.rng(20.0, 140.0)
+        bz = rnd.rng(110.0, D - 60.0)
+        for i in range(count):
+            r = rnd.rng(r_lo, r_hi)
+            w.usemtl(sphere_mtls[(c + i) % len(sphere_mtls)])
+            add_sphere(w, (bx + rnd.rng(0.0, 6.0), by + rnd.rng(0.0, 3.0), bz + rnd.rng(0.0, 6.0)), r, level)
+    mtl = ROOM_MTL if with_materials else None
+    if mtl is not None and textured:
+        for mname, tex in (("floor", "planks"), ("white", "plaster"), ("green", "tiles")):
+            mtl = mtl.replace("newmtl %s\n" % mname, "newmtl %s\nmap_Ka %s_%s.ppm\n" % (mname, name, tex))
+    return w.text(), mtl, w.ntris
 
 
 # name -> generator arguments.  "room" is the BASELINE-sized scene.
@@ -301,6 +342,13 @@ SCENES = {
     "room_nomtl": dict(wall_div=40, spheres=[(3, 12), (4, 10)], n_boxes=20, box_div=8, with_materials=False),
     "mini":       dict(wall_div=6, spheres=[(1, 3), (2, 4)], n_boxes=3, box_div=2, with_materials=True),
     "mini_nomtl": dict(wall_div=6, spheres=[(1, 3), (2, 4)], n_boxes=3, box_div=2, with_materials=False),
+    # round 4, performance off the scene the kernels were tuned on (profiles/README.md):
+    # the same room with map_Ka textures on floor, ceiling and walls: Texture::GetColorAt on the timed path
+    "room_tex":   dict(wall_div=40, spheres=[(3, 12), (4, 10)], n_boxes=20, box_div=8, with_materials=True, textured=True),
+    # 770 720 triangles, an octree of 16 levels (153 977 nodes): bigger and finer objects, and shelves of small spheres
+    # (radius 0.03 .. 0.6) -- the deepest tree the hit-set walk takes (kHsMaxDepth)
+    "loft":       dict(wall_div=48, spheres=[(4, 14), (5, 12)], n_boxes=24, box_div=10, with_materials=True,
+                       clusters=[(60, 3, 0.04, 0.6), (60, 3, 0.04, 0.6), (40, 4, 0.1, 0.6), (30, 3, 0.03, 0.3)]),
 }
 
 
@@ -314,6 +362,10 @@ def write_scene(name: str, out_dir: str) -> dict:
     if mtl is not None:
         with open(os.path.join(out_dir, name + ".mtl"), "w", newline="\n") as f:
             f.write(mtl)
+        for tex in ("planks", "plaster", "tiles"):
+            if ("%s_%s.ppm" % (name, tex)) in mtl:
+                with open(os.path.join(out_dir, "%s_%s.ppm" % (name, tex)), "wb") as f:
+                    f.write(texture_ppm(tex))
     return {"obj": obj_path, "triangles": ntris,
             "sha256": hashlib.sha256(obj.encode()).hexdigest()}
 

@@ -275,6 +275,43 @@ def tree_and_wire_cases(td):
 
 def main():
     assert orclib.have_ref(), "build the reference first: make -C oracle ref"
+    if "--r4scenes" in sys.argv:
+        # round 4's two more scenes (profiles/README.md): "loft" by the compiled reference (small frame in full + the SHA-256
+        # of the 1920x1080 frame), "room_tex" by the ORACLE -- the reference build here has no texture.cc (SDL2), so a
+        # textured frame cannot come from it: Texture::GetColorAt stays "parity unpinned", as everywhere
+        with tempfile.TemporaryDirectory() as td:
+            scenes = os.path.join(td, "scenes")
+            loft = scenegen.write_scene("loft", scenes)
+            render_case(td, "loft_240x135", loft["obj"], 240, 135, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS)
+            tex = scenegen.write_scene("room_tex", scenes)
+            o = orclib.OracleScene(tex["obj"])
+            o.set_lights(scenegen.ROOM_LIGHTS)
+            r = o.render(scenegen.ROOM_CAMERA, 240, 135, debug=True)
+            np.savez_compressed(os.path.join(HERE, "room_tex_240x135.npz"), rgb=r["rgb"], line=r["line"], point=r["point"],
+                                cam=np.array(scenegen.ROOM_CAMERA), lights=np.array(scenegen.ROOM_LIGHTS),
+                                image=np.array([240, 135], dtype=np.int32), chunk=np.array([0, 0, 240, 135], dtype=np.int32))
+            print("room_tex_240x135 (oracle-made)", sha(r["rgb"]))
+            meta = json.load(open(os.path.join(HERE, "scene_hashes.json")))
+            meta["loft"], meta["room_tex"] = loft["sha256"], tex["sha256"]
+            json.dump(meta, open(os.path.join(HERE, "scene_hashes.json"), "w"), indent=1, sort_keys=True)
+            fpath = os.path.join(HERE, "frames.json")
+            frames = json.load(open(fpath))
+            if "--big" in sys.argv:
+                W, H = 1920, 1080
+                rr = orclib.run_ref(os.path.join(td, "loft_big"), loft["obj"], (W, H), cam=scenegen.ROOM_CAMERA,
+                                    lights=scenegen.ROOM_LIGHTS, want_debug=True)
+                assert rr["returncode"] == 0, rr["stderr"]
+                frames["loft_1920x1080_d5"] = {"sha256": sha(rr["rgb"]), "line_sha256": sha(rr["line"].astype("<i4")),
+                                               "seconds_reference_here": rr["time"]["seconds"], "threads": rr["time"]["threads"],
+                                               "scene_sha256": loft["sha256"]}
+                print("loft_1920x1080_d5", frames["loft_1920x1080_d5"])
+                ro = o.render(scenegen.ROOM_CAMERA, W, H, debug=True)
+                frames["room_tex_1920x1080_d5"] = {"sha256": sha(ro["rgb"]), "line_sha256": sha(ro["line"].astype("<i4")),
+                                                   "scene_sha256": tex["sha256"],
+                                                   "made_by": "oracle (Texture::GetColorAt has no buildable reference here: parity unpinned)"}
+                print("room_tex_1920x1080_d5", frames["room_tex_1920x1080_d5"])
+            json.dump(frames, open(fpath, "w"), indent=1, sort_keys=True)
+        return
     if "--f2" in sys.argv:
         with tempfile.TemporaryDirectory() as td:
             render_case(td, "f2_decal_96x64", F2_DECAL, 96, 64, F2_CAM, F2_LIGHTS)

@@ -86,7 +86,10 @@ RENDER_CASES = [("cornell_256", "cornell"), ("cornell_cam2_96x64", "cornell"),
                 ("room_view_axis", "room"),
                 # the shadow loop restarts BEYOND an opaque decal 5e-6 behind a pane of glass -- the frame the
                 # reference renders has no shadow there (tests/test_oracle_golden.py says why that rules the early-out out)
-                ("f2_decal_96x64", "f2_decal")]
+                ("f2_decal_96x64", "f2_decal"),
+                # round 4's two more scenes (profiles/README.md): 770 720 triangles in an octree of 16 levels, made by the
+                # reference; the room with map_Ka textures, made by the ORACLE (Texture::GetColorAt: parity unpinned)
+                ("loft_240x135", "loft"), ("room_tex_240x135", "room_tex")]
 
 
 @pytest.mark.parametrize("case,scene", RENDER_CASES)
@@ -640,21 +643,9 @@ def test_big_frames_identical_to_reference(scenes):
         assert np.array_equal(g["point"][::16, ::16], sub["point"], equal_nan=True)
         assert_rgb_close(g["rgb"][::16, ::16], sub["rgb"], key)
         assert hashlib.sha256(g["line"].astype("<i4").tobytes()).hexdigest() == frames[key]["line_sha256"]
-        sha = hashlib.sha256(g["rgb"].tobytes()).hexdigest()
-        print(key, "frame sha256", sha, "reference", frames[key]["sha256"], "kernel ms", g["kernel_ms"])
-        n_diff = 0
-        if sha != frames[key]["sha256"]:
-            # Not the reference's bytes: count the differing pixels against the
-            # oracle (bit-identical to the reference on this frame, see
-            # test_oracle_golden.py) and hold them to the pow tolerance.
-            o = orclib.OracleScene(scenes[scene])
-            o.set_lights(scenegen.ROOM_LIGHTS)
-            want = o.render(scenegen.ROOM_CAMERA, W, H)["rgb"]
-            assert hashlib.sha256(want.tobytes()).hexdigest() == frames[key]["sha256"]
-            n_diff = int((g["rgb"] != want).any(axis=-1).sum())
-            assert_rgb_close(g["rgb"], want, key + " (full frame)")
-        print(key, "pixels differing from the reference frame:", n_diff, "of", W * H)
-        assert n_diff <= W * H // 10000
+        # the frame IS the reference's, byte for byte (pow -- the one operation whose implementation differs from glibc's --
+        # has not produced a different byte on any frame of three rounds: no tolerance here)
+        assert hashlib.sha256(g["rgb"].tobytes()).hexdigest() == frames[key]["sha256"], key
 
 
 @pytest.mark.parametrize("scale,offset", [(1e-4, 0.0), (3e4, 0.0), (1.0, 2.5e6), (7.0, -9.1e5)])
@@ -781,6 +772,26 @@ def test_4k_frame_contains_the_reference_1080p_frame(scenes):
         order = torch.zeros(total, dtype=torch.int32, device="cuda")
         abi.order_tiles_device(h, vp(comb), mw, mh, W, H, T, T, vp(order))
     assert order.cpu().numpy().tolist() != list(range(total))
+
+
+@pytest.mark.parametrize("scene", ["loft", "room_tex"])
+def test_full_frames_of_the_other_scenes(scene, scenes):
+    """1920x1080 of round 4's two more scenes, first frame (no costs) and the two after it, against the SHA-256 of the
+    frame the compiled reference rendered (loft) / the oracle rendered (room_tex: textured frames cannot come from the
+    reference build here, texture.cc needs SDL2 -- `made_by` in frames.json says so)."""
+    import hashlib
+    frames = json.load(open(os.path.join(GOLDEN, "frames.json")))
+    e = frames[scene + "_1920x1080_d5"]
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes[scene])
+    h = m.device_scene()
+    abi.set_lights(h, scenegen.ROOM_LIGHTS)
+    sens = binding.sensor(scenegen.ROOM_CAMERA, 1920, 1080)
+    for launch in range(3):
+        r = abi.render_chunk(h, sens, 1920, 1080)
+        sha = hashlib.sha256(r["rgb"].tobytes()).hexdigest()
+        print(scene, "launch", launch, sha, "kernel ms", r["stats"]["kernel_ms"])
+        assert sha == e["sha256"], launch
 
 
 @pytest.mark.parametrize("view", ["room_view_back", "room_view_floor"])
