@@ -224,41 +224,52 @@ bool finite3(const double *p, size_t n) {
   return true;
 }
 
-// Launch geometry: as many 4-wave blocks as the CU's LDS/VGPR budget admits.
+// Launch geometry: workgroups of 4 waves -- or of 2 or 1 where that puts more waves on a CU: a deep octree's traversal
+// frames (27 KB per wave at 16 levels) let one 4-wave workgroup fill two thirds of the LDS and leave room for a fifth
+// wave only as a workgroup of its own.
 int configure_launch(mt_scene *s) {
   const size_t per_wave = wave_stack_bytes(s->dev.tree_depth, s->dev.pack_shift != 0);
-  int wpb = 4;
-  while (wpb > 1 && per_wave * wpb > kLdsBudget) wpb >>= 1;
-  if (per_wave * wpb > kLdsBudget) {
+  if (per_wave > kLdsBudget) {
     return fail(MT_ERR_UNSUPPORTED, "octree depth %d needs %zu B of LDS per wave (> %zu)",
                 s->dev.tree_depth, per_wave, kLdsBudget);
   }
-  s->waves_per_block = wpb;
-  s->lds_bytes = per_wave * wpb;
   // The attribute is per function AND per device: keep it, for every device, at the largest size any scene
   // of this process needs there (a shallower scene must not lower it; scenes may be created from several threads).
-  {
+  auto set_attribute = [&](size_t bytes) -> int {
     static std::mutex mu;
     static std::map<int, size_t> lds_attr;  // device -> bytes set
     std::lock_guard<std::mutex> lock(mu);
     size_t &have = lds_attr[s->device];
-    if (s->lds_bytes > have) {
+    if (bytes > have) {
       const void *kernels[] = {(const void *)render_kernel<true>, (const void *)render_kernel<false>,
                                (const void *)primary_kernel<true>, (const void *)primary_kernel<false>,
                                (const void *)pool_kernel<true>, (const void *)pool_kernel<false>,
                                (const void *)hybrid_kernel<true>, (const void *)hybrid_kernel<false>,
                                (const void *)probe_kernel, (const void *)intersect_kernel};
       for (const void *k : kernels) {
-        HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->lds_bytes));
+        HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       }
-      have = s->lds_bytes;
+      have = bytes;
+    }
+    return MT_OK;
+  };
+  int best_wpb = 0, best_per_cu = 0;
+  for (int wpb = 4; wpb >= 1; wpb >>= 1) {
+    if (per_wave * wpb > kLdsBudget) continue;
+    int rc = set_attribute(per_wave * wpb);
+    if (rc != MT_OK) return rc;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_kernel<true>, wpb * 64, per_wave * wpb));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * wpb > 16) per_cu = 16 / wpb;  // more waves only add divergence state
+    if (per_cu * wpb > best_per_cu * best_wpb) {  // (ties: the larger workgroup, tried first)
+      best_wpb = wpb;
+      best_per_cu = per_cu;
     }
   }
-  int per_cu = 0;
-  HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_kernel<true>,
-                                                       wpb * 64, s->lds_bytes));
-  if (per_cu < 1) per_cu = 1;
-  if (per_cu * wpb > 16) per_cu = 16 / wpb;  // more waves only add divergence state
+  int per_cu = best_per_cu;
+  s->waves_per_block = best_wpb;
+  s->lds_bytes = per_wave * best_wpb;
   {  // occupancy experiments
     const int v = (int)s->tune.v[MT_TUNE_BLOCKS_PER_CU];
     if (v >= 1 && v < per_cu) per_cu = v;

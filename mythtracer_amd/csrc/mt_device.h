@@ -249,7 +249,10 @@ __device__ __forceinline__ int slot_of_tile(const RenderParams &P, int t) {
 // levels of an octree the hit-set walk takes: its per-level child masks hold 16 levels; LDS -- 24-byte frames per lane
 // for all but the leaf level -- is 15 KB per wave at 9 levels (8 waves per CU) and 27 KB at 16 (4 waves per CU: the
 // launch configuration halves the waves per workgroup until the budget holds).  Deeper trees take the ordered descent.
-constexpr int kHsMaxDepth = 16;
+#ifndef MT_HS_MAX_DEPTH
+#define MT_HS_MAX_DEPTH 16  // (-DMT_HS_MAX_DEPTH=15: what does the ordered descent cost on a tree the walk would take?  profiles/README.md)
+#endif
+constexpr int kHsMaxDepth = MT_HS_MAX_DEPTH;
 __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
   size_t n = (size_t)depth * 64 * (packed ? 16 : 20);
   if (depth <= kHsMaxDepth && depth > 1) {

@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
 // the 4K frame at N = 8; a block of 26-32 passes that starts there ends 20-30 % after everybody else).
 template <bool STATS>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void hybrid_kernel(DevScene S, RenderParams P) {
-  const bool starter = (threadIdx.x >> 6) == 3 && blockIdx.x < P.n_work[2];
+  const bool starter = (threadIdx.x >> 6) == (blockDim.x >> 6) - 1 && blockIdx.x < P.n_work[2];  // (the last wave of a workgroup)
   if (!starter) {
     if (pool_engine<STATS, true>(S, P, kCarryNone) == kCarryFail) return;  // a device-side bound tripped (status is set)
   }

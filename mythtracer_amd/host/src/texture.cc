@@ -1,9 +1,10 @@
 // texture.cc — texture files -> texels (reference: VerStarting/texture.cc:60-109).
 //
 // The reference decodes through SDL2_image; this build has no third-party
-// decoder, so five self-contained formats are read directly: PNG (8-bit
-// grey / grey+alpha / RGB / RGBA / palette, non-interlaced; own inflate),
-// baseline JPEG (libjpeg's integer arithmetic restated, see DecodeJPEG), binary
+// decoder, so five self-contained formats are read directly: PNG (every colour
+// type and bit depth of the specification, Adam7 interlacing; own inflate),
+// JPEG (baseline and progressive Huffman, 8 bit; libjpeg's integer arithmetic
+// restated, see DecodeJPEG), binary
 // PPM (P6, maxval 255), uncompressed 24/32-bit BMP, uncompressed true-colour
 // TGA.  The texel conversion is the reference's: the image is taken
 // as RGBA32 and colour = byte / 255.0 (texture.cc:88-104), rows stored top to
@@ -254,7 +255,7 @@ Texture* DecodePNG(const std::vector<uint8_t>& d) {
     }
     pos += 12 + (size_t)len;  // (chunk CRCs are not verified)
   }
-  if (!seen_ihdr || !SaneSize(w, h) || depth != 8 || interlace != 0) return nullptr;
+  if (!seen_ihdr || !SaneSize(w, h) || interlace > 1) return nullptr;
   int channels;
   switch (ctype) {
     case 0: channels = 1; break;  // grey
@@ -264,11 +265,29 @@ Texture* DecodePNG(const std::vector<uint8_t>& d) {
     case 6: channels = 4; break;  // RGBA
     default: return nullptr;
   }
+  // bit depths the specification allows per colour type (section 11.2.2)
+  const bool depth_ok = ctype == 0 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)
+                      : ctype == 3 ? (depth == 1 || depth == 2 || depth == 4 || depth == 8)
+                                   : (depth == 8 || depth == 16);
+  if (!depth_ok) return nullptr;
   if (ctype == 3 && (palette.empty() || palette.size() % 3 != 0)) return nullptr;
   if (idat.size() < 6) return nullptr;
   // zlib wrapper: CMF/FLG, deflate data, Adler-32 (checked)
   if ((idat[0] & 0x0f) != 8 || ((idat[0] << 8) | idat[1]) % 31 != 0 || (idat[1] & 0x20)) return nullptr;
-  const size_t stride = (size_t)w * channels, raw_size = (stride + 1) * (size_t)h;
+  // The image arrives as one sub-image, or as the seven of Adam7 (section 8.2): pass p holds the pixels
+  // (x0 + i dx, y0 + j dy); every sub-image has its own rows of filtered bytes, empty ones are left out.
+  static const int kX0[7] = {0, 4, 0, 2, 0, 1, 0}, kY0[7] = {0, 0, 4, 0, 2, 0, 1};
+  static const int kDx[7] = {8, 8, 4, 4, 2, 2, 1}, kDy[7] = {8, 8, 8, 4, 4, 2, 2};
+  const int n_pass = interlace ? 7 : 1;
+  const int bits_pp = depth * channels;          // bits per pixel
+  const size_t bpp = (size_t)(bits_pp + 7) / 8;  // the filters' "corresponding byte" distance
+  size_t raw_size = 0;
+  long pw[7], ph[7];
+  for (int p = 0; p < n_pass; p++) {
+    pw[p] = interlace ? (w - kX0[p] + kDx[p] - 1) / kDx[p] : w;
+    ph[p] = interlace ? (h - kY0[p] + kDy[p] - 1) / kDy[p] : h;
+    if (pw[p] > 0 && ph[p] > 0) raw_size += (((size_t)pw[p] * bits_pp + 7) / 8 + 1) * (size_t)ph[p];
+  }
   std::vector<uint8_t> raw;
   if (!Inflate(idat.data() + 2, idat.size() - 6, raw_size, &raw) || raw.size() != raw_size) return nullptr;
   uint32_t a = 1, b = 0;
@@ -277,48 +296,70 @@ Texture* DecodePNG(const std::vector<uint8_t>& d) {
     b = (b + a) % 65521u;
   }
   if (((b << 16) | a) != Be32(&idat[idat.size() - 4])) return nullptr;
-  // undo the scanline filters (PNG specification, section 9)
-  std::vector<uint8_t> img(stride * (size_t)h);
-  for (long y = 0; y < h; y++) {
-    const uint8_t ft = raw[(size_t)y * (stride + 1)];
-    const uint8_t* in = &raw[(size_t)y * (stride + 1) + 1];
-    uint8_t* cur = &img[(size_t)y * stride];
-    const uint8_t* up = y > 0 ? &img[(size_t)(y - 1) * stride] : nullptr;
-    if (ft > 4) return nullptr;
-    for (size_t x = 0; x < stride; x++) {
-      const int left = x >= (size_t)channels ? cur[x - channels] : 0;
-      const int above = up ? up[x] : 0;
-      const int upleft = (up && x >= (size_t)channels) ? up[x - channels] : 0;
-      int pred = 0;
-      if (ft == 1) pred = left;
-      else if (ft == 2) pred = above;
-      else if (ft == 3) pred = (left + above) >> 1;
-      else if (ft == 4) {
-        const int p = left + above - upleft, pa = abs(p - left), pb = abs(p - above), pc = abs(p - upleft);
-        pred = (pa <= pb && pa <= pc) ? left : (pb <= pc ? above : upleft);
-      }
-      cur[x] = (uint8_t)(in[x] + pred);
-    }
-  }
+  // What SDL2_image's libpng reader asks for before it hands over RGBA32 (IMG_png.c): 16-bit samples stripped to
+  // their high byte (png_set_strip_16), samples below 8 bits unpacked, grey ones scaled to 8 bits
+  // (png_set_expand: 1 bit x 255, 2 bits x 85, 4 bits x 17), palette indices looked up, grey replicated.
   std::vector<uint8_t> rgb((size_t)w * h * 3);
-  for (size_t i = 0; i < (size_t)w * h; i++) {
-    const uint8_t* px = &img[i * channels];
-    uint8_t* o = &rgb[i * 3];
-    if (ctype == 2 || ctype == 6) {
-      o[0] = px[0]; o[1] = px[1]; o[2] = px[2];
-    } else if (ctype == 3) {
-      if ((size_t)px[0] * 3 + 2 >= palette.size()) return nullptr;
-      o[0] = palette[px[0] * 3]; o[1] = palette[px[0] * 3 + 1]; o[2] = palette[px[0] * 3 + 2];
-    } else {
-      o[0] = o[1] = o[2] = px[0];
+  std::vector<uint8_t> prev, cur;
+  size_t at = 0;
+  for (int p = 0; p < n_pass; p++) {
+    if (pw[p] <= 0 || ph[p] <= 0) continue;
+    const size_t stride = ((size_t)pw[p] * bits_pp + 7) / 8;
+    prev.assign(stride, 0);
+    cur.assign(stride, 0);
+    for (long y = 0; y < ph[p]; y++) {
+      const uint8_t ft = raw[at];
+      const uint8_t* in = &raw[at + 1];
+      at += stride + 1;
+      if (ft > 4) return nullptr;
+      // undo the scanline filter (PNG specification, section 9)
+      for (size_t x = 0; x < stride; x++) {
+        const int left = x >= bpp ? cur[x - bpp] : 0;
+        const int above = prev[x];
+        const int upleft = x >= bpp ? prev[x - bpp] : 0;
+        int pred = 0;
+        if (ft == 1) pred = left;
+        else if (ft == 2) pred = above;
+        else if (ft == 3) pred = (left + above) >> 1;
+        else if (ft == 4) {
+          const int q = left + above - upleft, pa = abs(q - left), pb = abs(q - above), pc = abs(q - upleft);
+          pred = (pa <= pb && pa <= pc) ? left : (pb <= pc ? above : upleft);
+        }
+        cur[x] = (uint8_t)(in[x] + pred);
+      }
+      const long oy = interlace ? kY0[p] + y * kDy[p] : y;
+      for (long x = 0; x < pw[p]; x++) {
+        const long ox = interlace ? kX0[p] + x * kDx[p] : x;
+        int v[4] = {0, 0, 0, 0};
+        for (int c = 0; c < channels; c++) {
+          if (depth == 8) v[c] = cur[(size_t)x * channels + c];
+          else if (depth == 16) v[c] = cur[((size_t)x * channels + c) * 2];  // the high byte
+          else {
+            const size_t bit = (size_t)x * depth;  // (one channel below 8 bits)
+            v[c] = (cur[bit >> 3] >> (8 - depth - (int)(bit & 7))) & ((1 << depth) - 1);
+            if (ctype == 0) v[c] *= depth == 1 ? 255 : (depth == 2 ? 85 : 17);
+          }
+        }
+        uint8_t* o = &rgb[((size_t)oy * w + ox) * 3];
+        if (ctype == 2 || ctype == 6) {
+          o[0] = (uint8_t)v[0]; o[1] = (uint8_t)v[1]; o[2] = (uint8_t)v[2];
+        } else if (ctype == 3) {
+          if ((size_t)v[0] * 3 + 2 >= palette.size()) return nullptr;
+          o[0] = palette[v[0] * 3]; o[1] = palette[v[0] * 3 + 1]; o[2] = palette[v[0] * 3 + 2];
+        } else {
+          o[0] = o[1] = o[2] = (uint8_t)v[0];
+        }
+      }
+      prev.swap(cur);
     }
   }
   return FromRgbRows((size_t)w, (size_t)h, rgb);
 }
 
-// ---- JPEG (baseline) --------------------------------------------------------
-// Sequential DCT, Huffman, 8 bit, grey or YCbCr with 1x1 / 2x1 / 2x2 chroma
-// sampling, restart intervals.  The reference decodes JPEG through SDL2_image,
+// ---- JPEG ---------------------------------------------------------------------
+// Sequential and progressive DCT (spectral selection and successive approximation, ITU T.81 annex G -- what a
+// 3ds-Max-era exporter's "progressive" check box writes), Huffman, 8 bit, grey or YCbCr with 1x1 / 2x1 / 2x2 chroma
+// sampling, interleaved and per-component scans, restart intervals.  The reference decodes JPEG through SDL2_image,
 // i.e. libjpeg with its defaults; decoders differ in the last bit unless they
 // use the same integer arithmetic, so this one restates libjpeg's: the
 // "islow" inverse DCT (jidctint.c: 13-bit constants, two passes), "fancy"
@@ -442,18 +483,25 @@ Texture* DecodeJPEG(const std::vector<uint8_t>& d) {
                                       41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22,
                                       15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55,
                                       62, 63};
-  struct Comp { int id, h, v, tq, td, ta, bw, bh, dc_pred; std::vector<uint8_t> plane; int pw, ph; };
+  // bw x bh: blocks of the component in the padded (whole-MCU) image, the layout of `coef` and `plane`;
+  // cbw x cbh: blocks that hold pixels of the component -- what a scan of this component ALONE covers (ITU T.81 A.2.3)
+  struct Comp {
+    int id, h, v, tq, td, ta, bw, bh, cbw, cbh, dc_pred, pw, ph;
+    bool q_latched;
+    int q[64];
+    std::vector<int16_t> coef;
+    std::vector<uint8_t> plane;
+  };
   int qt[4][64];
   bool qt_ok[4] = {false, false, false, false};
   JpegHuff hdc[4], hac[4];
   std::vector<Comp> comps;
-  long W = 0, H = 0;
-  int restart = 0, adobe_transform = -1;
-  bool sof = false;
+  long W = 0, H = 0, mcux = 0, mcuy = 0;
+  int restart = 0, adobe_transform = -1, hmax = 1, vmax = 1;
+  bool sof = false, progressive = false, any_scan = false;
   size_t pos = 2;
   if (d.size() < 4 || d[0] != 0xff || d[1] != 0xd8) return nullptr;
-  size_t scan_at = 0;
-  while (pos + 4 <= d.size()) {
+  while (pos + 2 <= d.size()) {
     if (d[pos] != 0xff) return nullptr;
     const int m = d[pos + 1];
     pos += 2;
@@ -476,25 +524,53 @@ Texture* DecodeJPEG(const std::vector<uint8_t>& d) {
         }
         qt_ok[tq] = true;
       }
-    } else if (m == 0xc0 || m == 0xc1) {  // SOF0 / SOF1 (Huffman, sequential)
-      if (bl < 6 || b[0] != 8) return nullptr;
+    } else if (m == 0xc0 || m == 0xc1 || m == 0xc2) {  // SOF0 / SOF1 (sequential) / SOF2 (progressive), Huffman, 8 bit
+      if (sof || bl < 6 || b[0] != 8) return nullptr;
+      progressive = m == 0xc2;
       H = (b[1] << 8) | b[2];
       W = (b[3] << 8) | b[4];
       const int nc = b[5];
-      if ((nc != 1 && nc != 3) || bl < 6 + 3 * (size_t)nc) return nullptr;
-      comps.clear();
+      if ((nc != 1 && nc != 3) || bl < 6 + 3 * (size_t)nc || !SaneSize(W, H)) return nullptr;
       for (int i = 0; i < nc; i++) {
         Comp c{};
         c.id = b[6 + 3 * i];
         c.h = b[7 + 3 * i] >> 4;
         c.v = b[7 + 3 * i] & 15;
         c.tq = b[8 + 3 * i];
-        if (c.tq > 3) return nullptr;
+        if (c.tq > 3 || c.h < 1 || c.v < 1 || c.h > 2 || c.v > 2) return nullptr;
         comps.push_back(c);
       }
+      if (nc == 3) {
+        // luminance at full resolution, both chroma planes sampled alike: 1x1, 2x1 (h2v1) or 2x2 (h2v2)
+        hmax = comps[0].h;
+        vmax = comps[0].v;
+        if (comps[1].h != 1 || comps[1].v != 1 || comps[2].h != 1 || comps[2].v != 1 || (hmax == 1 && vmax == 2)) return nullptr;
+      } else {
+        hmax = vmax = 1;  // a single component is never interleaved: one block per MCU
+        comps[0].h = comps[0].v = 1;
+      }
+      mcux = (W + 8 * hmax - 1) / (8 * hmax);
+      mcuy = (H + 8 * vmax - 1) / (8 * vmax);
+      {
+        // every block costs at least one bit in some scan: a header that promises more blocks than the file can
+        // hold is refused before anything is allocated
+        long blocks_per_mcu = 0;
+        for (const Comp& c : comps) blocks_per_mcu += c.h * c.v;
+        if (d.size() * 8 < (size_t)(mcux * mcuy * blocks_per_mcu)) return nullptr;
+      }
+      for (Comp& c : comps) {
+        c.bw = (int)(mcux * c.h);
+        c.bh = (int)(mcuy * c.v);
+        c.cbw = (int)(((W * c.h + hmax - 1) / hmax + 7) / 8);
+        c.cbh = (int)(((H * c.v + vmax - 1) / vmax + 7) / 8);
+        c.pw = c.bw * 8;
+        c.ph = c.bh * 8;
+        c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+        c.q_latched = false;
+      }
       sof = true;
-    } else if (m == 0xc2 || (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc)) {
-      return nullptr;  // progressive, lossless, arithmetic: not supported
+    } else if (m >= 0xc3 && m <= 0xcf && m != 0xc4 && m != 0xc8 && m != 0xcc) {
+      return nullptr;  // lossless, differential, arithmetic coding: not supported
     } else if (m == 0xc4) {  // DHT
       for (size_t i = 0; i < bl;) {
         if (i + 17 > bl) return nullptr;
@@ -510,101 +586,188 @@ Texture* DecodeJPEG(const std::vector<uint8_t>& d) {
       restart = (b[0] << 8) | b[1];
     } else if (m == 0xee) {  // Adobe APP14
       if (bl >= 12 && !memcmp(b, "Adobe", 5)) adobe_transform = b[11];
-    } else if (m == 0xda) {  // SOS
-      if (!sof || bl < 1 || b[0] != (int)comps.size() || bl < 1 + 2 * comps.size() + 3) return nullptr;
-      for (size_t i = 0; i < comps.size(); i++) {
-        bool found = false;
+    } else if (m == 0xda) {  // SOS: one scan (jdhuff.c decode_mcu; jdphuff.c decode_mcu_DC/AC_first/refine)
+      if (!sof || bl < 1) return nullptr;
+      const int ns = b[0];
+      if (ns < 1 || ns > (int)comps.size() || bl < 1 + 2 * (size_t)ns + 3) return nullptr;
+      Comp* sc[3];
+      for (int i = 0; i < ns; i++) {
+        sc[i] = nullptr;
         for (Comp& c : comps) {
           if (c.id == b[1 + 2 * i]) {
             c.td = b[2 + 2 * i] >> 4;
             c.ta = b[2 + 2 * i] & 15;
-            found = c.td < 4 && c.ta < 4;
+            if (c.td < 4 && c.ta < 4) sc[i] = &c;
           }
         }
-        if (!found) return nullptr;
+        if (!sc[i]) return nullptr;
+        for (int j = 0; j < i; j++) {
+          if (sc[j] == sc[i]) return nullptr;
+        }
+        if (!sc[i]->q_latched) {  // the table a component is dequantized with is the one in force at its first scan (jdinput.c latch_quant_tables)
+          if (!qt_ok[sc[i]->tq]) return nullptr;
+          memcpy(sc[i]->q, qt[sc[i]->tq], sizeof sc[i]->q);
+          sc[i]->q_latched = true;
+        }
       }
-      scan_at = pos + len;
-      break;
+      const int Ss = b[1 + 2 * ns], Se = b[2 + 2 * ns], Ah = b[3 + 2 * ns] >> 4, Al = b[3 + 2 * ns] & 15;
+      if (!progressive) {
+        if (Ss != 0 || Se != 63 || Ah != 0 || Al != 0) return nullptr;
+      } else {
+        // jdphuff.c start_pass_phuff_decoder's checks: a DC scan is Ss = Se = 0, an AC scan has one component and
+        // 1 <= Ss <= Se <= 63; successive approximation goes one bit at a time
+        if (Ss > Se || Se > 63 || Al > 13 || (Ss == 0 && Se != 0) || (Ss != 0 && ns != 1) || (Ah != 0 && Ah - 1 != Al)) return nullptr;
+      }
+      const bool dc_scan = Ss == 0;
+      for (int i = 0; i < ns; i++) {
+        if ((!progressive || (dc_scan && Ah == 0)) && !hdc[sc[i]->td].present) return nullptr;
+        if ((!progressive || !dc_scan) && !hac[sc[i]->ta].present) return nullptr;
+        sc[i]->dc_pred = 0;
+      }
+      JpegBits br{d.data(), d.size(), pos + len};
+      const long nx = ns > 1 ? mcux : sc[0]->cbw, ny = ns > 1 ? mcuy : sc[0]->cbh;
+      int until_restart = restart;
+      unsigned eobrun = 0;
+      for (long my = 0; my < ny; my++) {
+        for (long mx = 0; mx < nx; mx++) {
+          if (restart && until_restart == 0) {
+            br.Reset();
+            // skip to the RSTn marker
+            while (br.pos + 1 < d.size() && !(d[br.pos] == 0xff && d[br.pos + 1] >= 0xd0 && d[br.pos + 1] <= 0xd7)) br.pos++;
+            br.pos += 2;
+            for (int i = 0; i < ns; i++) sc[i]->dc_pred = 0;
+            eobrun = 0;
+            until_restart = restart;
+          }
+          for (int i = 0; i < ns; i++) {
+            Comp& c = *sc[i];
+            const int nbx = ns > 1 ? c.h : 1, nby = ns > 1 ? c.v : 1;
+            for (int by = 0; by < nby; by++) {
+              for (int bx = 0; bx < nbx; bx++) {
+                const long gx = ns > 1 ? mx * c.h + bx : mx, gy = ns > 1 ? my * c.v + by : my;
+                int16_t* blk = &c.coef[((size_t)gy * c.bw + gx) * 64];
+                if (!progressive) {  // sequential: the whole block
+                  const int t = hdc[c.td].Decode(br);
+                  if (t < 0 || t > 11) return nullptr;
+                  c.dc_pred += t ? JpegExtend(br.Bits(t), t) : 0;
+                  if (c.dc_pred < -32768 || c.dc_pred > 32767) return nullptr;  // beyond any 8-bit image (libjpeg keeps it in a short)
+                  blk[0] = (int16_t)c.dc_pred;
+                  for (int k = 1; k < 64;) {
+                    const int rs = hac[c.ta].Decode(br);
+                    if (rs < 0) return nullptr;
+                    const int r = rs >> 4, sz = rs & 15;
+                    if (sz == 0) {
+                      if (r != 15) break;  // end of block
+                      k += 16;
+                      continue;
+                    }
+                    k += r;
+                    if (k > 63) return nullptr;
+                    blk[kZigzag[k]] = (int16_t)JpegExtend(br.Bits(sz), sz);
+                    k++;
+                  }
+                } else if (dc_scan && Ah == 0) {  // DC, first scan: the difference, scaled up by Al
+                  const int t = hdc[c.td].Decode(br);
+                  if (t < 0 || t > 11) return nullptr;
+                  c.dc_pred += t ? JpegExtend(br.Bits(t), t) : 0;
+                  if (c.dc_pred < -32768 || c.dc_pred > 32767) return nullptr;
+                  blk[0] = (int16_t)(c.dc_pred * (1 << Al));
+                } else if (dc_scan) {  // DC, refinement: one more bit
+                  if (br.Bit()) blk[0] = (int16_t)(blk[0] | (1 << Al));
+                } else if (Ah == 0) {  // AC band, first scan
+                  if (eobrun > 0) {
+                    eobrun--;  // a band of zeroes
+                  } else {
+                    for (int k = Ss; k <= Se; k++) {
+                      const int rs = hac[c.ta].Decode(br);
+                      if (rs < 0) return nullptr;
+                      const int r = rs >> 4, sz = rs & 15;
+                      if (sz) {
+                        k += r;
+                        if (k > 63) return nullptr;
+                        blk[kZigzag[k]] = (int16_t)(JpegExtend(br.Bits(sz), sz) * (1 << Al));
+                      } else if (r == 15) {
+                        k += 15;  // sixteen zeroes
+                      } else {    // EOBr: 2^r + appended bits blocks end here, this one included
+                        eobrun = 1u << r;
+                        if (r) eobrun += (unsigned)br.Bits(r);
+                        eobrun--;
+                        break;
+                      }
+                    }
+                  }
+                } else {  // AC band, refinement
+                  const int p1 = 1 << Al, m1 = -(1 << Al);
+                  int k = Ss;
+                  auto correct = [&](int16_t* cf) {  // a correction bit: 1 = the magnitude grows by one step
+                    if (br.Bit() && (*cf & p1) == 0) *cf = (int16_t)(*cf >= 0 ? *cf + p1 : *cf + m1);
+                  };
+                  if (eobrun == 0) {
+                    for (; k <= Se; k++) {
+                      const int rs = hac[c.ta].Decode(br);
+                      if (rs < 0) return nullptr;
+                      int r = rs >> 4, sv = rs & 15;
+                      if (sv) {
+                        sv = br.Bit() ? p1 : m1;  // (the size of a newly non-zero coefficient is always 1)
+                      } else if (r != 15) {
+                        eobrun = 1u << r;
+                        if (r) eobrun += (unsigned)br.Bits(r);
+                        break;  // the rest of the block is handled by the end-of-band logic
+                      }
+                      // advance over already-nonzero coefficients and r still-zero ones, correcting the nonzero ones
+                      do {
+                        int16_t* cf = &blk[kZigzag[k]];
+                        if (*cf != 0) {
+                          correct(cf);
+                        } else if (--r < 0) {
+                          break;  // reached the target zero coefficient
+                        }
+                        k++;
+                      } while (k <= Se);
+                      if (sv) {
+                        if (k > 63) return nullptr;
+                        blk[kZigzag[k]] = (int16_t)sv;
+                      }
+                    }
+                  }
+                  if (eobrun > 0) {
+                    for (; k <= Se; k++) {
+                      int16_t* cf = &blk[kZigzag[k]];
+                      if (*cf != 0) correct(cf);
+                    }
+                    eobrun--;
+                  }
+                }
+              }
+            }
+          }
+          if (restart) until_restart--;
+        }
+      }
+      any_scan = true;
+      // the next marker: behind the entropy-coded bytes (stuffed zeroes and restart markers belong to them)
+      size_t q = br.pos;
+      while (q + 1 < d.size() && !(d[q] == 0xff && d[q + 1] != 0 && !(d[q + 1] >= 0xd0 && d[q + 1] <= 0xd7) && d[q + 1] != 0xff)) q++;
+      if (q + 1 >= d.size()) break;  // no EOI: what has been decoded is the image (libjpeg warns and goes on)
+      pos = q;
+      continue;
     }
     pos += len;
   }
-  if (!sof || scan_at == 0 || !SaneSize(W, H)) return nullptr;
-  int hmax = 1, vmax = 1;
-  for (const Comp& c : comps) {
-    if (c.h < 1 || c.v < 1 || c.h > 2 || c.v > 2 || !qt_ok[c.tq] || !hdc[c.td].present || !hac[c.ta].present) return nullptr;
-    hmax = c.h > hmax ? c.h : hmax;
-    vmax = c.v > vmax ? c.v : vmax;
-  }
-  if (comps.size() == 3) {
-    // luminance at full resolution, both chroma planes sampled alike: 1x1, 2x1 (h2v1) or 2x2 (h2v2)
-    if (comps[0].h != hmax || comps[0].v != vmax || comps[1].h != 1 || comps[1].v != 1 || comps[2].h != 1 ||
-        comps[2].v != 1 || (hmax == 1 && vmax == 2)) {
-      return nullptr;
-    }
-  } else {
-    hmax = vmax = 1;  // a single component is never interleaved: one block per MCU
-    comps[0].h = comps[0].v = 1;
-  }
-  const long mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
-  {
-    // every block costs at least two bits (a DC code and an end-of-block code): a header
-    // that promises more blocks than the file can hold is refused before anything is allocated
-    long blocks_per_mcu = 0;
-    for (const Comp& c : comps) blocks_per_mcu += c.h * c.v;
-    if ((d.size() - scan_at) * 8 < (size_t)(mcux * mcuy * blocks_per_mcu) * 2) return nullptr;
-  }
+  if (!sof || !any_scan) return nullptr;
+  // ---- dequantization and inverse DCT of every block (jddctmgr.c + jidctint.c)
   for (Comp& c : comps) {
-    c.bw = (int)(mcux * c.h);
-    c.bh = (int)(mcuy * c.v);
-    c.pw = c.bw * 8;
-    c.ph = c.bh * 8;
+    if (!c.q_latched) return nullptr;  // a component no scan brought
     c.plane.assign((size_t)c.pw * c.ph, 0);
-    c.dc_pred = 0;
-  }
-  // ---- entropy-coded segment
-  JpegBits br{d.data(), d.size(), scan_at};
-  int until_restart = restart;
-  for (long my = 0; my < mcuy; my++) {
-    for (long mx = 0; mx < mcux; mx++) {
-      if (restart && until_restart == 0) {
-        br.Reset();
-        // skip to the RSTn marker
-        while (br.pos + 1 < d.size() && !(d[br.pos] == 0xff && d[br.pos + 1] >= 0xd0 && d[br.pos + 1] <= 0xd7)) br.pos++;
-        br.pos += 2;
-        for (Comp& c : comps) c.dc_pred = 0;
-        until_restart = restart;
+    int in[64];
+    for (int by = 0; by < c.bh; by++) {
+      for (int bx = 0; bx < c.bw; bx++) {
+        const int16_t* blk = &c.coef[((size_t)by * c.bw + bx) * 64];
+        for (int k = 0; k < 64; k++) in[k] = blk[k] * c.q[k];
+        JpegIdctIslow(in, &c.plane[(size_t)by * 8 * c.pw + (size_t)bx * 8], c.pw);
       }
-      for (Comp& c : comps) {
-        for (int by = 0; by < c.v; by++) {
-          for (int bx = 0; bx < c.h; bx++) {
-            int coef[64] = {0};
-            const int t = hdc[c.td].Decode(br);
-            if (t < 0 || t > 11) return nullptr;
-            const int diff = t ? JpegExtend(br.Bits(t), t) : 0;
-            c.dc_pred += diff;
-            if (c.dc_pred < -32768 || c.dc_pred > 32767) return nullptr;  // beyond any 8-bit image (libjpeg keeps it in a short)
-            coef[0] = c.dc_pred * qt[c.tq][0];
-            for (int k = 1; k < 64;) {
-              const int rs = hac[c.ta].Decode(br);
-              if (rs < 0) return nullptr;
-              const int r = rs >> 4, sz = rs & 15;
-              if (sz == 0) {
-                if (r != 15) break;  // end of block
-                k += 16;
-                continue;
-              }
-              k += r;
-              if (k > 63) return nullptr;
-              coef[kZigzag[k]] = JpegExtend(br.Bits(sz), sz) * qt[c.tq][kZigzag[k]];
-              k++;
-            }
-            const size_t ox = (size_t)(mx * c.h + bx) * 8, oy = (size_t)(my * c.v + by) * 8;
-            JpegIdctIslow(coef, &c.plane[oy * c.pw + ox], c.pw);
-          }
-        }
-      }
-      if (restart) until_restart--;
     }
+    std::vector<int16_t>().swap(c.coef);
   }
   // ---- upsampling (jdsample.c, do_fancy_upsampling) and colour conversion (jdcolor.c)
   std::vector<uint8_t> rgb((size_t)W * H * 3);

@@ -1156,31 +1156,49 @@ def test_texture_files_end_to_end(tmp_path, engine):
     Image.fromarray(tb, "RGB").save(str(d_gpu / "b.png"))
     _write_ppm(str(d_orc / "a.ppm"), ta)
     _write_ppm(str(d_orc / "b.png"), tb)  # the oracle's PPM reader goes by content, the name stays the .mtl's
+    # round 4: a PROGRESSIVE JPEG and an Adam7-interlaced 16-bit PNG through map_Ka too (what a 3ds-Max export's textures
+    # tend to be); the oracle gets the pixels libjpeg-turbo decodes (through PIL) / the samples' high bytes as PPM
+    yy, xx = np.mgrid[0:24, 0:40]
+    tc = np.stack([(xx * 6 + yy) % 256, (xx + yy * 9) % 256, (xx * yy) % 256], axis=2).astype(np.uint8)
+    Image.fromarray(tc, "RGB").save(str(d_gpu / "c.jpg"), "JPEG", quality=85, progressive=True, subsampling=2)
+    assert b"\xff\xc2" in (d_gpu / "c.jpg").read_bytes()
+    _write_ppm(str(d_orc / "c.jpg"), np.array(Image.open(str(d_gpu / "c.jpg")).convert("RGB")))
+    import test_host_cpu
+    td16 = rnd.randint(0, 65536, size=(11, 7, 3))
+    (d_gpu / "d.png").write_bytes(test_host_cpu._png(7, 11, 2, td16, [0, 1, 2, 3, 4], 9, depth=16, interlace=1))
+    _write_ppm(str(d_orc / "d.png"), (td16 >> 8).astype(np.uint8))
     mtl = ("newmtl pa\nKa 1 1 1\nKd 0.8 0.8 0.8\nKs 0.1 0.1 0.1\nNs 4\nmap_Ka a.ppm\n"
            "newmtl pb\nKa 0.9 0.7 0.8\nKd 0.5 0.5 0.5\nKs 0 0 0\nNs 1\nmap_Ka b.png\n"
-           "newmtl pc\nKa 1 1 1\nKd 0.5 0.5 0.5\nKs 0 0 0\nNs 1\nmap_Ka a.ppm\n")
+           "newmtl pc\nKa 1 1 1\nKd 0.5 0.5 0.5\nKs 0 0 0\nNs 1\nmap_Ka a.ppm\n"
+           "newmtl pd\nKa 1 1 1\nKd 0.6 0.6 0.6\nKs 0 0 0\nNs 1\nmap_Ka c.jpg\n"
+           "newmtl pe\nKa 1 1 1\nKd 0.6 0.6 0.6\nKs 0 0 0\nNs 1\nmap_Ka d.png\n")
     obj = ("mtllib t.mtl\n"
            "v -6 -4 0\nv 0 -4 0\nv -6 4 0\nv 6 -4 0\nv 0 4 0\nv 6 4 0\nv 0 4.5 0\nv 6 4.5 0\nv 6 8 0\n"
            "vn 0 0 -1\n"
            "vt -0.5 -0.5\nvt 1.5 0\nvt 0 2.5\nvt 0 0\nvt 1 0\nvt 0 1\nvt nan nan\n"
            "usemtl pa\nf 1/1/1 2/2/1 3/3/1 \n"
            "usemtl pb\nf 2/4/1 4/5/1 5/6/1 \n"
-           "usemtl pc\nf 7/7/1 8/7/1 9/7/1 \n")
+           "usemtl pc\nf 7/7/1 8/7/1 9/7/1 \n"
+           "v -6 -8 0\nv 0 -8 0\nv -6 -4.5 0\nv 6 -8 0\nv 0 -4.5 0\n"
+           "usemtl pd\nf 10/4/1 11/5/1 12/6/1 \n"
+           "usemtl pe\nf 11/4/1 13/5/1 14/6/1 \n")
     for d in (d_gpu, d_orc):
         (d / "t.mtl").write_text(mtl)
         (d / "t.obj").write_text(obj)
     m = M.MythTracer(str(d_gpu / "t.obj"))
     o = orclib.OracleScene(str(d_orc / "t.obj"))
     flat = m.flatten()
-    assert sorted(t["texels"].dtype.name for t in flat["textures"]) == ["uint8", "uint8"]  # RGB8 on the device
-    assert sorted(t["texels"].shape for t in flat["textures"]) == [(9, 13, 3), (16, 16, 3)]
-    cam, lights = (0, 2, -9, 0, 0, 0, 80), [(0, 0, -6, .4, .4, .4, .7, .7, .7, .2, .2, .2)]
+    assert sorted(t["texels"].dtype.name for t in flat["textures"]) == ["uint8"] * 4  # RGB8 on the device
+    assert sorted(t["texels"].shape for t in flat["textures"]) == [(9, 13, 3), (11, 7, 3), (16, 16, 3), (24, 40, 3)]
+    cam, lights = (0, 0, -11, 0, 0, 0, 90), [(0, 0, -6, .4, .4, .4, .7, .7, .7, .2, .2, .2)]
     for frame in range(2):
         g = _render_both(m, o, cam, 96, 80, lights)
     rgb, line = g["rgb"], g["line"]
-    for ln in np.unique(line[line >= 0])[:2]:
+    lines = np.unique(line[line >= 0])
+    assert len(lines) == 5
+    for ln in [l for l in lines if l != lines[2]]:
         assert len(np.unique(rgb[line == ln], axis=0)) > 20  # the colour follows the texels
-    nan_tri = line == np.unique(line[line >= 0])[-1]
+    nan_tri = line == lines[2]  # (the third face of the file carries the NaN coordinates)
     assert nan_tri.any() and (rgb[nan_tri] == 0).all()
 
 

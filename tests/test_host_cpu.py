@@ -362,35 +362,61 @@ def test_texture_loaders(tmp_path):
         assert M.MythTracer().load_obj(str(tmp_path / "m.obj")) == ok, name
 
 
-def _png(w, h, ctype, pixels, filters, level, palette=None, idat_split=None):
+def _png(w, h, ctype, pixels, filters, level, palette=None, idat_split=None, depth=8, interlace=0):
     """A PNG written by hand: per-row filter types as given, zlib level as given
-    (0 = stored blocks, 1 = fixed Huffman for small inputs, 9 = dynamic)."""
+    (0 = stored blocks, 1 = fixed Huffman for small inputs, 9 = dynamic); `pixels` holds one sample per channel
+    (values below 2^depth); depth 1 / 2 / 4 packs them, 16 writes them big-endian; interlace = 1 cuts the image
+    into the seven sub-images of Adam7."""
     import struct, zlib
     channels = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
-    rows = pixels.reshape(h, w * channels).astype(np.int32)
+    px = np.asarray(pixels).reshape(h, w, channels).astype(np.int64)
+    bpp = max(1, depth * channels // 8)  # the filters' byte distance
+
+    def row_bytes(samples):  # (n, channels) -> packed bytes of one scanline
+        flat = samples.reshape(-1)
+        if depth == 8:
+            return flat.astype(np.uint8)
+        if depth == 16:
+            return np.stack([flat >> 8, flat & 255], axis=1).reshape(-1).astype(np.uint8)
+        per = 8 // depth
+        pad = (-len(flat)) % per
+        flat = np.concatenate([flat, np.zeros(pad, dtype=np.int64)]).reshape(-1, per)
+        out = np.zeros(len(flat), dtype=np.int64)
+        for k in range(per):
+            out |= flat[:, k] << (8 - depth * (k + 1))
+        return out.astype(np.uint8)
+
     raw = bytearray()
-    prev = np.zeros(w * channels, dtype=np.int32)
-    for y in range(h):
-        cur = rows[y]
-        ft = filters[y % len(filters)]
-        left = np.concatenate([np.zeros(channels, dtype=np.int32), cur[:-channels]])
-        upleft = np.concatenate([np.zeros(channels, dtype=np.int32), prev[:-channels]])
-        if ft == 0: pred = 0
-        elif ft == 1: pred = left
-        elif ft == 2: pred = prev
-        elif ft == 3: pred = (left + prev) >> 1
-        else:
-            p = left + prev - upleft
-            pa, pb, pc = abs(p - left), abs(p - prev), abs(p - upleft)
-            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
-        raw.append(ft)
-        raw += bytes(((cur - pred) & 255).astype(np.uint8))
-        prev = cur
+    passes = [(0, 0, 1, 1)] if not interlace else [(0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)]
+    row_no = 0
+    for (x0, y0, dx, dy) in passes:
+        sub = px[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        stride = len(row_bytes(sub[0]))
+        prev = np.zeros(stride, dtype=np.int32)
+        for y in range(sub.shape[0]):
+            cur = row_bytes(sub[y]).astype(np.int32)
+            ft = filters[row_no % len(filters)]
+            row_no += 1
+            left = np.concatenate([np.zeros(bpp, dtype=np.int32), cur[:-bpp]])[:stride]
+            upleft = np.concatenate([np.zeros(bpp, dtype=np.int32), prev[:-bpp]])[:stride]
+            if ft == 0: pred = 0
+            elif ft == 1: pred = left
+            elif ft == 2: pred = prev
+            elif ft == 3: pred = (left + prev) >> 1
+            else:
+                p = left + prev - upleft
+                pa, pb, pc = abs(p - left), abs(p - prev), abs(p - upleft)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            raw.append(ft)
+            raw += bytes(((cur - pred) & 255).astype(np.uint8))
+            prev = cur
     z = zlib.compress(bytes(raw), level)
 
     def chunk(t, body):
         return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body) & 0xffffffff)
-    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, ctype, 0, 0, 0))
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, interlace))
     if palette is not None:
         out += chunk(b"PLTE", bytes(palette.astype(np.uint8).reshape(-1)))
     parts = [z] if not idat_split else [z[:idat_split], z[idat_split:]]
@@ -432,9 +458,44 @@ def test_png_textures(tmp_path):
         m = M.MythTracer(str(tmp_path / "m.obj"))
         tex = m.flatten()["textures"][0]["texels"]
         assert tex.dtype == np.uint8 and np.array_equal(tex, rgb), name
+    # Round 4 (SURVEY 8f-3 leftovers): Adam7-interlaced files of every colour type, 16-bit samples (SDL2_image strips them
+    # to their high byte, png_set_strip_16), grey and palette below 8 bits (grey scaled to 8 bits: x255 / x85 / x17) --
+    # sizes that leave some of the seven passes empty included.  Where PIL reads the file as 8-bit RGB by itself (all
+    # but 16-bit grey) its pixels are compared too.
+    PIL_Image = pytest.importorskip("PIL.Image")
+    more = []
+    for (w2, h2) in ((1, 1), (2, 3), (5, 2), (8, 8), (13, 9), (33, 21)):
+        for ctype, ch, depths in ((2, 3, (8, 16)), (6, 4, (8, 16)), (0, 1, (1, 2, 4, 8, 16)), (4, 2, (8, 16)), (3, 1, (1, 2, 4, 8))):
+            for depth in depths:
+                for interlace in (0, 1):
+                    if interlace == 0 and depth == 8:
+                        continue  # covered above
+                    hi = min(1 << depth, 17 if ctype == 3 else 1 << depth)
+                    img = rnd.randint(0, hi, size=(h2, w2, ch))
+                    blob = _png(w2, h2, ctype, img, [0, 1, 2, 3, 4], 9, palette=pal if ctype == 3 else None, depth=depth, interlace=interlace)
+                    s8 = img >> 8 if depth == 16 else img
+                    if ctype in (2, 6):
+                        rgb = s8[:, :, :3]
+                    elif ctype == 3:
+                        rgb = pal[img[:, :, 0]]
+                    else:
+                        g = s8[:, :, :1] * {1: 255, 2: 85, 4: 17, 8: 1, 16: 1}[depth]
+                        rgb = np.repeat(g, 3, axis=2)
+                    more.append(("r4_%dx%d_t%d_d%d_i%d.png" % (w2, h2, ctype, depth, interlace), blob, rgb.astype(np.uint8), not (ctype in (0, 4) and depth == 16)))
+    import io
+    for name, blob, rgb, pil_too in more:
+        (tmp_path / name).write_bytes(blob)
+        (tmp_path / "m.mtl").write_text("newmtl a\nKa 1 1 1\nmap_Ka %s\n" % name)
+        m = M.MythTracer(str(tmp_path / "m.obj"))
+        tex = m.flatten()["textures"][0]["texels"]
+        assert tex.dtype == np.uint8 and np.array_equal(tex, rgb), name
+        if pil_too:
+            assert np.array_equal(np.array(PIL_Image.open(io.BytesIO(blob)).convert("RGB")), rgb), ("PIL disagrees", name)
+    assert len(more) == 6 * (3 + 3 + 9 + 3 + 7)
     good = cases[1][1]
     bad = {"truncated.png": good[:len(good) // 2], "bad_adler.png": good.replace(good[-20:-16], b"\0\0\0\0", 1),
-           "interlaced.png": good[:28] + b"\x01" + good[29:], "depth16.png": good[:24] + b"\x10" + good[25:]}
+           "interlace2.png": good[:28] + b"\x02" + good[29:], "depth3.png": good[:24] + b"\x03" + good[25:],
+           "rgb_depth4.png": _png(4, 4, 2, rnd.randint(0, 16, size=(4, 4, 3)), [0], 9, depth=8)[:24] + b"\x04" + _png(4, 4, 2, rnd.randint(0, 16, size=(4, 4, 3)), [0], 9)[25:]}
     for name, blob in bad.items():
         (tmp_path / name).write_bytes(blob)
         (tmp_path / "m.mtl").write_text("newmtl a\nKa 1 1 1\nmap_Ka %s\n" % name)
@@ -473,9 +534,32 @@ def test_jpeg_textures(tmp_path):
                 assert tex.dtype == np.uint8 and np.array_equal(tex, want), (w, h, mode, sub, q, extra)
                 checked += 1
     assert checked == 11 * 2 * 7
-    # progressive files, truncated headers and other damage are refused, not guessed at
-    PIL_Image.fromarray(noise).save(f, "JPEG", progressive=True)
-    assert not M.MythTracer().load_obj(str(tmp_path / "m.obj"))
+    # Round 4 (SURVEY 8f-3 leftovers): PROGRESSIVE files -- spectral selection and successive approximation, DC and AC
+    # refinement scans, end-of-band runs, per-component scans -- decode to the same coefficients and therefore to the
+    # same pixels as libjpeg-turbo's (jdphuff.c restated); libjpeg's scan script for colour (10 scans) and grey (6),
+    # with and without restart intervals and optimised tables
+    checked = 0
+    for (w, h) in ((1, 1), (3, 3), (6, 2), (13, 9), (16, 16), (33, 17), (64, 48), (200, 120)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        smooth = np.stack([(xx * 7 + yy * 3) % 256, (xx * 2 + yy * 11) % 256, (xx * yy) % 256], axis=2).astype(np.uint8)
+        noise = rnd.randint(0, 256, size=(h, w, 3)).astype(np.uint8)
+        for img in (smooth, noise):
+            for mode, sub, q, extra in (("RGB", 0, 92, {}), ("RGB", 1, 70, {"optimize": True}), ("RGB", 2, 35, {}),
+                                        ("RGB", 2, 98, {"restart_marker_blocks": 3}), ("L", None, 85, {}),
+                                        ("L", None, 30, {"restart_marker_rows": 1})):
+                kw = dict(quality=q, progressive=True, **extra)
+                if sub is not None:
+                    kw["subsampling"] = sub
+                PIL_Image.fromarray(img).convert(mode).save(f, "JPEG", **kw)
+                assert b"\xff\xc2" in f.read_bytes()
+                want = np.array(PIL_Image.open(f).convert("RGB"))
+                m = M.MythTracer()
+                assert m.load_obj(str(tmp_path / "m.obj")), ("progressive", w, h, mode, sub, q)
+                tex = m.flatten()["textures"][0]["texels"]
+                assert tex.dtype == np.uint8 and np.array_equal(tex, want), ("progressive", w, h, mode, sub, q, extra)
+                checked += 1
+    assert checked == 8 * 2 * 6
+    # truncated headers and other damage are refused, not guessed at
     PIL_Image.fromarray(noise).save(f, "JPEG")
     good = f.read_bytes()
     sof = good.index(b"\xff\xc0")
