@@ -1758,13 +1758,19 @@ struct TraceOut {
 
 };
 
-// NOT inlined on purpose: as a function of its own the traversal gets its own
-// register allocation, free of the shading kernel's SGPR/VGPR pressure.  It
-// takes ONE pointer to the scene description in device memory (read with
-// scalar loads) and returns its result in registers: nothing goes through the
-// stack.  Must be called by all 64 lanes (want = false for lanes without a ray).
+// It takes ONE pointer to the scene description in device memory (read with scalar loads) and returns its result in
+// registers.  Must be called by all 64 lanes (want = false for lanes without a ray).
+// Inlined into every engine since round 4 (-DMT_TRACE_CALL builds it as a function again): as a call it had its own
+// register allocation, but every pass saved and restored 39 callee-saved registers through scratch -- 1.7 GB written
+// and read per 1080p frame, nearly all of the frame kernel's memory-side traffic -- for a frame 1 % SLOWER (4.91
+// against 4.86 ms warm, 4.96 against 4.90 panning).
+#ifdef MT_TRACE_CALL
+#define MT_TRACE_ATTR __attribute__((noinline))
+#else
+#define MT_TRACE_ATTR __forceinline__
+#endif
 template <bool STATS>
-__device__ __attribute__((noinline)) TraceOut trace_wave(const DevScene *scene, unsigned stack_base, int lane,
+__device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned stack_base, int lane,
                                                          bool want_all, double ox, double oy, double oz,
                                                          double dx, double dy, double dz) {
   const MT_CONST DevScene *G = as_const(uniform_ptr(scene));
