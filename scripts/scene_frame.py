@@ -14,6 +14,8 @@ m = M.MythTracer(info["obj"])
 lib = os.environ.get("LIB")
 abi = M.HipAbi(os.path.join(ROOT, "mythtracer_amd", "lib", "libmythtracer_hip_%s.so" % lib)) if lib else M.hip_abi()
 h = abi.scene_create(m.flatten()); abi.set_lights(h, sg.ROOM_LIGHTS); abi.set_stats(h, False)
+for kv in [x for x in os.environ.get("TUNE", "").split(",") if x]:
+    abi.set_tuning(h, kv.split("=")[0], float(kv.split("=")[1]))
 W, H = 1920, 1080
 frames = json.load(open(os.path.join(ROOT, "tests", "golden", "frames.json")))
 gold = frames.get("%s_%dx%d_d5" % (scene, W, H), {}).get("sha256")

@@ -11,7 +11,7 @@ os.environ["MT_DEBUG_ITEM_CYCLES"] = out
 import mythtracer_amd as M
 from mythtracer_amd import scenegen as sg, binding, tiling
 torch.zeros(1, device="cuda")
-info = sg.write_scene("room", "/tmp/mt_scenes")
+info = sg.write_scene(os.environ.get("SCENE", "room"), "/tmp/mt_scenes")
 m = M.MythTracer(info["obj"])
 abi = M.HipAbi(os.path.join(ROOT, "mythtracer_amd", "lib", "libmythtracer_hip_knobs.so")); h = abi.scene_create(m.flatten()); abi.set_lights(h, sg.ROOM_LIGHTS); abi.set_stats(h, False)
 abi.set_engine(h, int(os.environ.get("ENGINE", "3")))
