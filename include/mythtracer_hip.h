@@ -351,6 +351,8 @@ enum {
   MT_TUNE_FORECAST_STEP,      /* pixels between the positions a re-projected forecast takes its maximum over (8) */
   MT_TUNE_HYBRID_STARTER_SHARE, /* engine 3: state-machine units above this share of an even split start with the launch,
                                    on waves that skip the pool's part (0.33; a value above every unit = none) */
+  MT_TUNE_DEEP_LAYOUT,        /* 1 (default): octrees of 12 .. 16 levels keep only the first ten levels' traversal frames in LDS
+                                 (the rest in global memory: 8 waves per CU instead of 7 .. 5); 0: everything in LDS */
   MT_TUNE_MULTI_FORCE_PEER_COPY, /* tests: mt_render_frame_multi copies every replica's tiles into the gather buffer with
                                     hipMemcpyPeerAsync even when it shares the first replica's device (0) */
   MT_TUNE_MULTI_BALANCE,      /* mt_render_frame_multi: 1 (default) = tiles dealt out by cost, 0 = by tile number */

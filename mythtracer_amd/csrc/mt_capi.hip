@@ -82,6 +82,7 @@ struct Tuning {
     v[MT_TUNE_FORECAST_STEP] = 8.0;       // pixels between the old-image positions a re-projected forecast takes its maximum over
     v[MT_TUNE_HYBRID_WORK1] = 1.3; v[MT_TUNE_HYBRID_WORK2] = 2.6;  // pool quarters / cells: summed cost over the state machine's whole-block cost
     v[MT_TUNE_HYBRID_STARTER_SHARE] = 0.33;  // hybrid launches: state-machine units above this share of an even split start with the launch (hybrid_kernel)
+    v[MT_TUNE_DEEP_LAYOUT] = 1.0;
     v[MT_TUNE_MULTI_FORCE_PEER_COPY] = 0.0;
     v[MT_TUNE_MULTI_BALANCE] = 1.0;
   }
@@ -135,6 +136,9 @@ struct mt_scene {
   std::vector<mt_light> lights_host;  // what d_lights holds
   int forecasts_in_a_row = 0;  // launches with this geometry and camera whose work order came from a forecast
   int waves_per_block = 4;
+  bool deep = false;               // the DEEP instantiations of the kernels (mt_device.h, kDeepFromDepth)
+  char *d_deep = nullptr;          // their per-wave areas
+  size_t deep_bytes = 0;
   size_t lds_bytes = 0;
   int grid_blocks = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -228,7 +232,8 @@ bool finite3(const double *p, size_t n) {
 // frames (27 KB per wave at 16 levels) let one 4-wave workgroup fill two thirds of the LDS and leave room for a fifth
 // wave only as a workgroup of its own.
 int configure_launch(mt_scene *s) {
-  const size_t per_wave = wave_stack_bytes(s->dev.tree_depth, s->dev.pack_shift != 0);
+  s->deep = deep_layout(s->dev.tree_depth) && s->tune.v[MT_TUNE_DEEP_LAYOUT] != 0.0;
+  const size_t per_wave = wave_stack_bytes(s->dev.tree_depth, s->dev.pack_shift != 0, s->deep);
   if (per_wave > kLdsBudget) {
     return fail(MT_ERR_UNSUPPORTED, "octree depth %d needs %zu B of LDS per wave (> %zu)",
                 s->dev.tree_depth, per_wave, kLdsBudget);
@@ -241,11 +246,16 @@ int configure_launch(mt_scene *s) {
     std::lock_guard<std::mutex> lock(mu);
     size_t &have = lds_attr[s->device];
     if (bytes > have) {
-      const void *kernels[] = {(const void *)render_kernel<true>, (const void *)render_kernel<false>,
-                               (const void *)primary_kernel<true>, (const void *)primary_kernel<false>,
-                               (const void *)pool_kernel<true>, (const void *)pool_kernel<false>,
-                               (const void *)hybrid_kernel<true>, (const void *)hybrid_kernel<false>,
-                               (const void *)probe_kernel, (const void *)intersect_kernel};
+      const void *kernels[] = {(const void *)render_kernel<true, false>, (const void *)render_kernel<false, false>,
+                               (const void *)primary_kernel<true, false>, (const void *)primary_kernel<false, false>,
+                               (const void *)pool_kernel<true, false>, (const void *)pool_kernel<false, false>,
+                               (const void *)hybrid_kernel<true, false>, (const void *)hybrid_kernel<false, false>,
+                               (const void *)probe_kernel<false>, (const void *)intersect_kernel<false>,
+                               (const void *)render_kernel<true, true>, (const void *)render_kernel<false, true>,
+                               (const void *)primary_kernel<true, true>, (const void *)primary_kernel<false, true>,
+                               (const void *)pool_kernel<true, true>, (const void *)pool_kernel<false, true>,
+                               (const void *)hybrid_kernel<true, true>, (const void *)hybrid_kernel<false, true>,
+                               (const void *)probe_kernel<true>, (const void *)intersect_kernel<true>};
       for (const void *k : kernels) {
         HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       }
@@ -259,7 +269,7 @@ int configure_launch(mt_scene *s) {
     int rc = set_attribute(per_wave * wpb);
     if (rc != MT_OK) return rc;
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)render_kernel<true>, wpb * 64, per_wave * wpb));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, s->deep ? (const void *)render_kernel<true, true> : (const void *)render_kernel<true, false>, wpb * 64, per_wave * wpb));
     if (per_cu < 1) per_cu = 1;
     if (per_cu * wpb > 16) per_cu = 16 / wpb;  // more waves only add divergence state
     if (per_cu * wpb > best_per_cu * best_wpb) {  // (ties: the larger workgroup, tried first)
@@ -285,6 +295,34 @@ int ensure_bytes(void **ptr, size_t *have, size_t need) {
   *have = 0;
   HIP_TRY(hipMalloc(ptr, need ? need : 1));
   *have = need;
+  return MT_OK;
+}
+
+// launches kernel<STATS, DEEP> (or kernel<DEEP>) for the scene's layout
+#define MT_LAUNCH_SD(kernel, stats, grid_, block_, lds_, stream_, ...)                                              \
+  do {                                                                                                                \
+    if (s->deep) {                                                                                                    \
+      if (stats) hipLaunchKernelGGL((kernel<true, true>), grid_, block_, lds_, stream_, __VA_ARGS__);                 \
+      else hipLaunchKernelGGL((kernel<false, true>), grid_, block_, lds_, stream_, __VA_ARGS__);                      \
+    } else {                                                                                                          \
+      if (stats) hipLaunchKernelGGL((kernel<true, false>), grid_, block_, lds_, stream_, __VA_ARGS__);                \
+      else hipLaunchKernelGGL((kernel<false, false>), grid_, block_, lds_, stream_, __VA_ARGS__);                     \
+    }                                                                                                                 \
+  } while (0)
+#define MT_LAUNCH_D(kernel, grid_, block_, lds_, stream_, ...)                                                      \
+  do {                                                                                                                \
+    if (s->deep) hipLaunchKernelGGL((kernel<true>), grid_, block_, lds_, stream_, __VA_ARGS__);                       \
+    else hipLaunchKernelGGL((kernel<false>), grid_, block_, lds_, stream_, __VA_ARGS__);                              \
+  } while (0)
+
+// the per-wave global areas of the DEEP instantiations, for a launch of `waves` waves
+int ensure_deep(mt_scene *s, size_t waves) {
+  if (!s->deep) return MT_OK;
+  const size_t stride = (wave_deep_bytes(s->dev.tree_depth) + 255) & ~(size_t)255;
+  int rc = ensure_bytes((void **)&s->d_deep, &s->deep_bytes, stride * waves);
+  if (rc != MT_OK) return rc;
+  s->dev.deep_base = s->d_deep;
+  s->dev.deep_stride = stride;
   return MT_OK;
 }
 
@@ -476,6 +514,11 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   HIP_TRY(hipMemsetAsync(s->d_work, 0, 16 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
+  {  // (the probe's grid follows the number of blocks: 16 of them per wave)
+    const size_t probe_waves = ((size_t)4 * P.n_items + block.x - 1) / block.x * s->waves_per_block;
+    int rc = ensure_deep(s, std::max(waves, probe_waves));
+    if (rc != MT_OK) return rc;
+  }
   HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
   // events: [0] -> [1] forecast / classification + work order; [1] -> [2] the frame kernel
   hipEvent_t *ek = s->ev_k[s->launches_timed % mt_scene::kTimedLaunches];
@@ -522,8 +565,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   s->forecasts_in_a_row = (history && !reproject && !from_map && s->last_engine == engine) ? s->forecasts_in_a_row + 1 : 0;
   if (pool_engine) {
     if (!history) {
-      hipLaunchKernelGGL(probe_kernel, dim3((4 * P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream,
-                         s->dev, P);
+      MT_LAUNCH_D(probe_kernel, dim3((4 * P.n_items + block.x - 1) / block.x), block, s->lds_bytes, stream, s->dev, P);
       HIP_TRY(hipGetLastError());
     }
     // blocks above cut_share of an even split of the frame are handed out in pieces
@@ -541,11 +583,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
                        s->grid_blocks * s->waves_per_block, sp);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ek[1], stream));
-    if (s->stats_enabled) {
-      hipLaunchKernelGGL(pool_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
-    } else {
-      hipLaunchKernelGGL(pool_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
-    }
+    MT_LAUNCH_SD(pool_kernel, s->stats_enabled, grid, block, s->lds_bytes, stream, s->dev, P);
   } else {
     if (history) {
       // blocks above this share of an even split are cut into quarters; a re-projected forecast (moving camera) is
@@ -574,20 +612,15 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
         hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
                            s->grid_blocks * s->waves_per_block, quad_share, quad_keep);
       }
-    } else if (s->stats_enabled) {
-      hipLaunchKernelGGL(primary_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
     } else {
-      hipLaunchKernelGGL(primary_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
+      MT_LAUNCH_SD(primary_kernel, s->stats_enabled, grid, block, s->lds_bytes, stream, s->dev, P);
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ek[1], stream));
     if (hybrid) {
-      if (s->stats_enabled) hipLaunchKernelGGL(hybrid_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
-      else hipLaunchKernelGGL(hybrid_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
-    } else if (s->stats_enabled) {
-      hipLaunchKernelGGL(render_kernel<true>, grid, block, s->lds_bytes, stream, s->dev, P);
+      MT_LAUNCH_SD(hybrid_kernel, s->stats_enabled, grid, block, s->lds_bytes, stream, s->dev, P);
     } else {
-      hipLaunchKernelGGL(render_kernel<false>, grid, block, s->lds_bytes, stream, s->dev, P);
+      MT_LAUNCH_SD(render_kernel, s->stats_enabled, grid, block, s->lds_bytes, stream, s->dev, P);
     }
   }
   HIP_TRY(hipEventRecord(ek[2], stream));
@@ -721,6 +754,7 @@ void mt_scene_destroy(mt_scene *s) {
     if (e) (void)hipEventDestroy(e);
   }
   if (s->h_counters) (void)hipHostFree(s->h_counters);
+  if (s->d_deep) (void)hipFree(s->d_deep);
   if (s->d_tile_list) (void)hipFree(s->d_tile_list);
   if (s->d_tile_slot) (void)hipFree(s->d_tile_slot);
   if (s->d_tile_cost) (void)hipFree(s->d_tile_cost);
@@ -1291,7 +1325,7 @@ int mt_scene_set_tuning(mt_scene *s, int knob, double value) {
   }
   s->tune.v[knob] = value;
   s->cost_signature = 0;  // other constants, other order: start from a first frame
-  if (knob == MT_TUNE_PACKED_STACK || knob == MT_TUNE_BLOCKS_PER_CU) {
+  if (knob == MT_TUNE_PACKED_STACK || knob == MT_TUNE_BLOCKS_PER_CU || knob == MT_TUNE_DEEP_LAYOUT) {
     if (knob == MT_TUNE_PACKED_STACK) {
       int tri_bits = 1;
       while (tri_bits < 31 && ((long long)s->dev.n_tris + 1) > (1ll << tri_bits)) tri_bits++;
@@ -1895,11 +1929,19 @@ int mt_intersect_rays(mt_scene *s, int n, const double *rays, int32_t *tri, int3
   TRY_OR_CLEAN(hipMemcpy(d_rays, rays, (size_t)n * 48, hipMemcpyHostToDevice));
   TRY_OR_CLEAN(hipMemset(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long)));
   const int block = s->waves_per_block * 64;
-  const int grid = (n + block - 1) / block;
+  // (DEEP layout: every wave of a launch has an area of global memory -- batches of at most 128 K rays per launch)
+  const int per_launch = s->deep ? (n < (1 << 17) ? n : (1 << 17)) : n;
+  if ((rc = ensure_deep(s, (size_t)((per_launch + block - 1) / block) * s->waves_per_block)) != MT_OK) {
+    cleanup();
+    return rc;
+  }
   TRY_OR_CLEAN(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, nullptr));
   TRY_OR_CLEAN(hipEventRecord(s->ev0, nullptr));
-  hipLaunchKernelGGL(intersect_kernel, dim3(grid), dim3(block), s->lds_bytes, nullptr, s->dev, n,
-                     d_rays, d_tri, d_line, d_t, d_point, s->d_counters);
+  for (int at = 0; at < n; at += per_launch) {
+    const int m = n - at < per_launch ? n - at : per_launch;
+    MT_LAUNCH_D(intersect_kernel, dim3((m + block - 1) / block), dim3(block), s->lds_bytes, nullptr, s->dev, m,
+                d_rays + (size_t)at * 6, d_tri + at, d_line + at, d_t + at, d_point + (size_t)at * 3, s->d_counters);
+  }
   TRY_OR_CLEAN(hipGetLastError());
   TRY_OR_CLEAN(hipEventRecord(s->ev1, nullptr));
   TRY_OR_CLEAN(hipDeviceSynchronize());

@@ -139,6 +139,9 @@ struct DevScene {
   volatile unsigned long long *hb;
   // Phase profile (only in the -DMT_PROF build): cycle and event sums.
   unsigned long long *prof;
+  // DEEP instantiations: per-wave areas of global memory for what does not stay in LDS (wave_deep_bytes)
+  char *deep_base;
+  unsigned long long deep_stride;
   // Copy of this struct in device memory (refreshed before every launch): the
   // non-inlined traversal takes this one pointer instead of a by-value struct.
   const DevScene *self;
@@ -253,7 +256,20 @@ __device__ __forceinline__ int slot_of_tile(const RenderParams &P, int t) {
 #define MT_HS_MAX_DEPTH 16  // (-DMT_HS_MAX_DEPTH=15: what does the ordered descent cost on a tree the walk would take?  profiles/README.md)
 #endif
 constexpr int kHsMaxDepth = MT_HS_MAX_DEPTH;
-__host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
+// DEEP trees (round 4).  This kernel's throughput goes with the waves a CU holds (the room scene at 4 instead of 8 waves
+// per CU: 1.8 times the frame time), and from 12 levels on the frames above leave room for 7, 6, at 16 levels for 5.
+// The DEEP instantiations of the kernels (octrees of kDeepFromDepth .. kHsMaxDepth levels) keep only the walk's frames
+// of the first kHsLdsLevels levels in LDS -- where nearly all of a walk's steps happen -- and put the deeper levels'
+// frames and the whole stack of the ordered descent (irregular rays only, in such trees) into a per-wave area of
+// global memory (DevScene::deep_base): 19 KB of LDS per wave whatever the depth, 8 waves per CU.
+constexpr int kHsLdsLevels = 10;
+constexpr int kDeepFromDepth = 12;
+__host__ __device__ inline bool deep_layout(int depth) { return depth >= kDeepFromDepth && depth <= kHsMaxDepth; }
+__host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed, bool deep = false) {
+  if (deep) {
+    const int lf = depth - 1 < kHsLdsLevels ? depth - 1 : kHsLdsLevels;
+    return (((size_t)lf * 64 * 24 + (size_t)(depth - 1) * 8 + 15) & ~(size_t)15) + 2 * sizeof(HsRec) + (size_t)(depth - 1) * 80;
+  }
   size_t n = (size_t)depth * 64 * (packed ? 16 : 20);
   if (depth <= kHsMaxDepth && depth > 1) {
     // frames, (node, first child) per level, room for two staged records (16-byte aligned), per level the nine
@@ -263,9 +279,15 @@ __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed) {
   }
   return n;
 }
-__host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed) {
-  size_t n = wave_frames_bytes(depth, packed) + 64 * 24;  // the fp32 boxes of a short list: (kHsShortList / 4) quads of 144 bytes = 1 152 (the counters are in registers)
+__host__ __device__ inline size_t wave_stack_bytes(int depth, bool packed, bool deep = false) {
+  size_t n = wave_frames_bytes(depth, packed, deep) + 64 * 24;  // the fp32 boxes of a short list: (kHsShortList / 4) quads of 144 bytes = 1 152 (the counters are in registers)
   return n;
+}
+// bytes of a wave's area in global memory (DEEP instantiations): the ordered descent's stack, 20 bytes per lane and
+// level, then the walk's frames of the levels from kHsLdsLevels on, 24 bytes per lane and level
+__host__ __device__ inline size_t wave_deep_bytes(int depth) {
+  const int ld = depth - 1 > kHsLdsLevels ? depth - 1 - kHsLdsLevels : 0;
+  return (size_t)depth * 64 * 20 + (size_t)ld * 64 * 24;
 }
 
 constexpr int kFrameSlots = 11;  // throughput engine: 10 doubles + 1 packed meta word per recursion frame

@@ -158,12 +158,13 @@ __device__ __forceinline__ void pool_flush_item_stats(LaneStats &st, unsigned lo
 // block misses the rims of the glass spheres: those blocks then run late and
 // whole, and the first frame took 21 ms instead of 14.)  The forecast only
 // orders the work; nothing computed for a pixel depends on it.
+template <bool DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void probe_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP);
   const unsigned sample = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned item = sample >> 2;
   const int which = (int)(sample & 3u);
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void probe_kernel(DevScene 
                  (v3_load(P.sensor.delta_pixel) * (double)g.px);
     rd = normalized(d);
   }
-  const TraceOut to = trace_wave<false>(S.self, stk.base, lane, want, cam_origin.x, cam_origin.y, cam_origin.z,
+  const TraceOut to = trace_wave<false, DEEP>(S.self, stk.base, lane, want, cam_origin.x, cam_origin.y, cam_origin.z,
                                         rd.x, rd.y, rd.z);
   if (to.status != DEV_OK && lane == 0) atomicMax(P.counters + ST_STATUS, (unsigned long long)to.status);
   // Forecast in the unit of the measured costs (64 s_memtime ticks): passes
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
 // failure.
 constexpr unsigned kCarryNone = 0xffffffffu, kCarryDone = 0xfffffffeu, kCarryFail = 0xfffffffdu;
 constexpr int kHybridPoolSub = 32;
-template <bool STATS, bool MIXED>
+template <bool STATS, bool MIXED, bool DEEP>
 __device__ __forceinline__ unsigned pool_engine(const DevScene &S, const RenderParams &P, unsigned carry) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -320,7 +321,7 @@ __device__ __forceinline__ unsigned pool_engine(const DevScene &S, const RenderP
   const int waves_per_block = blockDim.x >> 6;
   const int wave_id = blockIdx.x * waves_per_block + wave_in_block;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP);
 
   // this wave's scratch: records, pool (a stack of entries), free list (a stack of record numbers)
   const int n_lights = S.n_lights;
@@ -464,7 +465,7 @@ __device__ __forceinline__ unsigned pool_engine(const DevScene &S, const RenderP
 #ifdef MT_DIAG
       const unsigned long long diag_tt0 = __builtin_amdgcn_s_memtime();
 #endif
-      const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, active, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+      const TraceOut to = trace_wave<STATS, DEEP>(S.self, stk.base, lane, active, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
       add_trace_stats<STATS>(st, to);
 #ifdef MT_DIAG
       diag_trace_ticks += __builtin_amdgcn_s_memtime() - diag_tt0;
@@ -813,9 +814,9 @@ __device__ __forceinline__ unsigned pool_engine(const DevScene &S, const RenderP
   return result;
 }
 
-template <bool STATS>
+template <bool STATS, bool DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void pool_kernel(DevScene S, RenderParams P) {
-  (void)pool_engine<STATS, false>(S, P, kCarryNone);
+  (void)pool_engine<STATS, false, DEEP>(S, P, kCarryNone);
   if (S.hb && (threadIdx.x & 63) == 0) S.hb[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + 0] = 5;
 }
 

@@ -146,13 +146,13 @@ __device__ __forceinline__ void flush_item_stats(LaneStats &st, unsigned long lo
 // materials it sees, so that launch 2 can start with the expensive blocks:
 //   class 2: some pixel hit a transparent material (deep refraction trees),
 //   class 1: some pixel hit a reflective one, class 0: everything else.
-template <bool STATS>
+template <bool STATS, bool DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP);
   const MT_CONST mt_material *mtls = as_const(S.mtls);
   LaneStats st;
   st.clear();
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScen
     }
     int prim;
     double t;
-    const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, g.inside, cam_origin.x, cam_origin.y,
+    const TraceOut to = trace_wave<STATS, DEEP>(S.self, stk.base, lane, g.inside, cam_origin.x, cam_origin.y,
                                           cam_origin.z, rd.x, rd.y, rd.z);
     add_trace_stats<STATS>(st, to);
     prim = to.prim;
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(kSchedThreads) void hybrid_schedule_kernel(RenderPa
 // pixel, i.e. with the pixel's shadow loops running side by side.)
 // sm_engine is the body shared by render_kernel and hybrid_kernel (below); `carry` and the return value as for
 // pool_engine (mt_pool.h).
-template <bool STATS, bool MIXED>
+template <bool STATS, bool MIXED, bool DEEP>
 __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderParams &P, unsigned carry) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -654,7 +654,7 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
   const int waves_per_block = blockDim.x >> 6;
   const int wave_id = blockIdx.x * waves_per_block + wave_in_block;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP);
   FrameIO fio;
   fio.base = P.frames + (size_t)wave_id * (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64;
   fio.park = P.frames + (size_t)gridDim.x * waves_per_block * (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64 +
@@ -782,7 +782,7 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
 #ifdef MT_DIAG
         const unsigned long long diag_tt0 = __builtin_amdgcn_s_memtime();
 #endif
-        const TraceOut to = trace_wave<STATS>(S.self, stk.base, lane, tracing, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
+        const TraceOut to = trace_wave<STATS, DEEP>(S.self, stk.base, lane, tracing, ro.x, ro.y, ro.z, rd.x, rd.y, rd.z);
 #ifdef MT_DIAG
         asm volatile("" :: "v"(to.prim));
         diag_trace_ticks += __builtin_amdgcn_s_memtime() - diag_tt0;
@@ -1125,9 +1125,9 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
   return result;
 }
 
-template <bool STATS>
+template <bool STATS, bool DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene S, RenderParams P) {
-  (void)sm_engine<STATS, false>(S, P, kCarryNone);
+  (void)sm_engine<STATS, false, DEEP>(S, P, kCarryNone);
 }
 
 // The HYBRID frame kernel (engine 3): the work order starts with the longest blocks, cut into pieces for the ray
@@ -1141,17 +1141,18 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
 // machine has units expected to take more than a third of an even share -- skip the pool's part: the state machine's
 // longest blocks start with the launch instead of behind the pool's part (which lasts a quarter of a rank's share of
 // the 4K frame at N = 8; a block of 26-32 passes that starts there ends 20-30 % after everybody else).
-template <bool STATS>
+template <bool STATS, bool DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void hybrid_kernel(DevScene S, RenderParams P) {
   const bool starter = (threadIdx.x >> 6) == (blockDim.x >> 6) - 1 && blockIdx.x < P.n_work[2];  // (the last wave of a workgroup)
   if (!starter) {
-    if (pool_engine<STATS, true>(S, P, kCarryNone) == kCarryFail) return;  // a device-side bound tripped (status is set)
+    if (pool_engine<STATS, true, DEEP>(S, P, kCarryNone) == kCarryFail) return;  // a device-side bound tripped (status is set)
   }
-  (void)sm_engine<STATS, true>(S, P, kCarryNone);
+  (void)sm_engine<STATS, true, DEEP>(S, P, kCarryNone);
 }
 
 // OctTree::IntersectRay for a batch of arbitrary rays: lane i of the grid
 // traces ray i.
+template <bool DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void intersect_kernel(DevScene S, int n, const double *rays,
                                                         int *out_tri, int *out_line,
                                                         double *out_t, double *out_point,
@@ -1160,7 +1161,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void intersect_kernel(DevSc
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool want = i < n;
   double o[3] = {0, 0, 0}, d[3] = {0, 0, 1};
@@ -1174,7 +1175,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void intersect_kernel(DevSc
   st.clear();
   int prim;
   double t;
-  const TraceOut to = trace_wave<true>(S.self, stk.base, lane, want, o[0], o[1], o[2], d[0], d[1], d[2]);
+  const TraceOut to = trace_wave<true, DEEP>(S.self, stk.base, lane, want, o[0], o[1], o[2], d[0], d[1], d[2]);
   add_trace_stats<true>(st, to);
   prim = to.prim;
   t = to.t;
@@ -1224,13 +1225,19 @@ __global__ void blit_tiles_kernel(int image_w, int image_h, int tile_w, int tile
   }
 }
 
-template __global__ void render_kernel<true>(DevScene, RenderParams);
-template __global__ void render_kernel<false>(DevScene, RenderParams);
-template __global__ void primary_kernel<true>(DevScene, RenderParams);
-template __global__ void primary_kernel<false>(DevScene, RenderParams);
-template __global__ void pool_kernel<true>(DevScene, RenderParams);
-template __global__ void pool_kernel<false>(DevScene, RenderParams);
-template __global__ void hybrid_kernel<true>(DevScene, RenderParams);
-template __global__ void hybrid_kernel<false>(DevScene, RenderParams);
+#define MT_INSTANTIATE(DEEP_)                                                                    \
+  template __global__ void render_kernel<true, DEEP_>(DevScene, RenderParams);                   \
+  template __global__ void render_kernel<false, DEEP_>(DevScene, RenderParams);                  \
+  template __global__ void primary_kernel<true, DEEP_>(DevScene, RenderParams);                  \
+  template __global__ void primary_kernel<false, DEEP_>(DevScene, RenderParams);                 \
+  template __global__ void pool_kernel<true, DEEP_>(DevScene, RenderParams);                     \
+  template __global__ void pool_kernel<false, DEEP_>(DevScene, RenderParams);                    \
+  template __global__ void hybrid_kernel<true, DEEP_>(DevScene, RenderParams);                   \
+  template __global__ void hybrid_kernel<false, DEEP_>(DevScene, RenderParams);                  \
+  template __global__ void probe_kernel<DEEP_>(DevScene, RenderParams);                          \
+  template __global__ void intersect_kernel<DEEP_>(DevScene, int, const double *, int *, int *, double *, double *, unsigned long long *);
+MT_INSTANTIATE(false)
+MT_INSTANTIATE(true)
+#undef MT_INSTANTIATE
 
 }  // namespace mt

@@ -48,6 +48,7 @@
 // visited node and its tie-breaking (later equal-distance hit wins,
 // octtree.cc:186-195) is reproduced literally.
 #pragma once
+#include <type_traits>
 #include "mt_device.h"
 
 namespace mt {
@@ -219,11 +220,11 @@ struct WaveStack {
   __device__ __forceinline__ MT_LDS unsigned *ord() const {
     return (MT_LDS unsigned *)(uintptr_t)(base + (unsigned)depth * 64u * (pack_shift ? 12u : 16u));
   }
-  __device__ __forceinline__ void bind(char *smem_base, int wave_in_block, int tree_depth, int shift) {
+  __device__ __forceinline__ void bind(char *smem_base, int wave_in_block, int tree_depth, int shift, bool deep = false) {
     (void)smem_base;  // dynamic LDS starts at offset 0 of the block's allocation (no static LDS is declared)
     depth = tree_depth;
     pack_shift = shift;
-    base = (unsigned)wave_in_block * (unsigned)wave_stack_bytes(tree_depth, shift != 0);
+    base = (unsigned)wave_in_block * (unsigned)wave_stack_bytes(tree_depth, shift != 0, deep);
   }
 };
 
@@ -1147,6 +1148,51 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
       }
     }
   } else {
+    // Two shortcuts that the literal sort below would arrive at too (round 4: these rays' units are the longest of
+    // the frame, and the literal sort was half of their node steps):
+    //   * no key of an entered child is NaN: the insertion sort is stable and `<` is a strict weak order on the keys
+    //     (+-inf included, -0 == +0), so the result is the order by (tmin, index) -- rank counting;
+    //   * EVERY entered child's key is NaN (a ray with one zero direction component whose origin lies ON a plane of
+    //     the node: the children on the NaN side pass, the others fail outright): `vd < x` and `x < vd` are false for
+    //     every pair, nothing ever moves: the children stay in index order.
+    // Keys of both kinds together (two zero components) take the literal sort.
+    bool any_nan = false, all_nan = true;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      const bool isn = tm[c] != tm[c];
+      any_nan = any_nan || (valid[c] && isn);
+      all_nan = all_nan && (!valid[c] || isn);
+    }
+    if (!any_nan || all_nan) {
+      unsigned rank[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) rank[c] = 0;
+      if (!any_nan) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+          for (int j = i + 1; j < 8; j++) {
+            const bool both = valid[i] && valid[j];
+            const bool j_first = tm[j] < tm[i];
+            rank[i] += (both && j_first) ? 1u : 0u;
+            rank[j] += (both && !j_first) ? 1u : 0u;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+          for (int j = i + 1; j < 8; j++) rank[j] += (valid[i] && valid[j]) ? 1u : 0u;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        if (valid[c]) {
+          ord |= (unsigned)c << (3 * rank[c]);
+          cnt++;
+        }
+      }
+    } else {
     // libstdc++ std::sort on <= 16 elements is __insertion_sort; restated
     // literally (front-rotate branch and unguarded linear insert) so that NaN
     // keys land where the reference puts them.
@@ -1187,7 +1233,8 @@ __device__ __forceinline__ unsigned order_children(const MT_CONST NodeRec *N, co
 #pragma unroll
     for (int j = 0; j < 8; j++) ord |= (si[j] & 7u) << (3 * j);
     cnt = m;
-    // entries >= m are zero-filled garbage; they are never read (pos < cnt)
+    }
+    // entries >= cnt are zero-filled garbage; they are never read (pos < cnt)
     if (keep != 0xffu) {
       // With NaN keys the insertion sort's outcome depends on every element
       // that takes part, so skipped children are taken out AFTER the sort.
@@ -1769,7 +1816,7 @@ struct TraceOut {
 #else
 #define MT_TRACE_ATTR __forceinline__
 #endif
-template <bool STATS>
+template <bool STATS, bool DEEP = false>
 __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned stack_base, int lane,
                                                          bool want_all, double ox, double oy, double oz,
                                                          double dx, double dy, double dz) {
@@ -1809,11 +1856,30 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
   stk.base = (unsigned)uniform_i32((int)stack_base);
   stk.depth = S.tree_depth;
   stk.pack_shift = S.pack_shift;
-  MT_LDS double *const stk_bt = stk.bt();
-  MT_LDS int *const stk_fc = stk.fc();
-  MT_LDS int *const stk_bp = stk.bp();
-  MT_LDS unsigned *const stk_ord = stk.ord();
-  const unsigned frames_end = stk.base + (unsigned)wave_frames_bytes(stk.depth, stk.pack_shift != 0);
+  // the ordered descent's stack: in LDS, or (DEEP) in this wave's area of global memory
+  char *deep_area = nullptr;
+  if constexpr (DEEP) {
+    const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    deep_area = uniform_ptr(G->deep_base + (size_t)wave_global * G->deep_stride);
+  }
+  using BtPtr = typename std::conditional<DEEP, double *, MT_LDS double *>::type;
+  using IPtr = typename std::conditional<DEEP, int *, MT_LDS int *>::type;
+  using UPtr = typename std::conditional<DEEP, unsigned *, MT_LDS unsigned *>::type;
+  BtPtr stk_bt;
+  IPtr stk_fc, stk_bp;
+  UPtr stk_ord;
+  if constexpr (DEEP) {
+    stk_bt = (double *)deep_area;
+    stk_fc = (int *)(deep_area + (size_t)stk.depth * 64 * 8);
+    stk_bp = (int *)(deep_area + (size_t)stk.depth * 64 * 12);
+    stk_ord = (unsigned *)(deep_area + (size_t)stk.depth * 64 * 16);
+  } else {
+    stk_bt = stk.bt();
+    stk_fc = stk.fc();
+    stk_bp = stk.bp();
+    stk_ord = stk.ord();
+  }
+  const unsigned frames_end = stk.base + (unsigned)wave_frames_bytes(stk.depth, stk.pack_shift != 0, DEEP);
   unsigned cntr[5] = {0u, 0u, 0u, 0u, 0u};  // per-lane work counters of this traversal (STATS only)
   (void)cntr;
   const int pack_shift = stk.pack_shift;  // wave-uniform
@@ -1993,11 +2059,25 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
       S.bmax[0] <= 0x1p200 && S.bmax[1] <= 0x1p200 && S.bmax[2] <= 0x1p200 && __ballot(want && !tame) == 0ull) {
     hs_done = true;
     const int L = S.tree_depth > 1 ? S.tree_depth - 1 : 0;  // levels that can hold a node with children
-    MT_LDS double *const h_own_t = (MT_LDS double *)(uintptr_t)stk.base;  // [L][64] own list's best distance
-    MT_LDS double *const h_win_t = h_own_t + L * 64;                       // [L][64] best child candidate so far
-    MT_LDS int *const h_own_p = (MT_LDS int *)(h_win_t + L * 64);          // [L][64] own best triangle, -1 none
-    MT_LDS int *const h_win_p = h_own_p + L * 64;                          // [L][64] candidate triangle | child slot << 28, -1 none
-    MT_LDS int *const h_node = h_win_p + L * 64;                           // [L][2] (layout only; the values live in lane_node / lane_fc)
+    const int Lf = (DEEP && L > kHsLdsLevels) ? kHsLdsLevels : L;  // ... whose frames are in LDS (DEEP: the others in deep_area)
+    MT_LDS double *const h_own_t = (MT_LDS double *)(uintptr_t)stk.base;  // [Lf][64] own list's best distance
+    MT_LDS double *const h_win_t = h_own_t + Lf * 64;                      // [Lf][64] best child candidate so far
+    MT_LDS int *const h_own_p = (MT_LDS int *)(h_win_t + Lf * 64);         // [Lf][64] own best triangle, -1 none
+    MT_LDS int *const h_win_p = h_own_p + Lf * 64;                         // [Lf][64] candidate triangle | child slot << 28, -1 none
+    MT_LDS int *const h_node = h_win_p + Lf * 64;                          // [L][2] (layout only; the values live in lane_node / lane_fc)
+    // the frames of the levels from kHsLdsLevels on (DEEP): behind the descent's stack in the wave's global area
+    double *g_own_t = nullptr, *g_win_t = nullptr;
+    int *g_own_p = nullptr, *g_win_p = nullptr;
+    if constexpr (DEEP) {
+      const int Ld = L > kHsLdsLevels ? L - kHsLdsLevels : 0;
+      g_own_t = (double *)(deep_area + (size_t)stk.depth * 64 * 20);
+      g_win_t = g_own_t + Ld * 64;
+      g_own_p = (int *)(g_win_t + Ld * 64);
+      g_win_p = g_own_p + Ld * 64;
+    }
+    (void)g_own_t; (void)g_win_t; (void)g_own_p; (void)g_win_p;
+#define HS_LD(aL, aG, l) ((DEEP && (l) >= kHsLdsLevels) ? (aG)[((l) - kHsLdsLevels) * 64 + lane] : (aL)[(l) * 64 + lane])
+#define HS_ST(aL, aG, l, v) do { if (DEEP && (l) >= kHsLdsLevels) (aG)[((l) - kHsLdsLevels) * 64 + lane] = (v); else (aL)[(l) * 64 + lane] = (v); } while (0)
     // wave-uniform per level: the frame's node and its first child, level l in LANE l of a register pair
     // (v_readlane / v_writelane with the level as lane select: no LDS round trip in the walk's bookkeeping)
     int lane_node = 0, lane_fc = 0;
@@ -2281,10 +2361,10 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
       const double tmax = mn3<false>(xh ? amax[0][1] : amax[0][0], yh ? amax[1][1] : amax[1][0], zh ? amax[2][1] : amax[2][0]);
       const double tmin = mx3<false>(xh ? amin[0][1] : amin[0][0], yh ? amin[1][1] : amin[1][0], zh ? amin[2][1] : amin[2][0]);
       const bool entered = (tmax >= 0.0) & (tmin <= tmax);
-      const int own_p = h_own_p[lev * 64 + lane];
-      const double own_t = h_own_t[lev * 64 + lane];
+      const int own_p = HS_LD(h_own_p, g_own_p, lev);
+      const double own_t = HS_LD(h_own_t, g_own_t, lev);
       if (rp_ >= 0 && entered && !(own_p >= 0 && rt_ > own_t)) {
-        const int wp = h_win_p[lev * 64 + lane];
+        const int wp = HS_LD(h_win_p, g_win_p, lev);
         bool take = wp < 0;
         if (!take) {
           const int kw = (int)((unsigned)wp >> 28);
@@ -2293,8 +2373,8 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
           take = (tmin < wmin) || (tmin == wmin && slot_ < kw);
         }
         if (take) {
-          h_win_p[lev * 64 + lane] = rp_ | (slot_ << 28);
-          h_win_t[lev * 64 + lane] = rt_;
+          HS_ST(h_win_p, g_win_p, lev, rp_ | (slot_ << 28));
+          HS_ST(h_win_t, g_win_t, lev, rt_);
         }
       }
       // Lanes that hold a candidate drop the children that sort behind it: the reference's
@@ -2302,7 +2382,7 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
       {
         unsigned rest = get8(pendA, pendB, lev);
         if (rest != 0u) {
-          const int wp = h_win_p[lev * 64 + lane];
+          const int wp = HS_LD(h_win_p, g_win_p, lev);
           const int kw = (int)((unsigned)wp >> 28) & 7;
           const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
           const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
@@ -2482,9 +2562,9 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
           status = DEV_ERR_UNWIND_BOUND;
           break;
         }
-        h_own_t[lev * 64 + lane] = best_t;
-        h_own_p[lev * 64 + lane] = best;
-        h_win_p[lev * 64 + lane] = -1;
+        HS_ST(h_own_t, g_own_t, lev, best_t);
+        HS_ST(h_own_p, g_own_p, lev, best);
+        HS_ST(h_win_p, g_win_p, lev, -1);
         lane_node = lane == lev ? node : lane_node;
         lane_fc = lane == lev ? fc : lane_fc;
         if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + (unsigned)kHsRecPlanes))[lane];
@@ -2506,13 +2586,13 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
         const unsigned todo = get8(pendA, pendB, lev);
         MT_PROF_END(PROF_HS_RET_T, prof_t1);
         if (todo == 0u) {  // close the frame: octtree.cc:248-256
-          const int wp = h_win_p[lev * 64 + lane];
+          const int wp = HS_LD(h_win_p, g_win_p, lev);
           if (wp >= 0) {
             ret_p = wp & 0x0fffffff;
-            ret_t = h_win_t[lev * 64 + lane];
+            ret_t = HS_LD(h_win_t, g_win_t, lev);
           } else {
-            ret_p = h_own_p[lev * 64 + lane];
-            ret_t = h_own_t[lev * 64 + lane];
+            ret_p = HS_LD(h_own_p, g_own_p, lev);
+            ret_t = HS_LD(h_own_t, g_own_t, lev);
           }
           const int closed = __builtin_amdgcn_readlane(lane_node, lev);
           lev--;

@@ -33,6 +33,7 @@ for f in range(1, 33):
     j = f % 16; tri = j if j <= 4 else (8 - j if j <= 12 else j - 16)
     c = list(sg.ROOM_CAMERA); c[4] += 2.0 * tri
     pan.append(frame(c))
+if os.environ.get("PERFRAME"): print("   panning frames (ms): " + " ".join("%.2f" % x for x in pan[-16:]))
 abi.set_stats(h, True); abi.read_stats(h); frame(sg.ROOM_CAMERA); st = abi.read_stats(h)
 rays = st["rays_primary"] + st["rays_secondary"] + st["rays_shadow"]
 print("%s%s: %d triangles; first frame %.2f ms (%s), warm %.3f ms, panning %.3f ms = %.0f Mray/s (%d rays per frame, %.1f node visits per ray, %d wave steps)" % (
