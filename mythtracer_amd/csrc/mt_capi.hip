@@ -136,7 +136,7 @@ struct mt_scene {
   std::vector<mt_light> lights_host;  // what d_lights holds
   int forecasts_in_a_row = 0;  // launches with this geometry and camera whose work order came from a forecast
   int waves_per_block = 4;
-  bool deep = false;               // the DEEP instantiations of the kernels (mt_device.h, kDeepFromDepth)
+  int deep = 0;                    // which DEEP instantiations of the kernels: 0, 1, 2 (mt_device.h, deep_layout)
   char *d_deep = nullptr;          // their per-wave areas
   size_t deep_bytes = 0;
   size_t lds_bytes = 0;
@@ -232,8 +232,8 @@ bool finite3(const double *p, size_t n) {
 // frames (27 KB per wave at 16 levels) let one 4-wave workgroup fill two thirds of the LDS and leave room for a fifth
 // wave only as a workgroup of its own.
 int configure_launch(mt_scene *s) {
-  s->deep = deep_layout(s->dev.tree_depth) && s->tune.v[MT_TUNE_DEEP_LAYOUT] != 0.0;
-  const size_t per_wave = wave_stack_bytes(s->dev.tree_depth, s->dev.pack_shift != 0, s->deep);
+  s->deep = s->tune.v[MT_TUNE_DEEP_LAYOUT] != 0.0 ? deep_layout(s->dev.tree_depth) : 0;
+  const size_t per_wave = wave_stack_bytes(s->dev.tree_depth, s->dev.pack_shift != 0, s->deep != 0);
   if (per_wave > kLdsBudget) {
     return fail(MT_ERR_UNSUPPORTED, "octree depth %d needs %zu B of LDS per wave (> %zu)",
                 s->dev.tree_depth, per_wave, kLdsBudget);
@@ -246,16 +246,14 @@ int configure_launch(mt_scene *s) {
     std::lock_guard<std::mutex> lock(mu);
     size_t &have = lds_attr[s->device];
     if (bytes > have) {
-      const void *kernels[] = {(const void *)render_kernel<true, false>, (const void *)render_kernel<false, false>,
-                               (const void *)primary_kernel<true, false>, (const void *)primary_kernel<false, false>,
-                               (const void *)pool_kernel<true, false>, (const void *)pool_kernel<false, false>,
-                               (const void *)hybrid_kernel<true, false>, (const void *)hybrid_kernel<false, false>,
-                               (const void *)probe_kernel<false>, (const void *)intersect_kernel<false>,
-                               (const void *)render_kernel<true, true>, (const void *)render_kernel<false, true>,
-                               (const void *)primary_kernel<true, true>, (const void *)primary_kernel<false, true>,
-                               (const void *)pool_kernel<true, true>, (const void *)pool_kernel<false, true>,
-                               (const void *)hybrid_kernel<true, true>, (const void *)hybrid_kernel<false, true>,
-                               (const void *)probe_kernel<true>, (const void *)intersect_kernel<true>};
+#define MT_KERNELS_OF(D_)                                                                                  \
+  (const void *)render_kernel<true, D_>, (const void *)render_kernel<false, D_>,                              \
+  (const void *)primary_kernel<true, D_>, (const void *)primary_kernel<false, D_>,                            \
+  (const void *)pool_kernel<true, D_>, (const void *)pool_kernel<false, D_>,                                  \
+  (const void *)hybrid_kernel<true, D_>, (const void *)hybrid_kernel<false, D_>,                              \
+  (const void *)probe_kernel<D_>, (const void *)intersect_kernel<D_>
+      const void *kernels[] = {MT_KERNELS_OF(0), MT_KERNELS_OF(1), MT_KERNELS_OF(2)};
+#undef MT_KERNELS_OF
       for (const void *k : kernels) {
         HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
       }
@@ -269,7 +267,7 @@ int configure_launch(mt_scene *s) {
     int rc = set_attribute(per_wave * wpb);
     if (rc != MT_OK) return rc;
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, s->deep ? (const void *)render_kernel<true, true> : (const void *)render_kernel<true, false>, wpb * 64, per_wave * wpb));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, s->deep == 2 ? (const void *)render_kernel<true, 2> : (s->deep == 1 ? (const void *)render_kernel<true, 1> : (const void *)render_kernel<true, 0>), wpb * 64, per_wave * wpb));
     if (per_cu < 1) per_cu = 1;
     if (per_cu * wpb > 16) per_cu = 16 / wpb;  // more waves only add divergence state
     if (per_cu * wpb > best_per_cu * best_wpb) {  // (ties: the larger workgroup, tried first)
@@ -301,18 +299,22 @@ int ensure_bytes(void **ptr, size_t *have, size_t need) {
 // launches kernel<STATS, DEEP> (or kernel<DEEP>) for the scene's layout
 #define MT_LAUNCH_SD(kernel, stats, grid_, block_, lds_, stream_, ...)                                              \
   do {                                                                                                                \
-    if (s->deep) {                                                                                                    \
-      if (stats) hipLaunchKernelGGL((kernel<true, true>), grid_, block_, lds_, stream_, __VA_ARGS__);                 \
-      else hipLaunchKernelGGL((kernel<false, true>), grid_, block_, lds_, stream_, __VA_ARGS__);                      \
+    if (s->deep == 2) {                                                                                               \
+      if (stats) hipLaunchKernelGGL((kernel<true, 2>), grid_, block_, lds_, stream_, __VA_ARGS__);                    \
+      else hipLaunchKernelGGL((kernel<false, 2>), grid_, block_, lds_, stream_, __VA_ARGS__);                         \
+    } else if (s->deep == 1) {                                                                                        \
+      if (stats) hipLaunchKernelGGL((kernel<true, 1>), grid_, block_, lds_, stream_, __VA_ARGS__);                    \
+      else hipLaunchKernelGGL((kernel<false, 1>), grid_, block_, lds_, stream_, __VA_ARGS__);                         \
     } else {                                                                                                          \
-      if (stats) hipLaunchKernelGGL((kernel<true, false>), grid_, block_, lds_, stream_, __VA_ARGS__);                \
-      else hipLaunchKernelGGL((kernel<false, false>), grid_, block_, lds_, stream_, __VA_ARGS__);                     \
+      if (stats) hipLaunchKernelGGL((kernel<true, 0>), grid_, block_, lds_, stream_, __VA_ARGS__);                    \
+      else hipLaunchKernelGGL((kernel<false, 0>), grid_, block_, lds_, stream_, __VA_ARGS__);                         \
     }                                                                                                                 \
   } while (0)
 #define MT_LAUNCH_D(kernel, grid_, block_, lds_, stream_, ...)                                                      \
   do {                                                                                                                \
-    if (s->deep) hipLaunchKernelGGL((kernel<true>), grid_, block_, lds_, stream_, __VA_ARGS__);                       \
-    else hipLaunchKernelGGL((kernel<false>), grid_, block_, lds_, stream_, __VA_ARGS__);                              \
+    if (s->deep == 2) hipLaunchKernelGGL((kernel<2>), grid_, block_, lds_, stream_, __VA_ARGS__);                     \
+    else if (s->deep == 1) hipLaunchKernelGGL((kernel<1>), grid_, block_, lds_, stream_, __VA_ARGS__);                \
+    else hipLaunchKernelGGL((kernel<0>), grid_, block_, lds_, stream_, __VA_ARGS__);                                  \
   } while (0)
 
 // the per-wave global areas of the DEEP instantiations, for a launch of `waves` waves
@@ -530,20 +532,26 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   // re-projects them (radius 1 block; 2 when the origin moved too: parallax).
   int reproject = 0, radius = 0;
   float blend = 0.0f;  // see forecast_kernel
-  // Did the frame that measured the costs have a pixel column or row whose primary rays had a zero direction component
-  // (found on the host: such a column or row runs through the whole image, so its ends are enough)?  Its blocks'
-  // costs are skipped by a re-projected forecast (forecast_kernel).
+  // Did the frame that measured the costs have pixels whose primary rays had a zero direction component?  Found on the
+  // host, exactly: per scanline and component the direction is r + dp x with r = start + ds y (the kernels' own
+  // expression, Sensor::GetRay), zero for at most the pixels next to -r / dp -- a whole column or row for a camera on
+  // an axis, isolated pixels for one with roll or pitch.  Those blocks' costs are skipped by a re-projected forecast
+  // (forecast_kernel).
   int old_irr = 0;
-  if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {  // (from_map: the map is the frame cost_sensor saw, on every rank)
+  if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {
     const mt_sensor &o = s->cost_sensor;
     for (int k = 0; k < 3 && !old_irr; k++) {
-      for (int x = 0; x < image_w && !old_irr; x++) {
-        if (o.start_point[k] + o.delta_scanline[k] * 0.0 + o.delta_pixel[k] * (double)x == 0.0 ||
-            o.start_point[k] + o.delta_scanline[k] * (double)(image_h - 1) + o.delta_pixel[k] * (double)x == 0.0) old_irr = 1;
-      }
       for (int y = 0; y < image_h && !old_irr; y++) {
-        if (o.start_point[k] + o.delta_scanline[k] * (double)y + o.delta_pixel[k] * 0.0 == 0.0 ||
-            o.start_point[k] + o.delta_scanline[k] * (double)y + o.delta_pixel[k] * (double)(image_w - 1) == 0.0) old_irr = 1;
+        const double r = o.start_point[k] + o.delta_scanline[k] * (double)y;
+        if (o.delta_pixel[k] == 0.0 || !std::isfinite(r / o.delta_pixel[k])) {
+          if (r + o.delta_pixel[k] * 0.0 == 0.0) old_irr = 1;
+          continue;
+        }
+        const double x0 = std::nearbyint(-r / o.delta_pixel[k]);
+        for (int dx = -1; dx <= 1; dx++) {
+          const double x = x0 + dx;
+          if (x >= 0.0 && x < (double)image_w && r + o.delta_pixel[k] * x == 0.0) old_irr = 1;
+        }
       }
     }
     reproject = 1;

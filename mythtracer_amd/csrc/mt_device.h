@@ -264,7 +264,14 @@ constexpr int kHsMaxDepth = MT_HS_MAX_DEPTH;
 // global memory (DevScene::deep_base): 19 KB of LDS per wave whatever the depth, 8 waves per CU.
 constexpr int kHsLdsLevels = 10;
 constexpr int kDeepFromDepth = 12;
-__host__ __device__ inline bool deep_layout(int depth) { return depth >= kDeepFromDepth && depth <= kHsMaxDepth; }
+// ... and with the frames out of the LDS's way a third set of instantiations (DEEP = 2, octrees of 17 .. 24 levels)
+// carries a third word of per-level child bytes: the walk takes octrees of up to 24 levels there (deeper ones, or
+// DEEP_LAYOUT switched off above 16: ordered descent).  A set of its own: the third word in the 12 .. 16-level
+// kernels costs the loft 6 % of its frame time.  0 no, 1 deep, 2 deep and wide.
+constexpr int kHsMaxDepthDeep = MT_HS_MAX_DEPTH < 16 ? MT_HS_MAX_DEPTH : 24;
+__host__ __device__ inline int deep_layout(int depth) {
+  return depth < kDeepFromDepth || depth > kHsMaxDepthDeep ? 0 : (depth <= kHsMaxDepth ? 1 : 2);
+}
 __host__ __device__ inline size_t wave_frames_bytes(int depth, bool packed, bool deep = false) {
   if (deep) {
     const int lf = depth - 1 < kHsLdsLevels ? depth - 1 : kHsLdsLevels;

@@ -158,13 +158,13 @@ __device__ __forceinline__ void pool_flush_item_stats(LaneStats &st, unsigned lo
 // block misses the rims of the glass spheres: those blocks then run late and
 // whole, and the first frame took 21 ms instead of 14.)  The forecast only
 // orders the work; nothing computed for a pixel depends on it.
-template <bool DEEP>
+template <int DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void probe_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP != 0);
   const unsigned sample = blockIdx.x * blockDim.x + threadIdx.x;
   const unsigned item = sample >> 2;
   const int which = (int)(sample & 3u);
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(Render
 // failure.
 constexpr unsigned kCarryNone = 0xffffffffu, kCarryDone = 0xfffffffeu, kCarryFail = 0xfffffffdu;
 constexpr int kHybridPoolSub = 32;
-template <bool STATS, bool MIXED, bool DEEP>
+template <bool STATS, bool MIXED, int DEEP>
 __device__ __forceinline__ unsigned pool_engine(const DevScene &S, const RenderParams &P, unsigned carry) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -321,7 +321,7 @@ __device__ __forceinline__ unsigned pool_engine(const DevScene &S, const RenderP
   const int waves_per_block = blockDim.x >> 6;
   const int wave_id = blockIdx.x * waves_per_block + wave_in_block;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP != 0);
 
   // this wave's scratch: records, pool (a stack of entries), free list (a stack of record numbers)
   const int n_lights = S.n_lights;
@@ -814,7 +814,7 @@ __device__ __forceinline__ unsigned pool_engine(const DevScene &S, const RenderP
   return result;
 }
 
-template <bool STATS, bool DEEP>
+template <bool STATS, int DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void pool_kernel(DevScene S, RenderParams P) {
   (void)pool_engine<STATS, false, DEEP>(S, P, kCarryNone);
   if (S.hb && (threadIdx.x & 63) == 0) S.hb[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + 0] = 5;

@@ -146,13 +146,13 @@ __device__ __forceinline__ void flush_item_stats(LaneStats &st, unsigned long lo
 // materials it sees, so that launch 2 can start with the expensive blocks:
 //   class 2: some pixel hit a transparent material (deep refraction trees),
 //   class 1: some pixel hit a reflective one, class 0: everything else.
-template <bool STATS, bool DEEP>
+template <bool STATS, int DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScene S, RenderParams P) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP != 0);
   const MT_CONST mt_material *mtls = as_const(S.mtls);
   LaneStats st;
   st.clear();
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(kSchedThreads) void hybrid_schedule_kernel(RenderPa
 // pixel, i.e. with the pixel's shadow loops running side by side.)
 // sm_engine is the body shared by render_kernel and hybrid_kernel (below); `carry` and the return value as for
 // pool_engine (mt_pool.h).
-template <bool STATS, bool MIXED, bool DEEP>
+template <bool STATS, bool MIXED, int DEEP>
 __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderParams &P, unsigned carry) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -654,7 +654,7 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
   const int waves_per_block = blockDim.x >> 6;
   const int wave_id = blockIdx.x * waves_per_block + wave_in_block;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP != 0);
   FrameIO fio;
   fio.base = P.frames + (size_t)wave_id * (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64;
   fio.park = P.frames + (size_t)gridDim.x * waves_per_block * (size_t)(P.max_depth > 0 ? P.max_depth : 1) * kFrameSlots * 64 +
@@ -1125,7 +1125,7 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
   return result;
 }
 
-template <bool STATS, bool DEEP>
+template <bool STATS, int DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene S, RenderParams P) {
   (void)sm_engine<STATS, false, DEEP>(S, P, kCarryNone);
 }
@@ -1141,7 +1141,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void render_kernel(DevScene
 // machine has units expected to take more than a third of an even share -- skip the pool's part: the state machine's
 // longest blocks start with the launch instead of behind the pool's part (which lasts a quarter of a rank's share of
 // the 4K frame at N = 8; a block of 26-32 passes that starts there ends 20-30 % after everybody else).
-template <bool STATS, bool DEEP>
+template <bool STATS, int DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void hybrid_kernel(DevScene S, RenderParams P) {
   const bool starter = (threadIdx.x >> 6) == (blockDim.x >> 6) - 1 && blockIdx.x < P.n_work[2];  // (the last wave of a workgroup)
   if (!starter) {
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void hybrid_kernel(DevScene
 
 // OctTree::IntersectRay for a batch of arbitrary rays: lane i of the grid
 // traces ray i.
-template <bool DEEP>
+template <int DEEP>
 __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void intersect_kernel(DevScene S, int n, const double *rays,
                                                         int *out_tri, int *out_line,
                                                         double *out_t, double *out_point,
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void intersect_kernel(DevSc
   const int lane = threadIdx.x & 63;
   const int wave_in_block = threadIdx.x >> 6;
   WaveStack stk;
-  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP);
+  stk.bind(smem, wave_in_block, S.tree_depth, S.pack_shift, DEEP != 0);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool want = i < n;
   double o[3] = {0, 0, 0}, d[3] = {0, 0, 1};
@@ -1236,8 +1236,9 @@ __global__ void blit_tiles_kernel(int image_w, int image_h, int tile_w, int tile
   template __global__ void hybrid_kernel<false, DEEP_>(DevScene, RenderParams);                  \
   template __global__ void probe_kernel<DEEP_>(DevScene, RenderParams);                          \
   template __global__ void intersect_kernel<DEEP_>(DevScene, int, const double *, int *, int *, double *, double *, unsigned long long *);
-MT_INSTANTIATE(false)
-MT_INSTANTIATE(true)
+MT_INSTANTIATE(0)
+MT_INSTANTIATE(1)
+MT_INSTANTIATE(2)
 #undef MT_INSTANTIATE
 
 }  // namespace mt

@@ -1816,10 +1816,11 @@ struct TraceOut {
 #else
 #define MT_TRACE_ATTR __forceinline__
 #endif
-template <bool STATS, bool DEEP = false>
+template <bool STATS, int DEEP = 0>
 __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned stack_base, int lane,
                                                          bool want_all, double ox, double oy, double oz,
                                                          double dx, double dy, double dz) {
+  constexpr bool WIDE = DEEP >= 2;  // DEEP 2: child bytes for 24 levels (mt_device.h, deep_layout)
   const MT_CONST DevScene *G = as_const(uniform_ptr(scene));
   DevScene S;
   S.nodes = G->nodes;
@@ -1862,9 +1863,9 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
     const unsigned wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     deep_area = uniform_ptr(G->deep_base + (size_t)wave_global * G->deep_stride);
   }
-  using BtPtr = typename std::conditional<DEEP, double *, MT_LDS double *>::type;
-  using IPtr = typename std::conditional<DEEP, int *, MT_LDS int *>::type;
-  using UPtr = typename std::conditional<DEEP, unsigned *, MT_LDS unsigned *>::type;
+  using BtPtr = typename std::conditional<(DEEP != 0), double *, MT_LDS double *>::type;
+  using IPtr = typename std::conditional<(DEEP != 0), int *, MT_LDS int *>::type;
+  using UPtr = typename std::conditional<(DEEP != 0), unsigned *, MT_LDS unsigned *>::type;
   BtPtr stk_bt;
   IPtr stk_fc, stk_bp;
   UPtr stk_ord;
@@ -1879,7 +1880,7 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
     stk_bp = stk.bp();
     stk_ord = stk.ord();
   }
-  const unsigned frames_end = stk.base + (unsigned)wave_frames_bytes(stk.depth, stk.pack_shift != 0, DEEP);
+  const unsigned frames_end = stk.base + (unsigned)wave_frames_bytes(stk.depth, stk.pack_shift != 0, DEEP != 0);
   unsigned cntr[5] = {0u, 0u, 0u, 0u, 0u};  // per-lane work counters of this traversal (STATS only)
   (void)cntr;
   const int pack_shift = stk.pack_shift;  // wave-uniform
@@ -2055,7 +2056,7 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
   const bool tame = __builtin_fabs(dx) <= 0x1p100 && __builtin_fabs(dy) <= 0x1p100 && __builtin_fabs(dz) <= 0x1p100 &&
                     __builtin_fabs(ox) <= 0x1p200 && __builtin_fabs(oy) <= 0x1p200 && __builtin_fabs(oz) <= 0x1p200;
   bool hs_done = false;
-  if (cull && S.force_mode == 0 && S.tree_depth <= kHsMaxDepth && S.n_tris < (1 << 28) &&
+  if (cull && S.force_mode == 0 && S.tree_depth <= (WIDE ? kHsMaxDepthDeep : kHsMaxDepth) && S.n_tris < (1 << 28) &&
       S.bmax[0] <= 0x1p200 && S.bmax[1] <= 0x1p200 && S.bmax[2] <= 0x1p200 && __ballot(want && !tame) == 0ull) {
     hs_done = true;
     const int L = S.tree_depth > 1 ? S.tree_depth - 1 : 0;  // levels that can hold a node with children
@@ -2103,16 +2104,18 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
 #endif
     int lev = -1;                        // frame on top of the stack, -1 none
     // wave-uniform; byte l of the pair: children of frame l still to look at
-    unsigned long long pendA = 0ull, pendB = 0ull;
+    unsigned long long pendA = 0ull, pendB = 0ull, pendC = 0ull;  // (pendC / wantC: levels 16 .. 23, the WIDE instantiations only)
     // per lane; byte l of the pair: children of frame l this lane's filter lets through
-    unsigned long long wantA = 0ull, wantB = 0ull;
-    auto get8 = [&](unsigned long long a, unsigned long long b, int l) -> unsigned {
-      return (unsigned)((l < 8 ? a : b) >> (8 * (l & 7))) & 0xffu;
+    unsigned long long wantA = 0ull, wantB = 0ull, wantC = 0ull;
+    auto get8 = [&](unsigned long long a, unsigned long long b, unsigned long long c, int l) -> unsigned {
+      if constexpr (WIDE) return (unsigned)((l < 8 ? a : (l < 16 ? b : c)) >> (8 * (l & 7))) & 0xffu;
+      else return (unsigned)((l < 8 ? a : b) >> (8 * (l & 7))) & 0xffu;
     };
-    auto set8 = [&](unsigned long long &a, unsigned long long &b, int l, unsigned v) {
+    auto set8 = [&](unsigned long long &a, unsigned long long &b, unsigned long long &c, int l, unsigned v) {
       const int sh_ = 8 * (l & 7);
       if (l < 8) a = (a & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
-      else b = (b & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
+      else if (!WIDE || l < 16) b = (b & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
+      else c = (c & ~(0xffull << sh_)) | ((unsigned long long)v << sh_);
     };
     int node = 0;
     unsigned long long m = __ballot(cur == 0);
@@ -2380,13 +2383,13 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
       // Lanes that hold a candidate drop the children that sort behind it: the reference's
       // loop would have stopped before them (they could only be looked at, never taken).
       {
-        unsigned rest = get8(pendA, pendB, lev);
+        unsigned rest = get8(pendA, pendB, pendC, lev);
         if (rest != 0u) {
           const int wp = HS_LD(h_win_p, g_win_p, lev);
           const int kw = (int)((unsigned)wp >> 28) & 7;
           const bool wxh = (kw & 1) != 0, wzh = (kw & 2) != 0, wyh = (kw & 4) != 0;
           const double wmin = mx3<false>(wxh ? amin[0][1] : amin[0][0], wyh ? amin[1][1] : amin[1][0], wzh ? amin[2][1] : amin[2][0]);
-          unsigned my = get8(wantA, wantB, lev);
+          unsigned my = get8(wantA, wantB, wantC, lev);
           unsigned still = 0u;
           while (rest != 0u) {
             const int c2 = __builtin_ctz(rest);
@@ -2397,8 +2400,8 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
             if (behind) my &= ~(1u << c2);
             if (__ballot(((my >> c2) & 1u) != 0u) != 0ull) still |= 1u << c2;
           }
-          set8(wantA, wantB, lev, my);
-          set8(pendA, pendB, lev, still);
+          set8(wantA, wantB, wantC, lev, my);
+          set8(pendA, pendB, pendC, lev, still);
         }
       }
     };
@@ -2417,6 +2420,7 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
       entering = uniform_i32(entering ? 1 : 0) != 0;
       pendA = uniform_u64(pendA);
       pendB = uniform_u64(pendB);
+      if constexpr (WIDE) pendC = uniform_u64(pendC);
       m = ((unsigned long long)(unsigned)uniform_i32((int)(m >> 32)) << 32) | (unsigned)uniform_i32((int)m);
       if (entering) {
         MT_TL(2);  // ENTER
@@ -2568,8 +2572,8 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
         lane_node = lane == lev ? node : lane_node;
         lane_fc = lane == lev ? fc : lane_fc;
         if (lane < 9) h_planes[lev * 10 + lane] = ((const MT_LDS double *)(uintptr_t)(rec + (unsigned)kHsRecPlanes))[lane];
-        set8(wantA, wantB, lev, bits);
-        set8(pendA, pendB, lev, any);
+        set8(wantA, wantB, wantC, lev, bits);
+        set8(pendA, pendB, pendC, lev, any);
         ret_p = -1;  // nothing comes back yet
         MT_TL(7);  // frame open
       } else {
@@ -2582,8 +2586,9 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
           offer(slot, ret_p, ret_t);
           pendA = uniform_u64(pendA);  // (wave-uniform: built from ballots; said so, or picking the next child runs as vector code)
           pendB = uniform_u64(pendB);
+          if constexpr (WIDE) pendC = uniform_u64(pendC);
         }
-        const unsigned todo = get8(pendA, pendB, lev);
+        const unsigned todo = get8(pendA, pendB, pendC, lev);
         MT_PROF_END(PROF_HS_RET_T, prof_t1);
         if (todo == 0u) {  // close the frame: octtree.cc:248-256
           const int wp = HS_LD(h_win_p, g_win_p, lev);
@@ -2601,8 +2606,8 @@ __device__ MT_TRACE_ATTR TraceOut trace_wave(const DevScene *scene, unsigned sta
         }
         MT_TL(9);  // offer done, next child picked
         const int c = pick(todo);
-        set8(pendA, pendB, lev, todo & ~(1u << c));
-        m = __ballot(((get8(wantA, wantB, lev) >> c) & 1u) != 0u);
+        set8(pendA, pendB, pendC, lev, todo & ~(1u << c));
+        m = __ballot(((get8(wantA, wantB, wantC, lev) >> c) & 1u) != 0u);
         node = __builtin_amdgcn_readlane(lane_fc, lev) + c;
         entering = true;
       }

@@ -349,6 +349,10 @@ SCENES = {
     # (radius 0.03 .. 0.6) -- the deepest tree the hit-set walk takes (kHsMaxDepth)
     "loft":       dict(wall_div=48, spheres=[(4, 14), (5, 12)], n_boxes=24, box_div=10, with_materials=True,
                        clusters=[(60, 3, 0.04, 0.6), (60, 3, 0.04, 0.6), (40, 4, 0.1, 0.6), (30, 3, 0.03, 0.3)]),
+    # the loft with ten to sixteen times finer things on the shelves (radius from 0.002): an octree of 20 levels, 154 793
+    # nodes -- beyond round 3's walk (16 levels), inside the deep layout's (24)
+    "loft_fine":  dict(wall_div=48, spheres=[(4, 14), (5, 12)], n_boxes=24, box_div=10, with_materials=True,
+                       clusters=[(60, 3, 0.0025, 0.6), (60, 3, 0.005, 0.6), (40, 4, 0.006, 0.6), (30, 3, 0.002, 0.3)]),
 }
 
 

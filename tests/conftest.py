@@ -40,7 +40,7 @@ def scenes(tmp_path_factory):
     d = str(tmp_path_factory.mktemp("scenes"))
     want = json.load(open(os.path.join(GOLDEN, "scene_hashes.json")))
     out = {"cornell": CORNELL, "f2_decal": os.path.join(ROOT, "tests", "scenes", "f2_decal.obj")}
-    for name in ("mini", "mini_nomtl", "room", "room_nomtl", "room_tex", "loft"):
+    for name in ("mini", "mini_nomtl", "room", "room_nomtl", "room_tex", "loft", "loft_fine"):
         info = scenegen.write_scene(name, d)
         if name in want:
             assert info["sha256"] == want[name], "scene generator drifted for " + name

@@ -312,6 +312,26 @@ def main():
                 print("room_tex_1920x1080_d5", frames["room_tex_1920x1080_d5"])
             json.dump(frames, open(fpath, "w"), indent=1, sort_keys=True)
         return
+    if "--deep20" in sys.argv:
+        # "loft_fine": an octree of 20 levels, by the compiled reference (small frame in full + the SHA-256 of 1920x1080)
+        with tempfile.TemporaryDirectory() as td:
+            fine = scenegen.write_scene("loft_fine", os.path.join(td, "scenes"))
+            render_case(td, "loft_fine_240x135", fine["obj"], 240, 135, scenegen.ROOM_CAMERA, scenegen.ROOM_LIGHTS)
+            meta = json.load(open(os.path.join(HERE, "scene_hashes.json")))
+            meta["loft_fine"] = fine["sha256"]
+            json.dump(meta, open(os.path.join(HERE, "scene_hashes.json"), "w"), indent=1, sort_keys=True)
+            W, H = 1920, 1080
+            rr = orclib.run_ref(os.path.join(td, "fine_big"), fine["obj"], (W, H), cam=scenegen.ROOM_CAMERA,
+                                lights=scenegen.ROOM_LIGHTS, want_debug=True)
+            assert rr["returncode"] == 0, rr["stderr"]
+            fpath = os.path.join(HERE, "frames.json")
+            frames = json.load(open(fpath))
+            frames["loft_fine_1920x1080_d5"] = {"sha256": sha(rr["rgb"]), "line_sha256": sha(rr["line"].astype("<i4")),
+                                                "seconds_reference_here": rr["time"]["seconds"], "threads": rr["time"]["threads"],
+                                                "scene_sha256": fine["sha256"]}
+            print("loft_fine_1920x1080_d5", frames["loft_fine_1920x1080_d5"])
+            json.dump(frames, open(fpath, "w"), indent=1, sort_keys=True)
+        return
     if "--f2" in sys.argv:
         with tempfile.TemporaryDirectory() as td:
             render_case(td, "f2_decal_96x64", F2_DECAL, 96, 64, F2_CAM, F2_LIGHTS)

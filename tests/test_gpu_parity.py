@@ -89,7 +89,9 @@ RENDER_CASES = [("cornell_256", "cornell"), ("cornell_cam2_96x64", "cornell"),
                 ("f2_decal_96x64", "f2_decal"),
                 # round 4's two more scenes (profiles/README.md): 770 720 triangles in an octree of 16 levels, made by the
                 # reference; the room with map_Ka textures, made by the ORACLE (Texture::GetColorAt: parity unpinned)
-                ("loft_240x135", "loft"), ("room_tex_240x135", "room_tex")]
+                ("loft_240x135", "loft"), ("room_tex_240x135", "room_tex"),
+                # the loft with finer shelves: an octree of 20 levels (the third word of the walk's child bytes), reference-made
+                ("loft_fine_240x135", "loft_fine")]
 
 
 @pytest.mark.parametrize("case,scene", RENDER_CASES)
@@ -345,14 +347,17 @@ def _render_both(m, o, cam, W, H, lights):
     return g
 
 
-@pytest.mark.parametrize("ext,jit,depth", [(0.08, 0.015, 10), (0.04, 0.008, 11), (0.01, 0.002, 13), (0.005, 0.001, 14), (0.0012, 0.00025, 16), (0.0003, 0.00006, 18)])
-def test_deep_octrees(ext, jit, depth):
-    """A tight cluster of small triangles in a big room makes the octree deep.  Up to
-    16 levels (kHsMaxDepth) regular rays take the hit-set walk -- levels 8 and
-    deeper in the second half of its per-lane child masks, fewer waves per
-    workgroup as its LDS frames grow --, deeper trees (18 here) the ordered
-    descent with its per-lane stack.  Same pixels, hit points and counters as the
-    oracle."""
+@pytest.mark.parametrize("ext,jit,depth,layout", [(0.08, 0.015, 10, 1), (0.04, 0.008, 11, 1), (0.01, 0.002, 13, 1), (0.01, 0.002, 13, 0),
+                                                   (0.005, 0.001, 14, 1), (0.0012, 0.00025, 16, 1), (0.0012, 0.00025, 16, 0),
+                                                   (0.0003, 0.00006, 18, 1), (0.0003, 0.00006, 18, 0), (0.00004, 0.000008, 21, 1),
+                                                   (0.000005, 0.000001, 24, 1), (0.0000025, 0.0000005, 25, 1)])
+def test_deep_octrees(ext, jit, depth, layout):
+    """A tight cluster of small triangles in a big room makes the octree deep.  Up to 11 levels the hit-set walk keeps
+    all its frames in LDS; from 12 levels on the DEEP instantiations of the kernels (layout 1, the default) keep ten
+    levels' frames there and the rest -- and the ordered descent's stack -- in global memory, with a third word of
+    per-level child bytes for levels 16-23: the walk takes trees of up to 24 levels.  Layout 0 (MT_TUNE_DEEP_LAYOUT off)
+    is round 3's: everything in LDS, the walk up to 16 levels; beyond (18 with layout 0, 25 with either) every ray takes
+    the ordered descent with its per-lane stack.  Same pixels, hit points and counters as the oracle."""
     rnd = scenegen.SplitMix64(77)
     m, o = _both()
     tris = [[[0, 0, 0], [64, 0, 0], [0, 0, 64]], [[64, 0, 64], [0, 0, 64], [64, 0, 0]]]  # a floor
@@ -367,6 +372,7 @@ def test_deep_octrees(ext, jit, depth):
         for k, v in enumerate(tris):
             s.add_triangle(v, None, mtl=0, line_no=k)
     assert o.tree()["depth"] == depth
+    M.hip_abi().set_tuning(m.device_scene(), "DEEP_LAYOUT", float(layout))
     lights = [(30, 40, 20, .2, .2, .2, .8, .8, .8, .4, .4, .4)]
     _render_both(m, o, (19.0, 8.0, 12.0, 15.0, 0.0, 0.0, 70.0), 96, 64, lights)
     g = _render_both(m, o, (20.0 + ext / 2, 3.0 + ext / 2, 29.9, 0.0, 0.0, 0.0, min(8.0, 800.0 * ext)), 64, 64, lights)  # straight at the cluster
@@ -378,11 +384,19 @@ def test_deep_octrees(ext, jit, depth):
             tgt = [20.0 + ext * (0.1 + 0.8 * (i % 16) / 15.0), 3.0 + ext * (0.1 + 0.8 * (i // 16) / 15.0), 30.0 + ext * 0.5]
             org = [tgt[0] + 0.3 * (i % 5 - 2), tgt[1] + 0.2 * (i % 3), tgt[2] + 2.0]
             rays.append(org + [tgt[a] - org[a] for a in range(3)])
+        far = max(2.0, 4e-8 / (jit * jit))  # the triangle test drops |det| < 1e-8: a unit direction never hits triangles
+        for i in range(240):                # this small, a direction of this length does (the reference normalises nothing)
+            t = tris[2 + i % 120]
+            tgt = [(t[0][a] + t[1][a] + t[2][a]) / 3.0 for a in range(3)]
+            d = [0.3 * (i % 5 - 2), 1.0, 0.2 * (i % 3 - 1)]
+            org = [tgt[a] + far * d[a] for a in range(3)]
+            rays.append(org + [tgt[a] - org[a] for a in range(3)])
         rays = np.array(rays)
         want = o.intersect(rays)
         got = M.hip_abi().intersect_rays(m.device_scene(), rays)
         assert np.array_equal(got["line"], want["line"])
-        assert ((want["line"] >= 2) & (want["line"] < 122)).mean() > 0.2  # rays into the cluster: the deepest levels
+        assert np.array_equal(got["point"], want["point"], equal_nan=True)
+        assert ((want["line"][256:] >= 2) & (want["line"][256:] < 122)).mean() > 0.3  # rays into the cluster: the deepest levels
 
 
 def test_reference_octtree_test_scenario():
@@ -774,10 +788,10 @@ def test_4k_frame_contains_the_reference_1080p_frame(scenes):
     assert order.cpu().numpy().tolist() != list(range(total))
 
 
-@pytest.mark.parametrize("scene", ["loft", "room_tex"])
+@pytest.mark.parametrize("scene", ["loft", "room_tex", "loft_fine"])
 def test_full_frames_of_the_other_scenes(scene, scenes):
-    """1920x1080 of round 4's two more scenes, first frame (no costs) and the two after it, against the SHA-256 of the
-    frame the compiled reference rendered (loft) / the oracle rendered (room_tex: textured frames cannot come from the
+    """1920x1080 of round 4's three more scenes, first frame (no costs) and the two after it, against the SHA-256 of the
+    frame the compiled reference rendered (loft, loft_fine) / the oracle rendered (room_tex: textured frames cannot come from the
     reference build here, texture.cc needs SDL2 -- `made_by` in frames.json says so)."""
     import hashlib
     frames = json.load(open(os.path.join(GOLDEN, "frames.json")))

@@ -16,7 +16,9 @@ RENDER_CASES = [("cornell_256", "cornell"), ("cornell_cam2_96x64", "cornell"),
                 ("mini_nomtl_320x180", "mini_nomtl"), ("mini_chunk_101x67", "mini"),
                 ("mini_1x1", "mini"), ("room_240x135", "room"),
                 ("room_view_back", "room"), ("room_view_floor", "room"), ("room_view_down", "room"),
-                ("room_view_axis", "room")]
+                ("room_view_axis", "room"),
+                # octrees of 16 and 20 levels (770 720 triangles)
+                ("loft_240x135", "loft"), ("loft_fine_240x135", "loft_fine")]
 
 
 def load(name):
