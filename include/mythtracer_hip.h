@@ -356,6 +356,10 @@ enum {
   MT_TUNE_MULTI_FORCE_PEER_COPY, /* tests: mt_render_frame_multi copies every replica's tiles into the gather buffer with
                                     hipMemcpyPeerAsync even when it shares the first replica's device (0) */
   MT_TUNE_MULTI_BALANCE,      /* mt_render_frame_multi: 1 (default) = tiles dealt out by cost, 0 = by tile number */
+  MT_TUNE_XCD_QUEUES,         /* state-machine launches ordered by cost history: 0 = one work order for the chip; 1 = eight
+                                 orders, one per XCD, each over a stripe of the picture with an eighth of the forecast cost
+                                 (an XCD's L2 then holds its stripe's part of the tree; an XCD that runs dry takes units
+                                 from the fullest other queue); 2 = a 4 x 2 grid of regions instead of stripes */
   MT_TUNE_COUNT
 };
 int mt_scene_set_tuning(mt_scene *scene, int knob, double value);

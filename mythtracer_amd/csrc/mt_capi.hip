@@ -85,6 +85,7 @@ struct Tuning {
     v[MT_TUNE_DEEP_LAYOUT] = 1.0;
     v[MT_TUNE_MULTI_FORCE_PEER_COPY] = 0.0;
     v[MT_TUNE_MULTI_BALANCE] = 1.0;
+    v[MT_TUNE_XCD_QUEUES] = 2.0;  // one work order per XCD over a 4 x 2 grid of regions of equal forecast cost (L2 hit rate 0.82 -> 0.92 room, 0.66 -> 0.82 loft)
   }
 };
 
@@ -101,6 +102,9 @@ struct mt_scene {
   int lights_cap = 0;
   unsigned long long *d_counters = nullptr;
   unsigned int *d_work = nullptr;
+  unsigned int *d_queues = nullptr;  // kQueueWords: the per-XCD work orders' counters and bounds (RenderParams::queues)
+  unsigned short *d_item_cell = nullptr;
+  size_t item_cell_bytes = 0;
   double *d_frames = nullptr;      // throughput engine: recursion frames
   size_t frames_bytes = 0;
   int32_t *d_hit_prim = nullptr;   // launch 1 -> launch 2 hand-off (per pixel)
@@ -515,6 +519,14 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   }
   HIP_TRY(hipMemsetAsync(s->d_work, 0, 16 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
+  // one work order per XCD: state-machine launches with a cost history only (the other engines keep the one order)
+  P.queues = (s->tune.v[MT_TUNE_XCD_QUEUES] != 0.0 && history && !pool_engine && !hybrid) ? s->d_queues : nullptr;
+  if (P.queues) {
+    HIP_TRY(hipMemsetAsync(s->d_queues, 0, kQueueWords * sizeof(unsigned), stream));
+    int rc = ensure_bytes((void **)&s->d_item_cell, &s->item_cell_bytes, (size_t)P.n_items * 2);
+    if (rc != MT_OK) return rc;
+    P.item_cell = s->d_item_cell;
+  }
   const dim3 grid(s->grid_blocks), block(s->waves_per_block * 64);
   {  // (the probe's grid follows the number of blocks: 16 of them per wave)
     const size_t probe_waves = ((size_t)4 * P.n_items + block.x - 1) / block.x * s->waves_per_block;
@@ -618,7 +630,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
                            (float)tv[MT_TUNE_HYBRID_STARTER_SHARE], (unsigned)std::min(s->grid_blocks, (int)(0.25 * s->grid_blocks * s->waves_per_block)));
       } else {
         hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
-                           s->grid_blocks * s->waves_per_block, quad_share, quad_keep);
+                           s->grid_blocks * s->waves_per_block, quad_share, quad_keep, (int)s->tune.v[MT_TUNE_XCD_QUEUES]);
       }
     } else {
       MT_LAUNCH_SD(primary_kernel, s->stats_enabled, grid, block, s->lds_bytes, stream, s->dev, P);
@@ -753,6 +765,7 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_item_form) (void)hipFree(s->d_item_form);
   if (s->d_cost_map) (void)hipFree(s->d_cost_map);
   if (s->d_order_item) (void)hipFree(s->d_order_item);
+  if (s->d_item_cell) (void)hipFree(s->d_item_cell);
   if (s->d_order_sub) (void)hipFree(s->d_order_sub);
   if (s->d_rgb) (void)hipFree(s->d_rgb);
   if (s->d_debug) (void)hipFree(s->d_debug);
@@ -1199,6 +1212,8 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   HIP_TRY(hipMemset(s->d_counters, 0, ST_COUNT * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc((void **)&s->d_work, 64));
   s->allocs.push_back(s->d_work);
+  HIP_TRY(hipMalloc((void **)&s->d_queues, kQueueWords * sizeof(unsigned)));
+  s->allocs.push_back(s->d_queues);
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
   if ((rc = mt_scene_set_lights(s, nullptr, 0)) != MT_OK) return rc;
@@ -1328,6 +1343,9 @@ int mt_scene_set_tuning(mt_scene *s, int knob, double value) {
       break;
     case MT_TUNE_POOL_CUT_SHARE:
       if (!(value < 0.0 || (value >= 1e-6 && value <= 1e6))) return fail(MT_ERR_ARG, "the pool's cutting share must be negative (automatic) or lie in [1e-6, 1e6]");
+      break;
+    case MT_TUNE_XCD_QUEUES:
+      if (!(value == 0.0 || value == 1.0 || value == 2.0)) return fail(MT_ERR_ARG, "XCD queues: 0 (off), 1 (stripes) or 2 (grid)");
       break;
     default: break;  // switches: any finite value (0 / non-zero)
   }

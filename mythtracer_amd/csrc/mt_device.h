@@ -232,7 +232,16 @@ struct RenderParams {
   const int32_t *tile_list;
   const int32_t *tile_slot;
   int32_t from_map;  // 1: forecast_kernel reads the costs from cost_map by image position even when the camera is at rest
+  // One work order per XCD (MT_TUNE_XCD_QUEUES; nullptr = one order for the chip): queue q holds the units
+  // [queues[kQueueStart + q], queues[kQueueStart + q + 1]) of order_item / order_sub, longest first, and hands them out
+  // through the counter queues[q * kQueueStride]
+  unsigned int *queues;
+  unsigned short *item_cell;  // [n_items] the block's cell of the region grid (forecast_kernel -> schedule_kernel)
 };
+constexpr int kQueues = 8, kQueueStride = 32, kQueueStart = kQueues * kQueueStride;  // (a counter per 128-byte line)
+constexpr int kGridW = 128, kGridH = 64;           // the region grid: forecast cost per cell, queues[kQueueGrid + cy * kGridW + cx]
+constexpr int kQueueGrid = kQueueStart + 32;
+constexpr int kQueueWords = kQueueGrid + kGridW * kGridH;
 
 // slot j of a launch -> tile of the region's grid, and back (-1: not this launch's)
 __device__ __forceinline__ int tile_of_slot(const RenderParams &P, int j) {

@@ -234,6 +234,17 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScen
 // The order changes nothing about what is computed for a pixel.  Costs are in
 // units of 64 s_memtime ticks; a block rendered as quarters reports their sum,
 // which is scaled back (kQuadWork) before it is compared again.
+// (one work order per XCD, schedule_kernel below: the block's forecast goes to its cell of the region grid)
+__device__ __forceinline__ void note_cell(const RenderParams &P, unsigned i, unsigned f, int bx, int by) {
+  // (bx, by: the block's position in the launch's region, in blocks)
+  const int n_cols = (P.region_w + 7) >> 3, n_rows = (P.region_h + 7) >> 3;
+  int cx = bx * kGridW / (n_cols > 0 ? n_cols : 1), cy = by * kGridH / (n_rows > 0 ? n_rows : 1);
+  cx = cx < kGridW ? cx : kGridW - 1;
+  cy = cy < kGridH ? cy : kGridH - 1;
+  const unsigned cell = (unsigned)(cy * kGridW + cx);
+  P.item_cell[i] = (unsigned short)cell;
+  atomicAdd(P.queues + kQueueGrid + cell, ((f & 0x7fffffffu) >> 6) + 1u);  // (+ 1: a block costs something whatever its forecast says)
+}
 // Cost forecast from the previous frame's measured block costs.  When the
 // camera has not moved a block's forecast is its own last cost.  When it has
 // (an animation: main_local.cc:51-76 turns it 2 degrees per frame, 25..70
@@ -280,6 +291,7 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
       if (c != 0u) f = c;
     }
     P.item_forecast[i] = f;
+    if (P.queues) note_cell(P, i, f, bx_ - (P.region_x >> 3), by_ - (P.region_y >> 3));
     return;
   }
   if (!reproject) {
@@ -303,6 +315,12 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
     }
     if (blend > 0.0f) f = (unsigned)(blend * (float)(P.item_forecast[i] & 0x7fffffffu) + (1.0f - blend) * (float)f);
     P.item_forecast[i] = f | (pool ? 0u : (P.item_cost[i] & 0x80000000u));
+    if (P.queues) {
+      const int per_tile_ = P.blocks_x * P.blocks_y;
+      const int j_ = (int)(i / (unsigned)per_tile_), b_ = (int)(i % (unsigned)per_tile_);
+      const int tile_ = tile_of_slot(P, j_);
+      note_cell(P, i, f, (((tile_ % P.tiles_x) * P.tile_w) >> 3) + b_ % P.blocks_x, (((tile_ / P.tiles_x) * P.tile_h) >> 3) + b_ / P.blocks_x);
+    }
     return;
   }
   const int per_tile = P.blocks_x * P.blocks_y;
@@ -386,6 +404,7 @@ __global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, in
   // position: 9.0 -> ms at 1080p, 6.7 -> ms for the rank that owns the column at N = 8).
   if (block_has_zero_component_ray(P.sensor, (int)px - 4, (int)py - 4)) best = max(best, unseen * 30u);
   P.item_forecast[i] = best;
+  if (P.queues) note_cell(P, i, best, ((int)px - P.region_x) >> 3, ((int)py - P.region_y) >> 3);
 }
 
 // The block costs of the launch described by P, on the whole-block scale of the state machine, into a frame-wide
@@ -501,13 +520,86 @@ __device__ __forceinline__ int cost_bucket(unsigned c) {  // descending cost = a
   const int f = e >= 3 ? (int)((c >> (e - 3)) & 7u) : 0;      // eighth within it
   return kSchedBuckets - 1 - (e * 8 + f);
 }
-__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves, float quad_share, float quad_keep_share) {
+// P.queues (MT_TUNE_XCD_QUEUES): eight work orders instead of one, queue q over region q of the picture -- `mode` 1:
+// eight stripes of block columns, each with an eighth of the forecast cost; 2: four such stripes, each cut into an upper
+// and a lower half of equal cost.  A wave drains the queue of its XCD first (sm_engine), so that an XCD's L2 holds
+// its region's part of the tree and the triangle streams.  The cuts run along the cells of a kGridW x kGridH grid over
+// the launch's region: forecast_kernel adds every block's forecast to its cell (queues[kQueueGrid ...]) and notes the
+// cell (item_cell); here the grid's marginals give the cuts, a table cell -> region the rest.
+__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves, float quad_share, float quad_keep_share, int mode) {
   __shared__ unsigned long long s_sum;
-  __shared__ unsigned s_count[kSchedBuckets];
-  __shared__ unsigned s_start[kSchedBuckets];
+  __shared__ unsigned s_count[kQueues * kSchedBuckets];
+  __shared__ unsigned s_start[kQueues * kSchedBuckets];
+  __shared__ unsigned s_grid[kGridW * kGridH];
+  __shared__ unsigned char s_cellreg[kGridW * kGridH];
+  __shared__ unsigned long long s_colsum[kGridW];
+  __shared__ unsigned long long s_rowsum[4 * kGridH];
+  __shared__ int s_cut[kQueues + 1];                 // stripe s = cell columns [s_cut[s], s_cut[s + 1])
+  __shared__ int s_rowcut[kQueues];                  // mode 2: stripe s is cut in front of this cell row
+  __shared__ unsigned s_qtotal[kQueues];
   const int tid = threadIdx.x;
+  const bool queues = P.queues != nullptr && mode != 0;
+  const int n_regions = queues ? kQueues : 1;
+  const int n_stripes = mode == 2 ? 4 : kQueues;
   if (tid == 0) s_sum = 0ull;
-  for (int b = tid; b < kSchedBuckets; b += kSchedThreads) s_count[b] = 0u;
+  for (int b = tid; b < n_regions * kSchedBuckets; b += kSchedThreads) s_count[b] = 0u;
+  if (queues) {
+    for (int c = tid; c < kGridW * kGridH; c += kSchedThreads) s_grid[c] = P.queues[kQueueGrid + c];
+    __syncthreads();
+    if (tid < kGridW) {
+      unsigned long long t = 0ull;
+      for (int y = 0; y < kGridH; y++) t += s_grid[y * kGridW + tid];
+      s_colsum[tid] = t;
+    }
+    __syncthreads();
+    // stripes of equal cost: cut s lies behind the first cell column at which the running cost reaches s / n_stripes of the total
+    if (tid <= n_stripes) {
+      unsigned long long total = 0ull;
+      for (int x = 0; x < kGridW; x++) total += s_colsum[x];
+      int cut = tid == 0 ? 0 : kGridW;
+      if (tid > 0 && tid < n_stripes && total != 0ull) {
+        unsigned long long acc = 0ull;
+        for (int x = 0; x < kGridW; x++) {
+          acc += s_colsum[x];
+          if (acc * (unsigned long long)n_stripes >= total * (unsigned long long)tid) {
+            cut = x + 1;
+            break;
+          }
+        }
+      }
+      s_cut[tid] = cut;
+    }
+    __syncthreads();
+    if (mode == 2) {  // per stripe the cell row that halves its cost
+      if (tid < 4 * kGridH) {
+        const int st = tid / kGridH, y = tid % kGridH;
+        unsigned long long t = 0ull;
+        for (int x = s_cut[st]; x < s_cut[st + 1] && x < kGridW; x++) t += s_grid[y * kGridW + x];
+        s_rowsum[tid] = t;
+      }
+      __syncthreads();
+      if (tid < 4) {
+        unsigned long long total = 0ull, acc = 0ull;
+        for (int y = 0; y < kGridH; y++) total += s_rowsum[tid * kGridH + y];
+        int cut = kGridH;
+        for (int y = 0; y < kGridH; y++) {
+          acc += s_rowsum[tid * kGridH + y];
+          if (acc * 2ull >= total) {
+            cut = y + 1;
+            break;
+          }
+        }
+        s_rowcut[tid] = cut;
+      }
+      __syncthreads();
+    }
+    for (int c = tid; c < kGridW * kGridH; c += kSchedThreads) {
+      const int cx = c % kGridW, cy = c / kGridW;
+      int st = 0;
+      while (st + 1 < n_stripes && cx >= s_cut[st + 1]) st++;
+      s_cellreg[c] = (unsigned char)(mode == 2 ? st * 2 + (cy >= s_rowcut[st] ? 1 : 0) : st);
+    }
+  }
   __syncthreads();
   // (forecast_kernel has scaled the costs measured in quad mode -- sums over four
   // quarters, kQuadWork = 1.7 -- back to whole blocks)
@@ -522,40 +614,85 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
   // threshold: the scaled-back sum of four quarters and the cost of the whole block are two
   // different measurements, and a block near the threshold would change its form every frame
   const float quad_keep = quad_above * kQuadKeep;
-  // pass 1: bucket counts (a quad block contributes four units)
-  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
-    const unsigned c = P.item_forecast[i] & 0x7fffffffu;
-    const bool quad = (float)c > ((P.item_forecast[i] >> 31) ? quad_keep : quad_above) && c > 0u;
+  // what a block becomes: bucket | quad << 16 | region << 24
+  auto unit_of = [&](unsigned f, unsigned reg) -> unsigned {
+    const unsigned c = f & 0x7fffffffu;
+    const bool quad = (float)c > ((f >> 31) ? quad_keep : quad_above) && c > 0u;
     const unsigned unit = quad ? (unsigned)((float)c * kQuarterTime) : c;
-    atomicAdd(&s_count[cost_bucket(unit)], quad ? 4u : 1u);
+    return (unsigned)cost_bucket(unit) | (quad ? 0x10000u : 0u) | (reg << 24);
+  };
+  // the two passes take their items four at a time: the loads of a round are in flight together
+  constexpr int kRound = 4;
+  // pass 1: bucket counts (a quad block contributes four units)
+  for (unsigned i0 = tid; i0 < P.n_items; i0 += kRound * kSchedThreads) {
+    unsigned f[kRound], reg[kRound];
+#pragma unroll
+    for (int k = 0; k < kRound; k++) {
+      const unsigned i = i0 + (unsigned)k * kSchedThreads;
+      f[k] = i < P.n_items ? P.item_forecast[i] : 0u;
+      reg[k] = (queues && i < P.n_items) ? (unsigned)P.item_cell[i] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kRound; k++) {
+      const unsigned i = i0 + (unsigned)k * kSchedThreads;
+      if (i < P.n_items) {
+        const unsigned u = unit_of(f[k], queues ? (unsigned)s_cellreg[reg[k]] : 0u);
+        atomicAdd(&s_count[(u >> 24) * kSchedBuckets + (u & 0xffffu)], (u & 0x10000u) ? 4u : 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < n_regions) {  // (per region one thread: the eight run side by side)
+    unsigned acc = 0u;
+    for (int b = 0; b < kSchedBuckets; b++) {
+      s_start[tid * kSchedBuckets + b] = acc;
+      acc += s_count[tid * kSchedBuckets + b];
+    }
+    s_qtotal[tid] = acc;
   }
   __syncthreads();
   if (tid == 0) {
     unsigned acc = 0u;
-    for (int b = 0; b < kSchedBuckets; b++) {
-      s_start[b] = acc;
-      acc += s_count[b];
+    for (int q = 0; q < n_regions; q++) {
+      if (queues) P.queues[kQueueStart + q] = acc;
+      const unsigned n = s_qtotal[q];
+      s_qtotal[q] = acc;
+      acc += n;
     }
+    if (queues) P.queues[kQueueStart + kQueues] = acc;
     *P.n_work = acc;
   }
   __syncthreads();
   // pass 2: scatter, and reset the costs for the coming frame (bit 31 notes
   // that the block will be measured as quarters)
-  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
-    const unsigned c = P.item_forecast[i] & 0x7fffffffu;
-    const bool quad = (float)c > ((P.item_forecast[i] >> 31) ? quad_keep : quad_above) && c > 0u;
-    const unsigned unit = quad ? (unsigned)((float)c * kQuarterTime) : c;
-    const unsigned at = atomicAdd(&s_start[cost_bucket(unit)], quad ? 4u : 1u);
-    if (quad) {
-      for (int q = 0; q < 4; q++) {
-        P.order_item[at + q] = i;
-        P.order_sub[at + q] = (signed char)q;
-      }
-    } else {
-      P.order_item[at] = i;
-      P.order_sub[at] = (signed char)-1;
+  for (unsigned i0 = tid; i0 < P.n_items; i0 += kRound * kSchedThreads) {
+    unsigned f[kRound], reg[kRound];
+#pragma unroll
+    for (int k = 0; k < kRound; k++) {
+      const unsigned i = i0 + (unsigned)k * kSchedThreads;
+      f[k] = i < P.n_items ? P.item_forecast[i] : 0u;
+      reg[k] = (queues && i < P.n_items) ? (unsigned)P.item_cell[i] : 0u;
     }
-    P.item_cost[i] = quad ? 0x80000000u : 0u;
+#pragma unroll
+    for (int k = 0; k < kRound; k++) {
+      const unsigned i = i0 + (unsigned)k * kSchedThreads;
+      if (i < P.n_items) {
+        const unsigned u = unit_of(f[k], queues ? (unsigned)s_cellreg[reg[k]] : 0u);
+        const bool quad = (u & 0x10000u) != 0u;
+        const unsigned r = u >> 24;
+        const unsigned at = s_qtotal[r] + atomicAdd(&s_start[r * kSchedBuckets + (u & 0xffffu)], quad ? 4u : 1u);
+        if (quad) {
+          for (int q = 0; q < 4; q++) {
+            P.order_item[at + q] = i;
+            P.order_sub[at + q] = (signed char)q;
+          }
+        } else {
+          P.order_item[at] = i;
+          P.order_sub[at] = (signed char)-1;
+        }
+        P.item_cost[i] = quad ? 0x80000000u : 0u;
+      }
+    }
   }
 }
 
@@ -678,9 +815,52 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
   // (hybrid launches: the state machine's units lie behind the pool's n_work[1] and have a counter of their own)
   const unsigned w_base = MIXED ? P.n_work[1] : 0u;
 
+  // one work order per XCD (P.queues): this wave's queue, the queues found empty so far
+  const bool xcd_queues = !MIXED && !from_primary && P.queues != nullptr;
+  unsigned my_queue = 0u, dry = 0u, q_rank = 0u, q_len = 1u;
+  if (xcd_queues) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    my_queue = xcc & (unsigned)(kQueues - 1);
+  }
+
   for (;;) {
     unsigned w = carry;
-    if (carry == kCarryNone) w = w_base + fetch_work(P.work_counter + (MIXED ? 2 : 1), lane);
+    if (xcd_queues) {
+      w = n_work;
+      while (dry != (1u << kQueues) - 1u) {
+        if ((dry >> my_queue) & 1u) {
+          // the own queue is dry: on to the one with the most units left (a glance, not a reservation)
+          unsigned left = 0u;
+          if (lane < kQueues) {
+            const unsigned s0 = P.queues[kQueueStart + lane], s1 = P.queues[kQueueStart + lane + 1];
+            const unsigned taken = __hip_atomic_load(P.queues + lane * kQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            left = (taken < s1 - s0 && !((dry >> lane) & 1u)) ? s1 - s0 - taken : 0u;
+          }
+          unsigned best_left = 0u, best_q = 0u;
+          for (int q = 0; q < kQueues; q++) {
+            const unsigned l = (unsigned)__builtin_amdgcn_readlane((int)left, q);
+            if (l > best_left) {
+              best_left = l;
+              best_q = (unsigned)q;
+            }
+          }
+          if (best_left == 0u) break;
+          my_queue = best_q;
+        }
+        const unsigned s0 = P.queues[kQueueStart + my_queue], s1 = P.queues[kQueueStart + my_queue + 1];
+        const unsigned k = fetch_work(P.queues + my_queue * kQueueStride, lane);
+        if (k < s1 - s0) {
+          w = s0 + k;
+          q_rank = k;
+          q_len = s1 - s0;
+          break;
+        }
+        dry |= 1u << my_queue;
+      }
+    } else if (carry == kCarryNone) {
+      w = w_base + fetch_work(P.work_counter + (MIXED ? 2 : 1), lane);
+    }
     carry = kCarryNone;
     if (S.hb) {
       const unsigned long long ex = __builtin_amdgcn_read_exec();
@@ -694,8 +874,9 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
       // (schedule_kernel); the longest blocks come as four quarters.
       item = P.order_item[w];
       sub = (int)P.order_sub[w];
-      if (w < (n_work >> 4)) __builtin_amdgcn_s_setprio(3);
-      else if (w < (n_work >> 2)) __builtin_amdgcn_s_setprio(2);
+      const unsigned rank = xcd_queues ? q_rank : w, of = xcd_queues ? q_len : n_work;
+      if (rank < (of >> 4)) __builtin_amdgcn_s_setprio(3);
+      else if (rank < (of >> 2)) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(0);
     } else if (w < n1) {
       // No history: reflective blocks (class 1) first — the longest of them (a
