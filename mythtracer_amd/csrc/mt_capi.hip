@@ -520,6 +520,9 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   HIP_TRY(hipMemsetAsync(s->d_work, 0, 16 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
   // one work order per XCD: state-machine launches with a cost history only (the other engines keep the one order)
+  // (measured and left out: first frames through the ray pool -- room 8.4 -> 8.9 ms, loft 19.7 -> 20.9: the probe's guess
+  // balances the regions too roughly, and such a frame ends with its longest units either way --; the state machine's
+  // part of hybrid launches, i.e. a rank's share of a frame -- mean of eight ranks' 4K shares 2.71 -> 2.77 ms)
   P.queues = (s->tune.v[MT_TUNE_XCD_QUEUES] != 0.0 && history && !pool_engine && !hybrid) ? s->d_queues : nullptr;
   if (P.queues) {
     HIP_TRY(hipMemsetAsync(s->d_queues, 0, kQueueWords * sizeof(unsigned), stream));

@@ -3,6 +3,7 @@
 // compute every pixel with the same operations in the same order.)
 #pragma once
 #include "mt_shade.h"
+#include "mt_queues.h"
 
 namespace mt {
 

@@ -234,17 +234,6 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScen
 // The order changes nothing about what is computed for a pixel.  Costs are in
 // units of 64 s_memtime ticks; a block rendered as quarters reports their sum,
 // which is scaled back (kQuadWork) before it is compared again.
-// (one work order per XCD, schedule_kernel below: the block's forecast goes to its cell of the region grid)
-__device__ __forceinline__ void note_cell(const RenderParams &P, unsigned i, unsigned f, int bx, int by) {
-  // (bx, by: the block's position in the launch's region, in blocks)
-  const int n_cols = (P.region_w + 7) >> 3, n_rows = (P.region_h + 7) >> 3;
-  int cx = bx * kGridW / (n_cols > 0 ? n_cols : 1), cy = by * kGridH / (n_rows > 0 ? n_rows : 1);
-  cx = cx < kGridW ? cx : kGridW - 1;
-  cy = cy < kGridH ? cy : kGridH - 1;
-  const unsigned cell = (unsigned)(cy * kGridW + cx);
-  P.item_cell[i] = (unsigned short)cell;
-  atomicAdd(P.queues + kQueueGrid + cell, ((f & 0x7fffffffu) >> 6) + 1u);  // (+ 1: a block costs something whatever its forecast says)
-}
 // Cost forecast from the previous frame's measured block costs.  When the
 // camera has not moved a block's forecast is its own last cost.  When it has
 // (an animation: main_local.cc:51-76 turns it 2 degrees per frame, 25..70
@@ -520,86 +509,19 @@ __device__ __forceinline__ int cost_bucket(unsigned c) {  // descending cost = a
   const int f = e >= 3 ? (int)((c >> (e - 3)) & 7u) : 0;      // eighth within it
   return kSchedBuckets - 1 - (e * 8 + f);
 }
-// P.queues (MT_TUNE_XCD_QUEUES): eight work orders instead of one, queue q over region q of the picture -- `mode` 1:
-// eight stripes of block columns, each with an eighth of the forecast cost; 2: four such stripes, each cut into an upper
-// and a lower half of equal cost.  A wave drains the queue of its XCD first (sm_engine), so that an XCD's L2 holds
-// its region's part of the tree and the triangle streams.  The cuts run along the cells of a kGridW x kGridH grid over
-// the launch's region: forecast_kernel adds every block's forecast to its cell (queues[kQueueGrid ...]) and notes the
-// cell (item_cell); here the grid's marginals give the cuts, a table cell -> region the rest.
+// P.queues (MT_TUNE_XCD_QUEUES, mt_queues.h): eight work orders instead of one, sorted by (region, cost bucket).
 __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves, float quad_share, float quad_keep_share, int mode) {
   __shared__ unsigned long long s_sum;
   __shared__ unsigned s_count[kQueues * kSchedBuckets];
   __shared__ unsigned s_start[kQueues * kSchedBuckets];
-  __shared__ unsigned s_grid[kGridW * kGridH];
-  __shared__ unsigned char s_cellreg[kGridW * kGridH];
-  __shared__ unsigned long long s_colsum[kGridW];
-  __shared__ unsigned long long s_rowsum[4 * kGridH];
-  __shared__ int s_cut[kQueues + 1];                 // stripe s = cell columns [s_cut[s], s_cut[s + 1])
-  __shared__ int s_rowcut[kQueues];                  // mode 2: stripe s is cut in front of this cell row
+  __shared__ RegionShared s_reg;
   __shared__ unsigned s_qtotal[kQueues];
   const int tid = threadIdx.x;
   const bool queues = P.queues != nullptr && mode != 0;
   const int n_regions = queues ? kQueues : 1;
-  const int n_stripes = mode == 2 ? 4 : kQueues;
   if (tid == 0) s_sum = 0ull;
   for (int b = tid; b < n_regions * kSchedBuckets; b += kSchedThreads) s_count[b] = 0u;
-  if (queues) {
-    for (int c = tid; c < kGridW * kGridH; c += kSchedThreads) s_grid[c] = P.queues[kQueueGrid + c];
-    __syncthreads();
-    if (tid < kGridW) {
-      unsigned long long t = 0ull;
-      for (int y = 0; y < kGridH; y++) t += s_grid[y * kGridW + tid];
-      s_colsum[tid] = t;
-    }
-    __syncthreads();
-    // stripes of equal cost: cut s lies behind the first cell column at which the running cost reaches s / n_stripes of the total
-    if (tid <= n_stripes) {
-      unsigned long long total = 0ull;
-      for (int x = 0; x < kGridW; x++) total += s_colsum[x];
-      int cut = tid == 0 ? 0 : kGridW;
-      if (tid > 0 && tid < n_stripes && total != 0ull) {
-        unsigned long long acc = 0ull;
-        for (int x = 0; x < kGridW; x++) {
-          acc += s_colsum[x];
-          if (acc * (unsigned long long)n_stripes >= total * (unsigned long long)tid) {
-            cut = x + 1;
-            break;
-          }
-        }
-      }
-      s_cut[tid] = cut;
-    }
-    __syncthreads();
-    if (mode == 2) {  // per stripe the cell row that halves its cost
-      if (tid < 4 * kGridH) {
-        const int st = tid / kGridH, y = tid % kGridH;
-        unsigned long long t = 0ull;
-        for (int x = s_cut[st]; x < s_cut[st + 1] && x < kGridW; x++) t += s_grid[y * kGridW + x];
-        s_rowsum[tid] = t;
-      }
-      __syncthreads();
-      if (tid < 4) {
-        unsigned long long total = 0ull, acc = 0ull;
-        for (int y = 0; y < kGridH; y++) total += s_rowsum[tid * kGridH + y];
-        int cut = kGridH;
-        for (int y = 0; y < kGridH; y++) {
-          acc += s_rowsum[tid * kGridH + y];
-          if (acc * 2ull >= total) {
-            cut = y + 1;
-            break;
-          }
-        }
-        s_rowcut[tid] = cut;
-      }
-      __syncthreads();
-    }
-    for (int c = tid; c < kGridW * kGridH; c += kSchedThreads) {
-      const int cx = c % kGridW, cy = c / kGridW;
-      int st = 0;
-      while (st + 1 < n_stripes && cx >= s_cut[st + 1]) st++;
-      s_cellreg[c] = (unsigned char)(mode == 2 ? st * 2 + (cy >= s_rowcut[st] ? 1 : 0) : st);
-    }
-  }
+  if (queues) build_region_table(P, mode, s_reg, tid, kSchedThreads);
   __syncthreads();
   // (forecast_kernel has scaled the costs measured in quad mode -- sums over four
   // quarters, kQuadWork = 1.7 -- back to whole blocks)
@@ -636,7 +558,7 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
     for (int k = 0; k < kRound; k++) {
       const unsigned i = i0 + (unsigned)k * kSchedThreads;
       if (i < P.n_items) {
-        const unsigned u = unit_of(f[k], queues ? (unsigned)s_cellreg[reg[k]] : 0u);
+        const unsigned u = unit_of(f[k], queues ? (unsigned)s_reg.cellreg[reg[k]] : 0u);
         atomicAdd(&s_count[(u >> 24) * kSchedBuckets + (u & 0xffffu)], (u & 0x10000u) ? 4u : 1u);
       }
     }
@@ -677,7 +599,7 @@ __global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P,
     for (int k = 0; k < kRound; k++) {
       const unsigned i = i0 + (unsigned)k * kSchedThreads;
       if (i < P.n_items) {
-        const unsigned u = unit_of(f[k], queues ? (unsigned)s_cellreg[reg[k]] : 0u);
+        const unsigned u = unit_of(f[k], queues ? (unsigned)s_reg.cellreg[reg[k]] : 0u);
         const bool quad = (u & 0x10000u) != 0u;
         const unsigned r = u >> 24;
         const unsigned at = s_qtotal[r] + atomicAdd(&s_start[r * kSchedBuckets + (u & 0xffffu)], quad ? 4u : 1u);
@@ -815,52 +737,15 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
   // (hybrid launches: the state machine's units lie behind the pool's n_work[1] and have a counter of their own)
   const unsigned w_base = MIXED ? P.n_work[1] : 0u;
 
-  // one work order per XCD (P.queues): this wave's queue, the queues found empty so far
+  // one work order per XCD (mt_queues.h)
   const bool xcd_queues = !MIXED && !from_primary && P.queues != nullptr;
-  unsigned my_queue = 0u, dry = 0u, q_rank = 0u, q_len = 1u;
-  if (xcd_queues) {
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
-    my_queue = xcc & (unsigned)(kQueues - 1);
-  }
+  QueueFetch qf;
+  qf.init();
 
   for (;;) {
     unsigned w = carry;
-    if (xcd_queues) {
-      w = n_work;
-      while (dry != (1u << kQueues) - 1u) {
-        if ((dry >> my_queue) & 1u) {
-          // the own queue is dry: on to the one with the most units left (a glance, not a reservation)
-          unsigned left = 0u;
-          if (lane < kQueues) {
-            const unsigned s0 = P.queues[kQueueStart + lane], s1 = P.queues[kQueueStart + lane + 1];
-            const unsigned taken = __hip_atomic_load(P.queues + lane * kQueueStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            left = (taken < s1 - s0 && !((dry >> lane) & 1u)) ? s1 - s0 - taken : 0u;
-          }
-          unsigned best_left = 0u, best_q = 0u;
-          for (int q = 0; q < kQueues; q++) {
-            const unsigned l = (unsigned)__builtin_amdgcn_readlane((int)left, q);
-            if (l > best_left) {
-              best_left = l;
-              best_q = (unsigned)q;
-            }
-          }
-          if (best_left == 0u) break;
-          my_queue = best_q;
-        }
-        const unsigned s0 = P.queues[kQueueStart + my_queue], s1 = P.queues[kQueueStart + my_queue + 1];
-        const unsigned k = fetch_work(P.queues + my_queue * kQueueStride, lane);
-        if (k < s1 - s0) {
-          w = s0 + k;
-          q_rank = k;
-          q_len = s1 - s0;
-          break;
-        }
-        dry |= 1u << my_queue;
-      }
-    } else if (carry == kCarryNone) {
-      w = w_base + fetch_work(P.work_counter + (MIXED ? 2 : 1), lane);
-    }
+    if (xcd_queues) w = qf.next(P, lane, n_work);
+    else if (carry == kCarryNone) w = w_base + fetch_work(P.work_counter + (MIXED ? 2 : 1), lane);
     carry = kCarryNone;
     if (S.hb) {
       const unsigned long long ex = __builtin_amdgcn_read_exec();
@@ -874,7 +759,7 @@ __device__ __forceinline__ unsigned sm_engine(const DevScene &S, const RenderPar
       // (schedule_kernel); the longest blocks come as four quarters.
       item = P.order_item[w];
       sub = (int)P.order_sub[w];
-      const unsigned rank = xcd_queues ? q_rank : w, of = xcd_queues ? q_len : n_work;
+      const unsigned rank = xcd_queues ? qf.rank : w, of = xcd_queues ? qf.len : n_work;
       if (rank < (of >> 4)) __builtin_amdgcn_s_setprio(3);
       else if (rank < (of >> 2)) __builtin_amdgcn_s_setprio(2);
       else __builtin_amdgcn_s_setprio(0);
