@@ -16,7 +16,7 @@ torch.cuda.init(); torch.zeros(1, device="cuda")
 info = sg.write_scene(os.environ.get("SCENE", "room"), "/tmp/mt_scenes")
 m = M.MythTracer(info["obj"])
 flat = m.flatten()
-abi = M.hip_abi()
+abi = M.HipAbi(os.path.join(ROOT, "mythtracer_amd", "lib", "libmythtracer_hip_%s.so" % os.environ["LIB"])) if os.environ.get("LIB") else M.hip_abi()  # (LIB=<name>: a second build, for A/B runs on one box)
 W4, H4, T = 3840, 2160, int(os.environ.get("TILE", "64"))
 mw, mh = (W4 + 7) // 8, (H4 + 7) // 8
 tx, ty = tiling.tile_grid(W4, H4, T, T)
