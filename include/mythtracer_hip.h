@@ -360,15 +360,17 @@ enum {
                                  orders, one per XCD, each over a stripe of the picture with an eighth of the forecast cost
                                  (an XCD's L2 then holds its stripe's part of the tree; an XCD that runs dry takes units
                                  from the fullest other queue); 2 = a 4 x 2 grid of regions instead of stripes */
+  MT_TUNE_ORDER_GROUPS,       /* workgroups of the kernel that makes a launch's work order (forecast per block, units
+                                 longest first): 64; 1 .. 256, at most one per CU */
   MT_TUNE_COUNT
 };
 int mt_scene_set_tuning(mt_scene *scene, int knob, double value);
 
 /* Device durations of the launches made since the previous call (at most the
  * last 64, oldest first; at most max_n): primary_ms[i] = the kernels that
- * prepare the work order (mt::schedule_kernel with cost history, else
- * mt::primary_kernel; for the latency engine mt::probe_kernel +
- * mt::pool_schedule_kernel), render_ms[i] = the frame kernel
+ * prepare the work order (mt::order_kernel with cost history, else
+ * mt::primary_kernel; for the latency engine's first frame mt::probe_kernel +
+ * mt::order_kernel), render_ms[i] = the frame kernel
  * (mt::render_kernel or mt::pool_kernel) of launch i, from HIP events recorded on
  * the launch's own stream.  Waits for those launches.  Returns the number of
  * entries written, or a negative MT_ERR_*.  (No reference counterpart: the

@@ -33,7 +33,8 @@ TUNE = {name: i for i, name in enumerate([
     "POOL_CUT_SHARE", "POOL_PIECE_TIME1", "POOL_PIECE_TIME2", "POOL_PIECE_WORK1", "POOL_PIECE_WORK2",
     "POOL_CELL_FACTOR", "QUAD_SHARE", "QUAD_SHARE_MOVING", "QUAD_KEEP", "QUAD_WORK", "QUAD_WORK_MOVING",
     "POOL_SCRATCH_MB", "HYBRID_POOL_SHARE", "HYBRID_QUAD_SHARE", "HYBRID_WORK1", "HYBRID_WORK2", "FORECAST_STEP",
-    "HYBRID_STARTER_SHARE", "DEEP_LAYOUT", "MULTI_FORCE_PEER_COPY", "MULTI_BALANCE", "XCD_QUEUES"])}
+    "HYBRID_STARTER_SHARE", "DEEP_LAYOUT", "MULTI_FORCE_PEER_COPY", "MULTI_BALANCE", "XCD_QUEUES",
+    "ORDER_GROUPS"])}
 
 STAT_NAMES = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests",
               "node_visits", "tri_tests", "mt_tests", "shaded_hits"]

@@ -85,6 +85,7 @@ struct Tuning {
     v[MT_TUNE_DEEP_LAYOUT] = 1.0;
     v[MT_TUNE_MULTI_FORCE_PEER_COPY] = 0.0;
     v[MT_TUNE_MULTI_BALANCE] = 1.0;
+    v[MT_TUNE_ORDER_GROUPS] = (double)kOrdGroups;  // workgroups of order_kernel (mt_order.h)
     v[MT_TUNE_XCD_QUEUES] = 2.0;  // one work order per XCD over a 4 x 2 grid of regions of equal forecast cost (L2 hit rate 0.82 -> 0.92 room, 0.66 -> 0.82 loft)
   }
 };
@@ -103,6 +104,13 @@ struct mt_scene {
   unsigned long long *d_counters = nullptr;
   unsigned int *d_work = nullptr;
   unsigned int *d_queues = nullptr;  // kQueueWords: the per-XCD work orders' counters and bounds (RenderParams::queues)
+  unsigned int *d_order_ctl = nullptr;  // kOrdWords: the order kernels' sums, histograms, grids (zero at creation, never reset by the host)
+  unsigned int *d_order_woff = nullptr; // [kOrdGroupsMax][kOrdKeysMax]
+  unsigned int *d_item_unit = nullptr;
+  size_t item_unit_bytes = 0;
+  unsigned order_epoch = 0;             // order_kernel launches of this scene so far
+  DevScene dev_uploaded;                // what d_dev holds
+  bool dev_uploaded_valid = false;
   unsigned short *d_item_cell = nullptr;
   size_t item_cell_bytes = 0;
   double *d_frames = nullptr;      // throughput engine: recursion frames
@@ -456,6 +464,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_item, &s->order_item_bytes, (size_t)P.n_items * 64);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_order_sub, &s->order_sub_bytes, (size_t)P.n_items * 16);
     if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_item_form, &s->item_form_bytes, (size_t)P.n_items);
+    if (rc == MT_OK) rc = ensure_bytes((void **)&s->d_item_unit, &s->item_unit_bytes, (size_t)P.n_items * 4);
     if (rc != MT_OK) return rc;
   }
   P.item_cost = s->d_item_cost;
@@ -517,15 +526,18 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     HIP_TRY(hipMemset(d_item, 0, (size_t)P.n_items * 16 * 16 * 4));
     P.item_cycles = d_item;
   }
-  HIP_TRY(hipMemsetAsync(s->d_work, 0, 16 * sizeof(unsigned), stream));
   if (P.n_items == 0) return MT_OK;
+  // (launches with a work order: order_kernel zeroes the counters on its way)
+  if (!history && !pool_engine) HIP_TRY(hipMemsetAsync(s->d_work, 0, 16 * sizeof(unsigned), stream));
+  P.order_ctl = s->d_order_ctl;
+  P.order_woff = s->d_order_woff;
+  P.item_unit = s->d_item_unit;
   // one work order per XCD: state-machine launches with a cost history only (the other engines keep the one order)
   // (measured and left out: first frames through the ray pool -- room 8.4 -> 8.9 ms, loft 19.7 -> 20.9: the probe's guess
   // balances the regions too roughly, and such a frame ends with its longest units either way --; the state machine's
   // part of hybrid launches, i.e. a rank's share of a frame -- mean of eight ranks' 4K shares 2.71 -> 2.77 ms)
   P.queues = (s->tune.v[MT_TUNE_XCD_QUEUES] != 0.0 && history && !pool_engine && !hybrid) ? s->d_queues : nullptr;
   if (P.queues) {
-    HIP_TRY(hipMemsetAsync(s->d_queues, 0, kQueueWords * sizeof(unsigned), stream));
     int rc = ensure_bytes((void **)&s->d_item_cell, &s->item_cell_bytes, (size_t)P.n_items * 2);
     if (rc != MT_OK) return rc;
     P.item_cell = s->d_item_cell;
@@ -536,7 +548,11 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     int rc = ensure_deep(s, std::max(waves, probe_waves));
     if (rc != MT_OK) return rc;
   }
-  HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
+  if (!s->dev_uploaded_valid || memcmp(&s->dev_uploaded, &s->dev, sizeof(DevScene)) != 0) {  // (nearly never: the scene description changes with the lights, the traversal mode, the layout)
+    HIP_TRY(hipMemcpyAsync(s->d_dev, &s->dev, sizeof(DevScene), hipMemcpyHostToDevice, stream));
+    memcpy(&s->dev_uploaded, &s->dev, sizeof(DevScene));
+    s->dev_uploaded_valid = true;
+  }
   // events: [0] -> [1] forecast / classification + work order; [1] -> [2] the frame kernel
   hipEvent_t *ek = s->ev_k[s->launches_timed % mt_scene::kTimedLaunches];
   for (int i = 0; i < 3; i++) {
@@ -552,23 +568,27 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   // expression, Sensor::GetRay), zero for at most the pixels next to -r / dp -- a whole column or row for a camera on
   // an axis, isolated pixels for one with roll or pitch.  Those blocks' costs are skipped by a re-projected forecast
   // (forecast_kernel).
-  int old_irr = 0;
-  if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {
-    const mt_sensor &o = s->cost_sensor;
-    for (int k = 0; k < 3 && !old_irr; k++) {
-      for (int y = 0; y < image_h && !old_irr; y++) {
+  auto has_zero_component_pixel = [&](const mt_sensor &o) -> int {
+    for (int k = 0; k < 3; k++) {
+      for (int y = 0; y < image_h; y++) {
         const double r = o.start_point[k] + o.delta_scanline[k] * (double)y;
         if (o.delta_pixel[k] == 0.0 || !std::isfinite(r / o.delta_pixel[k])) {
-          if (r + o.delta_pixel[k] * 0.0 == 0.0) old_irr = 1;
+          if (r + o.delta_pixel[k] * 0.0 == 0.0) return 1;
           continue;
         }
         const double x0 = std::nearbyint(-r / o.delta_pixel[k]);
         for (int dx = -1; dx <= 1; dx++) {
           const double x = x0 + dx;
-          if (x >= 0.0 && x < (double)image_w && r + o.delta_pixel[k] * x == 0.0) old_irr = 1;
+          if (x >= 0.0 && x < (double)image_w && r + o.delta_pixel[k] * x == 0.0) return 1;
         }
       }
     }
+    return 0;
+  };
+  int old_irr = 0, new_irr = 0;
+  if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {
+    old_irr = has_zero_component_pixel(s->cost_sensor);
+    new_irr = has_zero_component_pixel(*sensor);
     reproject = 1;
     radius = memcmp(s->cost_sensor.origin, sensor->origin, sizeof sensor->origin) != 0 ? 2 : 1;
     if (s->tune.v[MT_TUNE_FORECAST_RADIUS] >= 0.0) radius = (int)s->tune.v[MT_TUNE_FORECAST_RADIUS];
@@ -598,12 +618,18 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
                    (float)tv[MT_TUNE_POOL_CELL_FACTOR],
                    (!from_map && (!history || s->last_engine == 2)) ? 1 : 0};  // a forecast is cut more eagerly (own_costs: granularity in bits 30-31)
     if (tv[MT_TUNE_POOL_CUT_SHARE] >= 0.0) sp.cut_share = (float)tv[MT_TUNE_POOL_CUT_SHARE];
-    hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
-                       reproject, radius, (history && (s->last_engine == 1 || s->last_engine == 3)) ? 0 : 1,
-                       (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u, blend,
-                       (history && s->last_engine == 3) ? s->d_item_form : nullptr, (float)tv[MT_TUNE_HYBRID_WORK1], (float)tv[MT_TUNE_HYBRID_WORK2], (float)tv[MT_TUNE_FORECAST_STEP], old_irr);
-    hipLaunchKernelGGL(pool_schedule_kernel, dim3(1), dim3(kPoolSchedThreads), 0, stream, P,
-                       s->grid_blocks * s->waves_per_block, sp);
+    ForecastArgs fa{s->cost_sensor, reproject, radius, (history && (s->last_engine == 1 || s->last_engine == 3)) ? 0 : 1,
+                    (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u, blend,
+                    (history && s->last_engine == 3) ? s->d_item_form : nullptr, (float)tv[MT_TUNE_HYBRID_WORK1],
+                    (float)tv[MT_TUNE_HYBRID_WORK2], (float)tv[MT_TUNE_FORECAST_STEP], old_irr, new_irr};
+    OrderArgs oa{};
+    oa.n_waves = s->grid_blocks * s->waves_per_block;
+    oa.epoch = s->order_epoch++;
+    const int ord_groups = std::max(1, std::min((int)s->tune.v[MT_TUNE_ORDER_GROUPS], kOrdGroupsMax));
+    oa.sp = sp;
+    hipLaunchKernelGGL(order_forecast_kernel<2>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, fa, oa);
+        hipLaunchKernelGGL(order_count_kernel<2>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, oa);
+        hipLaunchKernelGGL(order_scatter_kernel<2>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, oa);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ek[1], stream));
     MT_LAUNCH_SD(pool_kernel, s->stats_enabled, grid, block, s->lds_bytes, stream, s->dev, P);
@@ -620,20 +646,34 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       const float quad_keep = (float)s->tune.v[MT_TUNE_QUAD_KEEP];
       // work of a block rendered as quarters / rendered whole (swept with the share): 1.5 / 1.7
       const float quad_work = (float)s->tune.v[reproject ? MT_TUNE_QUAD_WORK_MOVING : MT_TUNE_QUAD_WORK];
-      hipLaunchKernelGGL(forecast_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, stream, P, s->cost_sensor,
-                         reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f, 16000u, blend,
-                         s->last_engine == 3 ? s->d_item_form : nullptr, (float)s->tune.v[MT_TUNE_HYBRID_WORK1], (float)s->tune.v[MT_TUNE_HYBRID_WORK2], (float)s->tune.v[MT_TUNE_FORECAST_STEP], old_irr);
+      const double *tv = s->tune.v;
+      ForecastArgs fa{s->cost_sensor, reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f,
+                      16000u, blend, s->last_engine == 3 ? s->d_item_form : nullptr, (float)tv[MT_TUNE_HYBRID_WORK1],
+                      (float)tv[MT_TUNE_HYBRID_WORK2], (float)tv[MT_TUNE_FORECAST_STEP], old_irr, new_irr};
+      OrderArgs oa{};
+      oa.n_waves = s->grid_blocks * s->waves_per_block;
+      oa.epoch = s->order_epoch++;
+    const int ord_groups = std::max(1, std::min((int)s->tune.v[MT_TUNE_ORDER_GROUPS], kOrdGroupsMax));
       if (hybrid) {
-        const double *tv = s->tune.v;
         const float k = reproject ? (float)(tv[MT_TUNE_QUAD_SHARE_MOVING] / tv[MT_TUNE_QUAD_SHARE]) : 1.0f;  // a re-projected forecast is cut more eagerly
-        hipLaunchKernelGGL(hybrid_schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
-                           s->grid_blocks * s->waves_per_block, k * (float)tv[MT_TUNE_HYBRID_QUAD_SHARE],
-                           k * (float)tv[MT_TUNE_HYBRID_POOL_SHARE], (float)tv[MT_TUNE_POOL_PIECE_TIME1],
-                           (float)tv[MT_TUNE_POOL_PIECE_TIME2], (float)tv[MT_TUNE_POOL_CELL_FACTOR], s->d_item_form,
-                           (float)tv[MT_TUNE_HYBRID_STARTER_SHARE], (unsigned)std::min(s->grid_blocks, (int)(0.25 * s->grid_blocks * s->waves_per_block)));
+        oa.quad_share = k * (float)tv[MT_TUNE_HYBRID_QUAD_SHARE];
+        oa.pool_share = k * (float)tv[MT_TUNE_HYBRID_POOL_SHARE];
+        oa.piece_time1 = (float)tv[MT_TUNE_POOL_PIECE_TIME1];
+        oa.piece_time2 = (float)tv[MT_TUNE_POOL_PIECE_TIME2];
+        oa.cell_factor = (float)tv[MT_TUNE_POOL_CELL_FACTOR];
+        oa.form_out = s->d_item_form;
+        oa.starter_share = (float)tv[MT_TUNE_HYBRID_STARTER_SHARE];
+        oa.max_starters = (unsigned)std::min(s->grid_blocks, (int)(0.25 * s->grid_blocks * s->waves_per_block));
+        hipLaunchKernelGGL(order_forecast_kernel<1>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, fa, oa);
+        hipLaunchKernelGGL(order_count_kernel<1>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, oa);
+        hipLaunchKernelGGL(order_scatter_kernel<1>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, oa);
       } else {
-        hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(kSchedThreads), 0, stream, P,
-                           s->grid_blocks * s->waves_per_block, quad_share, quad_keep, (int)s->tune.v[MT_TUNE_XCD_QUEUES]);
+        oa.quad_share = quad_share;
+        oa.quad_keep = quad_keep;
+        oa.queue_mode = (int)tv[MT_TUNE_XCD_QUEUES];
+        hipLaunchKernelGGL(order_forecast_kernel<0>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, fa, oa);
+        hipLaunchKernelGGL(order_count_kernel<0>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, oa);
+        hipLaunchKernelGGL(order_scatter_kernel<0>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, oa);
       }
     } else {
       MT_LAUNCH_SD(primary_kernel, s->stats_enabled, grid, block, s->lds_bytes, stream, s->dev, P);
@@ -769,6 +809,7 @@ void mt_scene_destroy(mt_scene *s) {
   if (s->d_cost_map) (void)hipFree(s->d_cost_map);
   if (s->d_order_item) (void)hipFree(s->d_order_item);
   if (s->d_item_cell) (void)hipFree(s->d_item_cell);
+  if (s->d_item_unit) (void)hipFree(s->d_item_unit);
   if (s->d_order_sub) (void)hipFree(s->d_order_sub);
   if (s->d_rgb) (void)hipFree(s->d_rgb);
   if (s->d_debug) (void)hipFree(s->d_debug);
@@ -1217,6 +1258,11 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   s->allocs.push_back(s->d_work);
   HIP_TRY(hipMalloc((void **)&s->d_queues, kQueueWords * sizeof(unsigned)));
   s->allocs.push_back(s->d_queues);
+  HIP_TRY(hipMalloc((void **)&s->d_order_ctl, kOrdWords * sizeof(unsigned)));
+  s->allocs.push_back(s->d_order_ctl);
+  HIP_TRY(hipMemset(s->d_order_ctl, 0, kOrdWords * sizeof(unsigned)));
+  HIP_TRY(hipMalloc((void **)&s->d_order_woff, (size_t)kOrdGroupsMax * kOrdKeysMax * sizeof(unsigned)));
+  s->allocs.push_back(s->d_order_woff);
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
   if ((rc = mt_scene_set_lights(s, nullptr, 0)) != MT_OK) return rc;
@@ -1346,6 +1392,9 @@ int mt_scene_set_tuning(mt_scene *s, int knob, double value) {
       break;
     case MT_TUNE_POOL_CUT_SHARE:
       if (!(value < 0.0 || (value >= 1e-6 && value <= 1e6))) return fail(MT_ERR_ARG, "the pool's cutting share must be negative (automatic) or lie in [1e-6, 1e6]");
+      break;
+    case MT_TUNE_ORDER_GROUPS:
+      if (!(value >= 1.0 && value <= (double)kOrdGroupsMax)) return fail(MT_ERR_ARG, "the work-order kernel runs on 1 .. %d workgroups", kOrdGroupsMax);
       break;
     case MT_TUNE_XCD_QUEUES:
       if (!(value == 0.0 || value == 1.0 || value == 2.0)) return fail(MT_ERR_ARG, "XCD queues: 0 (off), 1 (stripes) or 2 (grid)");

@@ -236,12 +236,14 @@ struct RenderParams {
   // [queues[kQueueStart + q], queues[kQueueStart + q + 1]) of order_item / order_sub, longest first, and hands them out
   // through the counter queues[q * kQueueStride]
   unsigned int *queues;
-  unsigned short *item_cell;  // [n_items] the block's cell of the region grid (forecast_kernel -> schedule_kernel)
+  unsigned short *item_cell;  // [n_items] the block's cell of the region grid (mt_order.h)
+  unsigned int *order_ctl;    // the order kernels' forecast sums, histograms, region grids (kOrdWords; never reset by the host)
+  unsigned int *item_unit;    // [n_items] what the block becomes in this launch, packed (order_count_kernel -> order_scatter_kernel)
+  unsigned int *order_woff;   // [workgroups][kOrdKeysMax] a workgroup's offset within each key it has units under
 };
 constexpr int kQueues = 8, kQueueStride = 32, kQueueStart = kQueues * kQueueStride;  // (a counter per 128-byte line)
-constexpr int kGridW = 128, kGridH = 64;           // the region grid: forecast cost per cell, queues[kQueueGrid + cy * kGridW + cx]
-constexpr int kQueueGrid = kQueueStart + 32;
-constexpr int kQueueWords = kQueueGrid + kGridW * kGridH;
+constexpr int kGridW = 64, kGridH = 32;            // the region grid: forecast cost per cell (order_kernel's area)
+constexpr int kQueueWords = kQueueStart + 32;
 
 // slot j of a launch -> tile of the region's grid, and back (-1: not this launch's)
 __device__ __forceinline__ int tile_of_slot(const RenderParams &P, int j) {

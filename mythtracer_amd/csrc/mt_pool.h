@@ -154,7 +154,7 @@ __device__ __forceinline__ void pool_flush_item_stats(LaneStats &st, unsigned lo
 // primary rays of FOUR pixels per 8x8 block are traced (1/16 of the primary
 // rays; a lane per sample, so a wave probes 16 blocks) and the block is
 // weighted by the most expensive material they see -- reflective and
-// transparent surfaces start recursions -- so that pool_schedule_kernel can hand
+// transparent surfaces start recursions -- so that order_kernel can hand
 // out the blocks that are probably long first and in pieces.  (One sample per
 // block misses the rims of the glass spheres: those blocks then run late and
 // whole, and the first frame took 21 ms instead of 14.)  The forecast only
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void probe_kernel(DevScene 
 
 // ---------------------------------------------------------------------------
 // Work order from the block costs of the previous frame (or from
-// probe_kernel's forecast): one block of 1024 threads, a few microseconds.
+// probe_kernel's forecast), made by order_kernel<2> (mt_order.h):
 //   * units are handed out longest first (bucket sort on log2 of the expected
 //     cost, eight buckets per octave);
 //   * a unit is traced by ONE wave, pass after pass, and the frame cannot end
@@ -256,56 +256,9 @@ __device__ __forceinline__ void sched_decide(unsigned word, unsigned forecast, f
   if (c > thr) level = (c * sp.piece_time[1] > sp.cell_factor * thr) ? 2 : 1;
   unit_cost = (unsigned)(c * sp.piece_time[level]);
 }
-__global__ __launch_bounds__(kPoolSchedThreads) void pool_schedule_kernel(RenderParams P, int n_waves, SchedParams sp) {
-  __shared__ unsigned long long s_sum;
-  __shared__ unsigned s_count[kPoolSchedBuckets];
-  __shared__ unsigned s_start[kPoolSchedBuckets];
-  const int tid = threadIdx.x;
-  if (tid == 0) s_sum = 0ull;
-  for (int b = tid; b < kPoolSchedBuckets; b += kPoolSchedThreads) s_count[b] = 0u;
-  __syncthreads();
-  unsigned long long part = 0ull;
-  for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) part += P.item_forecast[i] & 0x7fffffffu;  // (bit 31: a note for the state machine's scheduler)
-  atomicAdd(&s_sum, part);
-  __syncthreads();
-  const float share = (float)s_sum / (float)(n_waves > 0 ? n_waves : 1);
-  const float cut_above = share * sp.cut_share;
-  // pass 1: bucket counts
-  for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) {
-    int level;
-    unsigned unit;
-    sched_decide(P.item_cost[i], P.item_forecast[i] & 0x7fffffffu, cut_above, sp, level, unit);
-    atomicAdd(&s_count[pool_cost_bucket(unit)], level == 0 ? 1u : (level == 1 ? 4u : 16u));
-  }
-  __syncthreads();
-  if (tid == 0) {
-    unsigned acc = 0u;
-    for (int b = 0; b < kPoolSchedBuckets; b++) {
-      s_start[b] = acc;
-      acc += s_count[b];
-    }
-    *P.n_work = acc;
-  }
-  __syncthreads();
-  // pass 2: scatter, and reset the costs for the coming frame (bits 30-31 note
-  // the granularity the block will be measured at)
-  for (unsigned i = tid; i < P.n_items; i += kPoolSchedThreads) {
-    int level;
-    unsigned unit;
-    sched_decide(P.item_cost[i], P.item_forecast[i] & 0x7fffffffu, cut_above, sp, level, unit);
-    const unsigned n = level == 0 ? 1u : (level == 1 ? 4u : 16u);
-    const unsigned at = atomicAdd(&s_start[pool_cost_bucket(unit)], n);
-    for (unsigned q = 0; q < n; q++) {
-      P.order_item[at + q] = i;
-      P.order_sub[at + q] = (signed char)(level == 0 ? -1 : (level == 1 ? (int)q : 4 + (int)q));
-    }
-    P.item_cost[i] = (unsigned)level << 30;
-  }
-}
-
 // ---------------------------------------------------------------------------
 // The frame kernel: TraceRayWorker for every pixel of the launch's tiles and
-// the pixel store.  Persistent waves pull work units in pool_schedule_kernel's
+// the pixel store.  Persistent waves pull work units in order_kernel's
 // order; the first ones (the longest) run at raised wave priority.
 // pool_engine is the body shared by pool_kernel (all units of the launch) and hybrid_kernel (mt_render.hip; MIXED: the
 // order holds units of both engines -- the pool's first, n_work[1] of them, marked by kHybridPoolSub in order_sub and

@@ -8,83 +8,88 @@
 // helps with the fullest other queue: an XCD's L2 holds its region's part of the tree and of the triangle streams
 // (0.92 / 0.82).  The order changes nothing about what is computed for a pixel.
 //
-// The cuts run along the cells of a kGridW x kGridH grid over the launch's region: forecast_kernel adds every block's
-// forecast to its cell (queues[kQueueGrid ...]) and notes the cell (item_cell); the schedule kernels turn the grid's
-// marginals into cuts and a table cell -> region (build_region_table), and sort by (region, cost bucket).
+// The cuts run along the cells of a kGridW x kGridH (64 x 32) grid over the launch's region: order_kernel (mt_order.h) adds every
+// block's forecast to its cell and notes the cell (item_cell), turns the grid's marginals into cuts and a table
+// cell -> region (build_region_table), and sorts by (region, cost bucket).
 #pragma once
 #include "mt_device.h"
 
 namespace mt {
 
-// forecast_kernel: block i (position bx, by in the launch's region, in blocks) with forecast f
-__device__ __forceinline__ void note_cell(const RenderParams &P, unsigned i, unsigned f, int bx, int by) {
-  const int n_cols = (P.region_w + 7) >> 3, n_rows = (P.region_h + 7) >> 3;
-  int cx = bx * kGridW / (n_cols > 0 ? n_cols : 1), cy = by * kGridH / (n_rows > 0 ? n_rows : 1);
-  cx = cx < 0 ? 0 : (cx < kGridW ? cx : kGridW - 1);
-  cy = cy < 0 ? 0 : (cy < kGridH ? cy : kGridH - 1);
-  const unsigned cell = (unsigned)(cy * kGridW + cx);
-  P.item_cell[i] = (unsigned short)cell;
-  atomicAdd(P.queues + kQueueGrid + cell, ((f & 0x7fffffffu) >> 6) + 1u);  // (+ 1: a block costs something whatever its forecast says)
-}
-
+static_assert(kGridW == 64 && kGridH == 32, "build_region_table deals its steps out to 1 024 threads by these sizes");
 struct RegionShared {
   unsigned grid[kGridW * kGridH];
   unsigned char cellreg[kGridW * kGridH];  // cell -> region
-  unsigned long long colsum[kGridW];
+  unsigned long long colsum[kGridW];       // cost per cell column, then its running sum
   unsigned long long rowsum[4 * kGridH];
   int cut[kQueues + 1];   // stripe s = cell columns [cut[s], cut[s + 1])
   int rowcut[kQueues];    // mode 2: stripe s is cut in front of this cell row
 };
 
-// All threads of the (single) workgroup call this; R.cellreg is valid after it returns.
-__device__ __forceinline__ void build_region_table(const RenderParams &P, int mode, RegionShared &R, int tid, int n_threads) {
+// All threads of the workgroup call this (n_threads = 1 024); R.cellreg is valid after it returns.
+// `grid`: filled by order_forecast_kernel's atomics (mt_order.h).
+// Every step is spread over the workgroup's threads (the serial form on a grid of 128 x 64 cells -- a thread per stripe
+// walking the columns -- took 19 us of dependent LDS reads in front of every frame).
+__device__ __forceinline__ void build_region_table(const unsigned *grid, int mode, RegionShared &R, int tid, int n_threads) {
   const int n_stripes = mode == 2 ? 4 : kQueues;
-  for (int c = tid; c < kGridW * kGridH; c += n_threads) R.grid[c] = P.queues[kQueueGrid + c];
+  {  // (both loads of a thread in flight together)
+    const int c0 = tid, c1 = tid + n_threads;
+    const unsigned v0 = c0 < kGridW * kGridH ? grid[c0] : 0u;
+    const unsigned v1 = c1 < kGridW * kGridH ? grid[c1] : 0u;
+    if (c0 < kGridW * kGridH) R.grid[c0] = v0;
+    if (c1 < kGridW * kGridH) R.grid[c1] = v1;
+  }
+  if (tid < kGridW) R.colsum[tid] = 0ull;
+  if (tid < 4 * kGridH) R.rowsum[tid] = 0ull;
+  if (tid <= kQueues) R.cut[tid] = tid == 0 ? 0 : kGridW;
+  if (tid < kQueues) R.rowcut[tid] = kGridH;
   __syncthreads();
-  if (tid < kGridW) {
-    unsigned long long t = 0ull;
-    for (int y = 0; y < kGridH; y++) t += R.grid[y * kGridW + tid];
-    R.colsum[tid] = t;
+  {  // cost per cell column: sixteen threads per column, two rows each
+    const int col = tid & (kGridW - 1), part = tid / kGridW;
+    if (part < kGridH / 2) {
+      const unsigned long long t = (unsigned long long)R.grid[(2 * part) * kGridW + col] + R.grid[(2 * part + 1) * kGridW + col];
+      if (t != 0ull) atomicAdd(&R.colsum[col], t);
+    }
   }
   __syncthreads();
-  // stripes of equal cost: cut s lies behind the first cell column at which the running cost reaches s / n_stripes of the total
-  if (tid <= n_stripes) {
-    unsigned long long total = 0ull;
-    for (int x = 0; x < kGridW; x++) total += R.colsum[x];
-    int cut = tid == 0 ? 0 : kGridW;
-    if (tid > 0 && tid < n_stripes && total != 0ull) {
-      unsigned long long acc = 0ull;
-      for (int x = 0; x < kGridW; x++) {
-        acc += R.colsum[x];
-        if (acc * (unsigned long long)n_stripes >= total * (unsigned long long)tid) {
-          cut = x + 1;
-          break;
-        }
+  // running sum over the columns (one wave), then the cuts: cut s lies behind the first cell column at which the running
+  // cost reaches s / n_stripes of the total
+  if (tid < kGridW) {
+    unsigned long long run = R.colsum[tid];
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long v = __shfl_up(run, d, 64);
+      if (tid >= d) run += v;
+    }
+    const unsigned long long total = __shfl(run, 63, 64), before = __shfl_up(run, 1, 64);
+    if (total != 0ull) {
+      for (int st = 1; st < n_stripes; st++) {
+        const unsigned long long want = total * (unsigned long long)st;
+        if (run * (unsigned long long)n_stripes >= want && !(tid > 0 && before * (unsigned long long)n_stripes >= want)) R.cut[st] = tid + 1;
       }
     }
-    R.cut[tid] = cut;
   }
   __syncthreads();
-  if (mode == 2) {  // per stripe the cell row that halves its cost
-    if (tid < 4 * kGridH) {
-      const int st = tid / kGridH, y = tid % kGridH;
-      unsigned long long t = 0ull;
-      for (int x = R.cut[st]; x < R.cut[st + 1] && x < kGridW; x++) t += R.grid[y * kGridW + x];
-      R.rowsum[tid] = t;
+  if (mode == 2) {  // per stripe the cell row that halves its cost: eight threads per (stripe, row), every eighth column each
+    {
+      const int y = tid & (kGridH - 1), st = (tid / kGridH) & 3, part = tid / (4 * kGridH);
+      if (part < 8) {
+        unsigned long long t = 0ull;
+        for (int x = R.cut[st] + part; x < R.cut[st + 1] && x < kGridW; x += 8) t += R.grid[y * kGridW + x];
+        if (t != 0ull) atomicAdd(&R.rowsum[st * kGridH + y], t);
+      }
     }
     __syncthreads();
-    if (tid < 4) {
-      unsigned long long total = 0ull, acc = 0ull;
-      for (int y = 0; y < kGridH; y++) total += R.rowsum[tid * kGridH + y];
-      int cut = kGridH;
-      for (int y = 0; y < kGridH; y++) {
-        acc += R.rowsum[tid * kGridH + y];
-        if (acc * 2ull >= total) {
-          cut = y + 1;
-          break;
-        }
+    if (tid < 4 * kGridH) {  // half a wave per stripe
+      const int st = tid / kGridH, y = tid & (kGridH - 1);
+      unsigned long long acc = R.rowsum[tid];
+      for (int d = 1; d < kGridH; d <<= 1) {
+        const unsigned long long v = __shfl_up(acc, d, kGridH);
+        if (y >= d) acc += v;
       }
-      R.rowcut[tid] = cut;
+      const unsigned long long total = __shfl(acc, kGridH - 1, kGridH);
+      const unsigned long long reached64 = __ballot(acc * 2ull >= total);
+      const unsigned reached = (unsigned)(reached64 >> (32 * (st & 1)));
+      if (y == 0) R.rowcut[st] = reached != 0u ? __builtin_ctz(reached) + 1 : kGridH;
     }
     __syncthreads();
   }

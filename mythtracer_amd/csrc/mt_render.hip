@@ -220,11 +220,10 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScen
 }
 
 // ---------------------------------------------------------------------------
-// Work order from the previous frame's measured block costs (one block of 1024
-// threads, a few microseconds).  A frame cannot finish before its slowest work
-// item, and the per-pixel ray chains cannot be split, so:
-//   * blocks are handed out longest first (bucket sort on log2 of the cost,
-//     eight buckets per octave);
+// The work order of a launch with a cost history -- forecast per block, units longest first, the longest blocks in
+// pieces -- is made by order_kernel (mt_order.h, included below).  A frame cannot finish before its slowest work
+// item, and the per-pixel ray chains cannot be split, so for the state machine:
+//   * blocks are handed out longest first (bucket sort on log2 of the cost, eight buckets per octave);
 //   * blocks that took longer than quad_share (0.8) of an even share of the
 //     frame's work are cut into four quarters with FOUR lanes per pixel (the
 //     shadow loops of a pixel's lights run side by side: a shorter chain for
@@ -234,168 +233,6 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScen
 // The order changes nothing about what is computed for a pixel.  Costs are in
 // units of 64 s_memtime ticks; a block rendered as quarters reports their sum,
 // which is scaled back (kQuadWork) before it is compared again.
-// Cost forecast from the previous frame's measured block costs.  When the
-// camera has not moved a block's forecast is its own last cost.  When it has
-// (an animation: main_local.cc:51-76 turns it 2 degrees per frame, 25..70
-// pixels depending on where in the picture), what was expensive in block b is
-// now somewhere else: the centre ray of every block of the NEW frame is
-// projected into the OLD camera's image (exact for a rotation; a translation
-// adds parallax, hence `radius`), and the forecast is the maximum over the old
-// blocks within `radius` of that position -- or, for a direction the old frame
-// did not see, `unseen`, the mean cost of a block.  The forecast only orders
-// the work and picks the blocks handed out in pieces.
-// pool != 0: cost words of the latency engine (granularity in bits 30-31).
-// form != nullptr: the previous launch was a HYBRID one -- form[b] = how block b was rendered: 0 / 1 by the state
-// machine (whole / as quarters: bit 31 of its cost word, as ever), 2 / 3 by the ray pool as quarters / cells, whose
-// summed costs are scaled to the state machine's whole-block scale by wq / wc.
-__global__ void forecast_kernel(RenderParams P, mt_sensor old, int reproject, int radius, int pool, float w1,
-                                float w2, unsigned unseen, float blend, const unsigned char *form, float wq, float wc,
-                                float step_px, int old_irr) {
-  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.n_items) return;
-  auto cost_of = [&](unsigned word, unsigned idx) -> unsigned {
-    if (form != nullptr && form[idx] >= 2) {
-      return (unsigned)((float)(word & 0x3fffffffu) / (form[idx] == 2 ? wq : wc));
-    }
-    if (pool) {
-      const unsigned lvl = word >> 30;
-      const float c = (float)(word & 0x3fffffffu);
-      return (unsigned)(lvl == 1u ? c / w1 : (lvl >= 2u ? c / w2 : c));
-    }
-    const float c = (float)(word & 0x7fffffffu);
-    return (unsigned)((word >> 31) ? c / w1 : c);
-  };
-  if (!reproject && P.from_map) {
-    // A tile-list launch whose list differs from the previous launch's (the ownership of the tiles was re-balanced):
-    // the slots' own cost words belong to other tiles; the block's cost comes from the frame-wide map (all ranks' costs
-    // of the previous frame, mt_scene_import_costs_device) at its own position.  0 = nobody reported it.
-    const int per_tile_ = P.blocks_x * P.blocks_y;
-    const int j_ = (int)(i / (unsigned)per_tile_), b_ = (int)(i % (unsigned)per_tile_);
-    const int tile_ = tile_of_slot(P, j_);
-    const int bx_ = (P.region_x + (tile_ % P.tiles_x) * P.tile_w + (b_ % P.blocks_x) * 8) >> 3;
-    const int by_ = (P.region_y + (tile_ / P.tiles_x) * P.tile_h + (b_ / P.blocks_x) * 8) >> 3;
-    unsigned f = unseen;
-    if (bx_ < P.cost_map_w && by_ < P.cost_map_h) {
-      const unsigned c = P.cost_map[(size_t)by_ * P.cost_map_w + bx_];
-      if (c != 0u) f = c;
-    }
-    P.item_forecast[i] = f;
-    if (P.queues) note_cell(P, i, f, bx_ - (P.region_x >> 3), by_ - (P.region_y >> 3));
-    return;
-  }
-  if (!reproject) {
-    // (bit 31, state machine only: the block was rendered as quarters -- schedule_kernel's hysteresis)
-    // blend > 0 (the camera stands still and the previous launch made a forecast too): the new forecast is a mix
-    // of the old one and the measurement -- a block near a cutting threshold is otherwise measured whole in one
-    // frame and in pieces in the next, and the schedule alternates between two states
-    unsigned f = cost_of(P.item_cost[i], i);
-    if (!pool && P.item_whole != nullptr && !(form != nullptr && form[i] >= 2)) {
-      // A block near the cutting threshold: measured whole it costs c, in four pieces s, and s / w1 is only a guess
-      // of c -- when the guess is below the threshold and c above it, the block changes its form every few frames
-      // and every frame that renders it whole ends late.  Once both have been measured, THEIR ratio scales the one to
-      // the other, and the forecast of the block no longer depends on the form it was rendered in.
-      const unsigned word = P.item_cost[i], c = word & 0x7fffffffu;
-      if (word >> 31) P.item_qsum[i] = c; else P.item_whole[i] = c;
-      const unsigned w = P.item_whole[i], qs = P.item_qsum[i];
-      if ((word >> 31) && w > 0u && qs > 0u) {
-        const float ratio = fminf(fmaxf((float)qs / (float)w, 1.0f), 4.0f);
-        f = (unsigned)((float)c / ratio);
-      }
-    }
-    if (blend > 0.0f) f = (unsigned)(blend * (float)(P.item_forecast[i] & 0x7fffffffu) + (1.0f - blend) * (float)f);
-    P.item_forecast[i] = f | (pool ? 0u : (P.item_cost[i] & 0x80000000u));
-    if (P.queues) {
-      const int per_tile_ = P.blocks_x * P.blocks_y;
-      const int j_ = (int)(i / (unsigned)per_tile_), b_ = (int)(i % (unsigned)per_tile_);
-      const int tile_ = tile_of_slot(P, j_);
-      note_cell(P, i, f, (((tile_ % P.tiles_x) * P.tile_w) >> 3) + b_ % P.blocks_x, (((tile_ / P.tiles_x) * P.tile_h) >> 3) + b_ / P.blocks_x);
-    }
-    return;
-  }
-  const int per_tile = P.blocks_x * P.blocks_y;
-  const int j = (int)(i / (unsigned)per_tile), b = (int)(i % (unsigned)per_tile);
-  const int tile = tile_of_slot(P, j);
-  const int tx0 = P.region_x + (tile % P.tiles_x) * P.tile_w, ty0 = P.region_y + (tile / P.tiles_x) * P.tile_h;
-  const double px = tx0 + (b % P.blocks_x) * 8 + 4.0, py = ty0 + (b / P.blocks_x) * 8 + 4.0;  // block centre
-  double d[3], m[3][3];
-  for (int k = 0; k < 3; k++) {
-    d[k] = P.sensor.start_point[k] + P.sensor.delta_scanline[k] * py + P.sensor.delta_pixel[k] * px;
-    m[k][0] = old.delta_pixel[k];
-    m[k][1] = old.delta_scanline[k];
-    m[k][2] = -d[k];
-  }
-  // old.start + old.dp * x + old.ds * y = lambda * d   (Cramer's rule)
-  auto det3 = [](const double a[3][3]) {
-    return a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
-           a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
-  };
-  const double D = det3(m);
-  unsigned best = unseen;
-  if (D != 0.0) {
-    double mx[3][3], my[3][3], ml[3][3];
-    for (int k = 0; k < 3; k++) {
-      for (int c = 0; c < 3; c++) mx[k][c] = my[k][c] = ml[k][c] = m[k][c];
-      mx[k][0] = -old.start_point[k];
-      my[k][1] = -old.start_point[k];
-      ml[k][2] = -old.start_point[k];
-    }
-    double ox = det3(mx) / D, oy = det3(my) / D;
-    const double lambda = det3(ml) / D;
-    // A direction the old frame did not see, but not by much (the strip that a turning camera brings into view: up to
-    // two tiles wide at 3840 pixels): what lies just inside the old frame's edge is the better guess than the mean
-    // cost of a block -- objects continue across the edge.
-    if (lambda > 0.0) {
-      const double slack = 160.0;
-      if (ox < P.region_x && ox >= P.region_x - slack) ox = P.region_x + 0.5;
-      if (oy < P.region_y && oy >= P.region_y - slack) oy = P.region_y + 0.5;
-      if (ox >= P.region_x + P.region_w && ox < P.region_x + P.region_w + slack) ox = P.region_x + P.region_w - 0.5;
-      if (oy >= P.region_y + P.region_h && oy < P.region_y + P.region_h + slack) oy = P.region_y + P.region_h - 0.5;
-    }
-    // old pixel -> old block of the SAME launch geometry (single-chunk launches and tiles alike)
-    if (lambda > 0.0 && ox >= P.region_x && oy >= P.region_y && ox < P.region_x + P.region_w && oy < P.region_y + P.region_h) {
-      bool any = false;
-      unsigned mxc = 0u;
-      for (int dy = -radius; dy <= radius; dy++) {
-        for (int dx = -radius; dx <= radius; dx++) {
-          const double qx = ox + (double)step_px * dx, qy = oy + (double)step_px * dy;
-          if (qx < P.region_x || qy < P.region_y || qx >= P.region_x + P.region_w || qy >= P.region_y + P.region_h) continue;
-          // (an old block whose rays had a zero direction component says nothing about the turned camera's rays)
-          if (old_irr && block_has_zero_component_ray(old, (int)qx & ~7, (int)qy & ~7)) continue;
-          if (P.cost_map != nullptr) {  // every rank's costs of the old frame (0 = nobody reported that block)
-            const int mx_ = (int)qx >> 3, my_ = (int)qy >> 3;
-            if (mx_ < P.cost_map_w && my_ < P.cost_map_h) {
-              const unsigned c = P.cost_map[(size_t)my_ * P.cost_map_w + mx_];
-              if (c != 0u) {
-                mxc = max(mxc, c);
-                any = true;
-              }
-            }
-            continue;
-          }
-          const int tx = ((int)qx - P.region_x) / P.tile_w, ty = ((int)qy - P.region_y) / P.tile_h;
-          const int t = ty * P.tiles_x + tx;
-          const int jj = slot_of_tile(P, t);
-          if (jj < 0) continue;  // another rank's tile
-          const int lx = ((int)qx - P.region_x) % P.tile_w, ly = ((int)qy - P.region_y) % P.tile_h;
-          const unsigned nb = (unsigned)((size_t)jj * per_tile + (size_t)(ly / 8) * P.blocks_x + lx / 8);
-          mxc = max(mxc, cost_of(P.item_cost[nb], nb));
-          any = true;
-        }
-      }
-      if (any) best = mxc;
-    }
-  }
-  // A block with a primary ray that has a ZERO direction component (a camera on an axis: one pixel column or row of
-  // the frame) is among the frame's longest, whatever the old frame measured where it projects to -- the turned
-  // camera's rays there were ordinary ones.  Such rays leave the hit-set walk for the exact, lane-serial descent and
-  // pass the reference's box tests through NaN (mt_trace.h): about thirty times a block's mean cost.  Telling the
-  // scheduler so lets those blocks start first and in pieces (frames of a turning camera that pass through such a
-  // position: 9.0 -> ms at 1080p, 6.7 -> ms for the rank that owns the column at N = 8).
-  if (block_has_zero_component_ray(P.sensor, (int)px - 4, (int)py - 4)) best = max(best, unseen * 30u);
-  P.item_forecast[i] = best;
-  if (P.queues) note_cell(P, i, best, ((int)px - P.region_x) >> 3, ((int)py - P.region_y) >> 3);
-}
-
 // The block costs of the launch described by P, on the whole-block scale of the state machine, into a frame-wide
 // map (see RenderParams::cost_map): block (bx, by) of the IMAGE -> map[by * map_w + bx]; blocks of tiles that are not
 // this launch's keep what the map holds (the caller zeroes it).  engine = the engine that measured the costs (how
@@ -509,188 +346,14 @@ __device__ __forceinline__ int cost_bucket(unsigned c) {  // descending cost = a
   const int f = e >= 3 ? (int)((c >> (e - 3)) & 7u) : 0;      // eighth within it
   return kSchedBuckets - 1 - (e * 8 + f);
 }
-// P.queues (MT_TUNE_XCD_QUEUES, mt_queues.h): eight work orders instead of one, sorted by (region, cost bucket).
-__global__ __launch_bounds__(kSchedThreads) void schedule_kernel(RenderParams P, int n_waves, float quad_share, float quad_keep_share, int mode) {
-  __shared__ unsigned long long s_sum;
-  __shared__ unsigned s_count[kQueues * kSchedBuckets];
-  __shared__ unsigned s_start[kQueues * kSchedBuckets];
-  __shared__ RegionShared s_reg;
-  __shared__ unsigned s_qtotal[kQueues];
-  const int tid = threadIdx.x;
-  const bool queues = P.queues != nullptr && mode != 0;
-  const int n_regions = queues ? kQueues : 1;
-  if (tid == 0) s_sum = 0ull;
-  for (int b = tid; b < n_regions * kSchedBuckets; b += kSchedThreads) s_count[b] = 0u;
-  if (queues) build_region_table(P, mode, s_reg, tid, kSchedThreads);
-  __syncthreads();
-  // (forecast_kernel has scaled the costs measured in quad mode -- sums over four
-  // quarters, kQuadWork = 1.7 -- back to whole blocks)
-  const float kQuadShare = quad_share, kQuarterTime = 0.45f, kQuadKeep = quad_keep_share;
-  unsigned long long part = 0ull;
-  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) part += P.item_forecast[i] & 0x7fffffffu;
-  atomicAdd(&s_sum, part);
-  __syncthreads();
-  const float share = (float)s_sum / (float)(n_waves > 0 ? n_waves : 1);
-  const float quad_above = share * kQuadShare;
-  // a block that was rendered as quarters stays so until its forecast falls well below the
-  // threshold: the scaled-back sum of four quarters and the cost of the whole block are two
-  // different measurements, and a block near the threshold would change its form every frame
-  const float quad_keep = quad_above * kQuadKeep;
-  // what a block becomes: bucket | quad << 16 | region << 24
-  auto unit_of = [&](unsigned f, unsigned reg) -> unsigned {
-    const unsigned c = f & 0x7fffffffu;
-    const bool quad = (float)c > ((f >> 31) ? quad_keep : quad_above) && c > 0u;
-    const unsigned unit = quad ? (unsigned)((float)c * kQuarterTime) : c;
-    return (unsigned)cost_bucket(unit) | (quad ? 0x10000u : 0u) | (reg << 24);
-  };
-  // the two passes take their items four at a time: the loads of a round are in flight together
-  constexpr int kRound = 4;
-  // pass 1: bucket counts (a quad block contributes four units)
-  for (unsigned i0 = tid; i0 < P.n_items; i0 += kRound * kSchedThreads) {
-    unsigned f[kRound], reg[kRound];
-#pragma unroll
-    for (int k = 0; k < kRound; k++) {
-      const unsigned i = i0 + (unsigned)k * kSchedThreads;
-      f[k] = i < P.n_items ? P.item_forecast[i] : 0u;
-      reg[k] = (queues && i < P.n_items) ? (unsigned)P.item_cell[i] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < kRound; k++) {
-      const unsigned i = i0 + (unsigned)k * kSchedThreads;
-      if (i < P.n_items) {
-        const unsigned u = unit_of(f[k], queues ? (unsigned)s_reg.cellreg[reg[k]] : 0u);
-        atomicAdd(&s_count[(u >> 24) * kSchedBuckets + (u & 0xffffu)], (u & 0x10000u) ? 4u : 1u);
-      }
-    }
-  }
-  __syncthreads();
-  if (tid < n_regions) {  // (per region one thread: the eight run side by side)
-    unsigned acc = 0u;
-    for (int b = 0; b < kSchedBuckets; b++) {
-      s_start[tid * kSchedBuckets + b] = acc;
-      acc += s_count[tid * kSchedBuckets + b];
-    }
-    s_qtotal[tid] = acc;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    unsigned acc = 0u;
-    for (int q = 0; q < n_regions; q++) {
-      if (queues) P.queues[kQueueStart + q] = acc;
-      const unsigned n = s_qtotal[q];
-      s_qtotal[q] = acc;
-      acc += n;
-    }
-    if (queues) P.queues[kQueueStart + kQueues] = acc;
-    *P.n_work = acc;
-  }
-  __syncthreads();
-  // pass 2: scatter, and reset the costs for the coming frame (bit 31 notes
-  // that the block will be measured as quarters)
-  for (unsigned i0 = tid; i0 < P.n_items; i0 += kRound * kSchedThreads) {
-    unsigned f[kRound], reg[kRound];
-#pragma unroll
-    for (int k = 0; k < kRound; k++) {
-      const unsigned i = i0 + (unsigned)k * kSchedThreads;
-      f[k] = i < P.n_items ? P.item_forecast[i] : 0u;
-      reg[k] = (queues && i < P.n_items) ? (unsigned)P.item_cell[i] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < kRound; k++) {
-      const unsigned i = i0 + (unsigned)k * kSchedThreads;
-      if (i < P.n_items) {
-        const unsigned u = unit_of(f[k], queues ? (unsigned)s_reg.cellreg[reg[k]] : 0u);
-        const bool quad = (u & 0x10000u) != 0u;
-        const unsigned r = u >> 24;
-        const unsigned at = s_qtotal[r] + atomicAdd(&s_start[r * kSchedBuckets + (u & 0xffffu)], quad ? 4u : 1u);
-        if (quad) {
-          for (int q = 0; q < 4; q++) {
-            P.order_item[at + q] = i;
-            P.order_sub[at + q] = (signed char)q;
-          }
-        } else {
-          P.order_item[at] = i;
-          P.order_sub[at] = (signed char)-1;
-        }
-        P.item_cost[i] = quad ? 0x80000000u : 0u;
-      }
-    }
-  }
-}
-
 // Work order of a HYBRID launch (engine 3, hybrid_kernel below): blocks whose forecast lies above pool_share of an
 // even share of the frame's work go to the ray pool in pieces (4x4 quarters; 2x2 cells when a quarter would still be
-// cell_factor times above that; order_sub = kHybridPoolSub + piece); the others go to the state machine as in
-// schedule_kernel (whole, or above quad_share as quarters with four lanes per pixel).  The pool's units come first,
-// longest expected unit first within either kind.  form[b] records how block b is rendered (forecast_kernel needs
-// it to read the costs).
-__global__ __launch_bounds__(kSchedThreads) void hybrid_schedule_kernel(RenderParams P, int n_waves, float quad_share,
-                                                                        float pool_share, float piece_time1,
-                                                                        float piece_time2, float cell_factor,
-                                                                        unsigned char *form, float starter_share,
-                                                                        unsigned max_starters) {
-  __shared__ unsigned long long s_sum;
-  __shared__ unsigned s_starters;
-  __shared__ unsigned s_count[2][kSchedBuckets];
-  __shared__ unsigned s_start[2][kSchedBuckets];
-  const int tid = threadIdx.x;
-  if (tid == 0) { s_sum = 0ull; s_starters = 0u; }
-  for (int b = tid; b < 2 * kSchedBuckets; b += kSchedThreads) (&s_count[0][0])[b] = 0u;
-  __syncthreads();
-  const float kQuarterTime = 0.45f;
-  unsigned long long part = 0ull;
-  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) part += P.item_forecast[i] & 0x7fffffffu;
-  atomicAdd(&s_sum, part);
-  __syncthreads();
-  const float share = (float)s_sum / (float)(n_waves > 0 ? n_waves : 1);
-  const float quad_above = share * quad_share, pool_above = share * pool_share;
-  auto decide = [&](unsigned i, int &f, unsigned &unit, unsigned &n) {
-    const unsigned c = P.item_forecast[i] & 0x7fffffffu;
-    if ((float)c > pool_above && c > 0u) {
-      f = ((float)c * piece_time1 > cell_factor * pool_above) ? 3 : 2;
-      unit = (unsigned)((float)c * (f == 3 ? piece_time2 : piece_time1));
-      n = f == 3 ? 16u : 4u;
-    } else if ((float)c > quad_above && c > 0u) {
-      f = 1; unit = (unsigned)((float)c * kQuarterTime); n = 4u;
-    } else {
-      f = 0; unit = c; n = 1u;
-    }
-  };
-  unsigned my_starters = 0u;
-  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
-    int f; unsigned unit, n;
-    decide(i, f, unit, n);
-    atomicAdd(&s_count[f >= 2 ? 0 : 1][cost_bucket(unit)], n);
-    if (f < 2 && (float)unit > share * starter_share) my_starters += n;
-  }
-  if (my_starters) atomicAdd(&s_starters, my_starters);
-  __syncthreads();
-  if (tid == 0) {
-    unsigned acc = 0u;
-    for (int g = 0; g < 2; g++) {  // the pool's units come first
-      for (int b = 0; b < kSchedBuckets; b++) {
-        s_start[g][b] = acc;
-        acc += s_count[g][b];
-      }
-      if (g == 0) P.n_work[1] = acc;  // the pool's part: units [0, n_work[1])
-    }
-    P.n_work[0] = acc;
-    // (no pool part: nobody needs to skip it)
-    P.n_work[2] = P.n_work[1] == 0u ? 0u : (s_starters < max_starters ? s_starters : max_starters);
-  }
-  __syncthreads();
-  for (unsigned i = tid; i < P.n_items; i += kSchedThreads) {
-    int f; unsigned unit, n;
-    decide(i, f, unit, n);
-    const unsigned at = atomicAdd(&s_start[f >= 2 ? 0 : 1][cost_bucket(unit)], n);
-    for (unsigned q = 0; q < n; q++) {
-      P.order_item[at + q] = i;
-      P.order_sub[at + q] = (signed char)(f == 0 ? -1 : (f == 1 ? (int)q : kHybridPoolSub + (f == 3 ? 4 + (int)q : (int)q)));
-    }
-    P.item_cost[i] = f == 1 ? 0x80000000u : 0u;
-    form[i] = (unsigned char)f;
-  }
-}
+// cell_factor times above that; order_sub = kHybridPoolSub + piece); the others go to the state machine (whole, or
+// above quad_share as quarters with four lanes per pixel).  The pool's units come first, longest expected unit first
+// within either kind.  form[b] records how block b is rendered (the next forecast needs it to read the costs).
+}  // namespace mt
+#include "mt_order.h"
+namespace mt {
 
 // ---------------------------------------------------------------------------
 // The frame kernel: TraceRayWorker for every pixel of the launch's tiles and

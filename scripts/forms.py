@@ -1,5 +1,5 @@
 """A block near the cutting threshold changes its form every few frames of a repeated frame; with the block's own ratio of
-its two measured costs (forecast_kernel, item_whole / item_qsum) it does not.  MT_DEBUG_NO_FORMS=1 switches that off.
+its two measured costs (forecast_item in mt_order.h, item_whole / item_qsum) it does not.  MT_DEBUG_NO_FORMS=1 switches that off.
 64 timed frames per setting after 32, work counters off; then the moving camera (yaw += 2 degrees per frame)."""
 import os, sys, ctypes, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -991,7 +991,7 @@ def test_binary_recursion_trees_fill_the_ray_pool(pool_cap):
 def test_moving_camera_uses_reprojected_costs(scenes):
     """The animation regime (main_local.cc:51-76: yaw += 2 degrees per frame):
     from the second frame on the work order comes from the previous frame's
-    costs, re-projected through the camera change (forecast_kernel) -- also with
+    costs, re-projected through the camera change (order_kernel's forecast) -- also with
     a translation and a roll.  The order must not change a pixel: every frame
     equals the oracle's."""
     m = M.MythTracer(scenes["room"])
