@@ -290,15 +290,19 @@ struct OrderUnit {
 };
 static_assert(kOrdKeysMax <= 2048, "an OrderUnit packs its key into 11 bits");
 
-// thread (wg, tid) takes the blocks gt, gt + T, ..: consecutive blocks go to DIFFERENT workgroups, so that a launch with
-// fewer blocks than threads still spreads its blocks (and their instructions) over all the workgroups' CUs -- the SAME
-// blocks in all three kernels
+// Workgroup wg takes the blocks [wg x chunk, (wg + 1) x chunk), chunk = ceil(n / G) -- the SAME blocks in all three kernels,
+// every workgroup busy however few blocks the launch has, and its blocks NEIGHBOURS in the picture: the units of one cost
+// bucket then come in runs of neighbouring blocks (dealt out block i -> workgroup i mod G, the first frames of the ray
+// pool -- few distinct forecasts, so a bucket is most of the picture -- took 8.5 instead of 7.8 ms: consecutive units
+// were 64 blocks apart).
 #define MT_ORD_THREAD()                                                                                              \
   const int tid = threadIdx.x, wg = blockIdx.x;                                                                      \
-  const unsigned G = gridDim.x, T = G * kOrdThreads, gt = (unsigned)tid * G + (unsigned)wg;                          \
+  const unsigned G = gridDim.x, chunk = (P.n_items + G - 1u) / G;                                                    \
+  const unsigned i_begin = (unsigned)wg * chunk, i_end = i_begin + chunk < P.n_items ? i_begin + chunk : P.n_items;  \
   unsigned *ctl = P.order_ctl;                                                                                       \
   unsigned *area = ctl + kOrdArea + (O.epoch & 1u) * kOrdAreaWords;                                                  \
-  (void)wg; (void)T; (void)gt; (void)area
+  (void)wg; (void)area; (void)i_begin; (void)i_end
+#define MT_ORD_FOR_ITEMS(i) for (unsigned i = i_begin + (unsigned)tid; i < i_end; i += (unsigned)kOrdThreads)
 
 // ---- 1: forecasts, their sum, the region grid; the next launch's area and this launch's counters zeroed
 template <int KIND>
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(kOrdThreads) void order_forecast_kernel(RenderParam
   MT_ORD_THREAD();
   unsigned *area_next = ctl + kOrdArea + ((O.epoch + 1u) & 1u) * kOrdAreaWords;
   const bool queues = KIND == 0 && P.queues != nullptr && O.queue_mode != 0;
-  for (unsigned c = gt; c < (unsigned)kOrdAreaWords; c += T) area_next[c] = 0u;
+  for (unsigned c = (unsigned)wg * kOrdThreads + (unsigned)tid; c < (unsigned)kOrdAreaWords; c += G * kOrdThreads) area_next[c] = 0u;
   if (wg == 0) {
     if (tid < 16) P.work_counter[tid] = 0u;  // (the frame kernel's counters, the class counts, n_work)
     if (queues) {
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(kOrdThreads) void order_forecast_kernel(RenderParam
   __syncthreads();
   unsigned long long part = 0ull;
   const int n_cols = (P.region_w + 7) >> 3, n_rows = (P.region_h + 7) >> 3;
-  for (unsigned i = gt; i < P.n_items; i += T) {
+  MT_ORD_FOR_ITEMS(i) {
     int gx, gy;
     const unsigned f = forecast_item(P, A, i, gx, gy);
     part += f & 0x7fffffffu;
@@ -355,7 +359,7 @@ __global__ __launch_bounds__(kOrdThreads) void order_count_kernel(RenderParams P
   else __syncthreads();
   const float kQuarterTime = 0.45f;
   unsigned my_starters = 0u;
-  for (unsigned i = gt; i < P.n_items; i += T) {
+  MT_ORD_FOR_ITEMS(i) {
     OrderUnit u;
     u.starter = false;
     u.form = 0;
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(kOrdThreads) void order_scatter_kernel(RenderParams
     }
   }
   __syncthreads();
-  for (unsigned i = gt; i < P.n_items; i += T) {
+  MT_ORD_FOR_ITEMS(i) {
     OrderUnit u;
     u.unpack(P.item_unit[i]);
     const unsigned at = atomicAdd(&s_pos[u.key], u.n);
@@ -476,5 +480,6 @@ __global__ __launch_bounds__(kOrdThreads) void order_scatter_kernel(RenderParams
   }
 }
 #undef MT_ORD_THREAD
+#undef MT_ORD_FOR_ITEMS
 
 }  // namespace mt
