@@ -72,7 +72,7 @@ N_SIMD = 1024          # 256 CUs x 4 SIMDs
 RAY_KEYS = ("rays_primary", "rays_secondary", "rays_shadow")
 KERNEL_SOURCES = ("mythtracer_amd/csrc/mt_capi.hip", "mythtracer_amd/csrc/mt_render.hip", "mythtracer_amd/csrc/mt_pool.h",
                   "mythtracer_amd/csrc/mt_trace.h", "mythtracer_amd/csrc/mt_shade.h", "mythtracer_amd/csrc/mt_device.h",
-                  "mythtracer_amd/csrc/mt_queues.h", "include/mythtracer_hip.h")
+                  "mythtracer_amd/csrc/mt_queues.h", "mythtracer_amd/csrc/mt_order.h", "include/mythtracer_hip.h")
 
 
 def kernel_source_sha256() -> str:
