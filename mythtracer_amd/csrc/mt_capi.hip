@@ -530,7 +530,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   // (launches with a work order: order_kernel zeroes the counters on its way)
   if (!history && !pool_engine) HIP_TRY(hipMemsetAsync(s->d_work, 0, 16 * sizeof(unsigned), stream));
   P.order_ctl = s->d_order_ctl;
-  P.order_woff = s->d_order_woff;
+  P.order_whist = s->d_order_woff;
   P.item_unit = s->d_item_unit;
   // one work order per XCD: state-machine launches with a cost history only (the other engines keep the one order)
   // (measured and left out: first frames through the ray pool -- room 8.4 -> 8.9 ms, loft 19.7 -> 20.9: the probe's guess

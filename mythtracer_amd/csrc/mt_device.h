@@ -239,7 +239,7 @@ struct RenderParams {
   unsigned short *item_cell;  // [n_items] the block's cell of the region grid (mt_order.h)
   unsigned int *order_ctl;    // the order kernels' forecast sums, histograms, region grids (kOrdWords; never reset by the host)
   unsigned int *item_unit;    // [n_items] what the block becomes in this launch, packed (order_count_kernel -> order_scatter_kernel)
-  unsigned int *order_woff;   // [workgroups][kOrdKeysMax] a workgroup's offset within each key it has units under
+  unsigned int *order_whist;  // [workgroups][kOrdKeysMax] every workgroup's histogram over the sort keys
 };
 constexpr int kQueues = 8, kQueueStride = 32, kQueueStart = kQueues * kQueueStride;  // (a counter per 128-byte line)
 constexpr int kGridW = 64, kGridH = 32;            // the region grid: forecast cost per cell (order_kernel's area)

@@ -10,11 +10,12 @@
 //      grid; the counters of the coming frame kernel and the OTHER launch's area are zeroed on the way (no memsets);
 //   2a order_count_kernel: what every block becomes (whole / quarters / pool pieces: the engines' rules, unchanged;
 //      kept as one packed word per block) and the workgroup's histogram over (region or engine part, cost bucket),
-//      ADDED to the launch's histogram in global memory -- the value an add returns is the workgroup's offset within
-//      that key;
-//   2b order_scatter_kernel: every workgroup reads the launch's histogram, takes the prefix sums (units longest first
-//      within a region / part) and scatters its blocks' units.
-// Within a key the order of the units is as arbitrary as it was (atomic order); nothing computed for a pixel depends on it.
+//      written to global memory;
+//   2b order_scatter_kernel: every workgroup sums the histograms -- all of them: the keys' totals, whose prefix sums put
+//      the units longest first within a region / part; the workgroups before it: its offset within each key -- and
+//      scatters its blocks' units.
+// Within a key the units come workgroup by workgroup, i.e. in the order of the picture's blocks (inside a workgroup's
+// range in LDS-atomic order); nothing computed for a pixel depends on any of it.
 // 53 us for the three steps as ONE kernel with two grid barriers (sc1 hand-offs) -- but a grid barrier needs all its
 // workgroups resident, and two such kernels of different scenes or processes that each hold half of the CUs wait for each
 // other until their spins time out; the kernel boundaries cost a few microseconds more and assume nothing.
@@ -29,8 +30,8 @@ constexpr int kOrdThreads = 1024;
 constexpr int kOrdKeysMax = kQueues * 256;
 // RenderParams::order_ctl, unsigned words (zero at allocation, never reset by the host):
 //   two areas used by alternate launches (a launch zeroes the other one), each: [0..1] u64 sum of the forecasts,
-//   [2] starters, [32 .. 32 + kOrdKeysMax) the histogram, then the region grid
-constexpr int kOrdArea = 32, kOrdAreaHist = 32, kOrdAreaGrid = 32 + kOrdKeysMax, kOrdAreaWords = kOrdAreaGrid + kGridW * kGridH;
+//   [2] starters, [32 ..) the region grid
+constexpr int kOrdArea = 32, kOrdAreaGrid = 32, kOrdAreaWords = kOrdAreaGrid + kGridW * kGridH;
 constexpr int kOrdWords = kOrdArea + 2 * kOrdAreaWords;
 
 struct ForecastArgs {
@@ -340,15 +341,13 @@ __global__ __launch_bounds__(kOrdThreads) void order_forecast_kernel(RenderParam
   if (tid == 0 && s_sum != 0ull) atomicAdd((unsigned long long *)area, s_sum);
 }
 
-// ---- 2a: what every block becomes; the workgroup's histogram, added to the launch's (the value an add returns is the
-// workgroup's offset within that key)
+// ---- 2a: what every block becomes; the workgroup's histogram
 template <int KIND>
 __global__ __launch_bounds__(kOrdThreads) void order_count_kernel(RenderParams P, OrderArgs O) {
   __shared__ unsigned s_starters;
   __shared__ unsigned s_hist[kOrdKeysMax];
   __shared__ RegionShared s_reg;
   MT_ORD_THREAD();
-  unsigned *ghist = area + kOrdAreaHist;
   const bool queues = KIND == 0 && P.queues != nullptr && O.queue_mode != 0;
   const int n_keys = KIND == 0 ? (queues ? kQueues * 256 : 256) : (KIND == 1 ? 2 * 256 : 256);
   if (tid == 0) s_starters = 0u;
@@ -409,11 +408,8 @@ __global__ __launch_bounds__(kOrdThreads) void order_count_kernel(RenderParams P
   }
   if (my_starters) atomicAdd(&s_starters, my_starters);
   __syncthreads();
-  unsigned *woff = P.order_woff + (size_t)wg * kOrdKeysMax;
-  for (int k = tid; k < n_keys; k += kOrdThreads) {
-    const unsigned c = s_hist[k];
-    if (c != 0u) woff[k] = atomicAdd(ghist + k, c);  // (what the add returns: the units other workgroups put under this key before)
-  }
+  unsigned *whist = P.order_whist + (size_t)wg * kOrdKeysMax;
+  for (int k = tid; k < n_keys; k += kOrdThreads) whist[k] = s_hist[k];
   if (tid == 0 && s_starters != 0u) atomicAdd(area + 2, s_starters);
 }
 
@@ -423,15 +419,17 @@ __global__ __launch_bounds__(kOrdThreads) void order_scatter_kernel(RenderParams
   __shared__ unsigned s_pos[kOrdKeysMax];  // next position of this workgroup per key
   __shared__ unsigned s_wave[kOrdThreads / 64];
   MT_ORD_THREAD();
-  const unsigned *ghist = area + kOrdAreaHist;
-  const unsigned *woff = P.order_woff + (size_t)wg * kOrdKeysMax;
   const bool queues = KIND == 0 && P.queues != nullptr && O.queue_mode != 0;
   const int n_keys = KIND == 0 ? (queues ? kQueues * 256 : 256) : (KIND == 1 ? 2 * 256 : 256);
   // thread t: keys 2t, 2t + 1 (n_keys <= 2 x kOrdThreads)
-  unsigned tot[2] = {0u, 0u};
-  for (int e = 0; e < 2; e++) {
-    const int k = 2 * tid + e;
-    if (k < n_keys) tot[e] = ghist[k];
+  unsigned tot[2] = {0u, 0u}, before[2] = {0u, 0u};
+  if (2 * tid < n_keys) {  // (n_keys is even; the two keys of a thread are one 8-byte load per workgroup)
+    const uint2 *col = (const uint2 *)(P.order_whist + 2 * tid);
+    for (unsigned w = 0; w < G; w++) {
+      const uint2 v = col[(size_t)w * (kOrdKeysMax / 2)];
+      tot[0] += v.x; tot[1] += v.y;
+      if (w < (unsigned)wg) { before[0] += v.x; before[1] += v.y; }
+    }
   }
   // exclusive scan of tot[0] + tot[1] over the threads: inside each wave by shuffles, then over the 16 waves
   const unsigned mine = tot[0] + tot[1];
@@ -450,9 +448,8 @@ __global__ __launch_bounds__(kOrdThreads) void order_scatter_kernel(RenderParams
     all += v;
   }
   const unsigned excl = wave_base + incl - mine;
-  // (woff holds something only for the keys this workgroup has units under -- the others' positions are never used)
-  if (2 * tid < n_keys) s_pos[2 * tid] = excl + (tot[0] != 0u ? woff[2 * tid] : 0u);
-  if (2 * tid + 1 < n_keys) s_pos[2 * tid + 1] = excl + tot[0] + (tot[1] != 0u ? woff[2 * tid + 1] : 0u);
+  if (2 * tid < n_keys) s_pos[2 * tid] = excl + before[0];
+  if (2 * tid + 1 < n_keys) s_pos[2 * tid + 1] = excl + tot[0] + before[1];
   if (wg == 0) {
     // bounds of the parts: queue q = keys [256 q, 256 q + 256) (mt_queues.h); hybrid: the pool's part = keys [0, 256)
     if (queues && (2 * tid) % 256 == 0 && 2 * tid < n_keys) P.queues[kQueueStart + (2 * tid) / 256] = excl;
