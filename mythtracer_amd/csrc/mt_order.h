@@ -425,10 +425,15 @@ __global__ __launch_bounds__(kOrdThreads) void order_scatter_kernel(RenderParams
   unsigned tot[2] = {0u, 0u}, before[2] = {0u, 0u};
   if (2 * tid < n_keys) {  // (n_keys is even; the two keys of a thread are one 8-byte load per workgroup)
     const uint2 *col = (const uint2 *)(P.order_whist + 2 * tid);
-    for (unsigned w = 0; w < G; w++) {
-      const uint2 v = col[(size_t)w * (kOrdKeysMax / 2)];
-      tot[0] += v.x; tot[1] += v.y;
-      if (w < (unsigned)wg) { before[0] += v.x; before[1] += v.y; }
+    for (unsigned w0 = 0; w0 < G; w0 += 8u) {  // (eight loads in flight)
+      uint2 v[8];
+#pragma unroll
+      for (unsigned k = 0; k < 8u; k++) v[k] = w0 + k < G ? col[(size_t)(w0 + k) * (kOrdKeysMax / 2)] : make_uint2(0u, 0u);
+#pragma unroll
+      for (unsigned k = 0; k < 8u; k++) {
+        tot[0] += v[k].x; tot[1] += v[k].y;
+        if (w0 + k < (unsigned)wg) { before[0] += v[k].x; before[1] += v[k].y; }
+      }
     }
   }
   // exclusive scan of tot[0] + tot[1] over the threads: inside each wave by shuffles, then over the 16 waves
