@@ -187,6 +187,41 @@ def test_cost_history_scheduling_changes_nothing(scenes):
         abi.scene_destroy(h)
 
 
+@pytest.mark.parametrize("groups", [1, 3, 64, 256])
+def test_work_order_on_any_number_of_workgroups(groups, scenes, engine):
+    """The work order of a launch with measured costs (mt_order.h: forecast, counting sort over (region or engine part,
+    cost bucket), scatter -- three kernels on MT_TUNE_ORDER_GROUPS workgroups, every thread for its own blocks) with one,
+    an odd number, the default and the largest number of workgroups, with one work order per XCD and with one for the
+    chip: every unit of every block exactly once -- same pixels and ray counts as the first, unordered launch -- for a
+    camera at rest, a moved one (re-projected forecast) and a chunk (another geometry).  (Launches of many tiles:
+    test_cost_balanced_tile_ownership.)"""
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["room"])
+    h = abi.scene_create(m.flatten())
+    try:
+        abi.set_lights(h, scenegen.ROOM_LIGHTS)
+        abi.set_tuning(h, "ORDER_GROUPS", float(groups))
+        W, H = 400, 224
+        for queues in (2.0, 0.0, 1.0):
+            abi.set_tuning(h, "XCD_QUEUES", queues)
+            cams = [scenegen.ROOM_CAMERA, scenegen.ROOM_CAMERA, scenegen.ROOM_CAMERA]
+            moved = list(scenegen.ROOM_CAMERA); moved[4] += 3.0
+            first = {}
+            for cam in cams + [moved, moved, scenegen.ROOM_CAMERA]:
+                r = abi.render_chunk(h, binding.sensor(cam, W, H), W, H)
+                key = tuple(cam)
+                if key not in first:
+                    first[key] = r  # (no cost history for this camera's first frame after set_tuning: the unordered launch)
+                assert np.array_equal(r["rgb"], first[key]["rgb"]), (groups, queues)
+                assert {k: r["stats"][k] for k in ALL_KEYS if k not in PRUNED} == {k: first[key]["stats"][k] for k in ALL_KEYS if k not in PRUNED}
+            full = first[tuple(scenegen.ROOM_CAMERA)]["rgb"]
+            for _ in range(3):
+                part = abi.render_chunk(h, binding.sensor(scenegen.ROOM_CAMERA, W, H), W, H, chunk=(40, 16, 301, 150))
+                assert np.array_equal(part["rgb"], full[16:166, 40:341]), (groups, queues)
+    finally:
+        abi.scene_destroy(h)
+
+
 def test_bad_chunks_are_rejected(scenes):
     m = M.MythTracer(scenes["cornell"])
     for chunk in [(-1, 0, 4, 4), (0, 0, 0, 4), (60, 60, 8, 8), (0, 0, 65, 1)]:
@@ -1436,7 +1471,8 @@ def test_cost_balanced_tile_ownership(scenes, engine):
             abi.render_tile_list_device(hs[0], sens, W, H, T, T, vp(lists[0]), total + 1, 0, 5, vp(slots))
         # the tuning knobs refuse values the kernels would divide by or overflow on (mt_scene_set_tuning)
         for knob, bad in (("QUAD_SHARE", 0.0), ("HYBRID_WORK1", 0.0), ("POOL_PIECE_WORK1", -1.0), ("POOL_SCRATCH_MB", float("inf")),
-                          ("BLEND", 1.5), ("HYBRID_POOL_SHARE", float("nan"))):
+                          ("BLEND", 1.5), ("HYBRID_POOL_SHARE", float("nan")), ("ORDER_GROUPS", 0.0), ("ORDER_GROUPS", 257.0),
+                          ("XCD_QUEUES", 3.0)):
             with pytest.raises(RuntimeError):
                 abi.set_tuning(hs[0], knob, bad)
     finally:
