@@ -2,7 +2,7 @@
 duration, and its start stamp and wave.)  Prints the launch's makespan in s_memtime ticks, the units that end last, the
 waves' idle time at the end, and how much of the launch had fewer than all waves busy.
 
-  WHAT=1080p|rank  RANK=5 WORLD=8  ENGINE=3  python scripts/unit_timeline.py"""
+  WHAT=1080p|rank  RANK=5 WORLD=8  ENGINE=3  YAW=0  python scripts/unit_timeline.py"""
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,7 +21,8 @@ for k, v in [kv.split("=") for kv in os.environ.get("TUNE", "").split(",") if kv
 what = os.environ.get("WHAT", "rank")
 if what == "1080p":
     W, H = 1920, 1080
-    sens = binding.sensor(sg.ROOM_CAMERA, W, H)
+    cam1080 = list(sg.ROOM_CAMERA); cam1080[4] += float(os.environ.get("YAW", "0"))  # (YAW=2: no pixel column of zero-component rays)
+    sens = binding.sensor(cam1080, W, H)
     buf = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
     n_items = (W // 8) * (H // 8)
     for i in range(10):
