@@ -362,6 +362,9 @@ enum {
                                  from the fullest other queue); 2 = a 4 x 2 grid of regions instead of stripes */
   MT_TUNE_ORDER_GROUPS,       /* workgroups of the kernel that makes a launch's work order (forecast per block, units
                                  longest first): 64; 1 .. 256, at most one per CU */
+  MT_TUNE_SM_CELL_SHARE,      /* state machine: a block goes out as sixteen 2x2 cells (four lanes per pixel) when a QUARTER
+                                 of it is expected above this multiple of the quarters' cutting threshold */
+  MT_TUNE_SM_CELL_TIME, MT_TUNE_SM_CELL_WORK, /* a cell's expected time / the cells' summed cost, over the block as one unit */
   MT_TUNE_COUNT
 };
 int mt_scene_set_tuning(mt_scene *scene, int knob, double value);

@@ -85,6 +85,9 @@ struct Tuning {
     v[MT_TUNE_DEEP_LAYOUT] = 1.0;
     v[MT_TUNE_MULTI_FORCE_PEER_COPY] = 0.0;
     v[MT_TUNE_MULTI_BALANCE] = 1.0;
+    v[MT_TUNE_SM_CELL_SHARE] = 0.8;  // (x the quarters' cutting threshold; blocks with zero-component rays only: mt_order.h)
+    v[MT_TUNE_SM_CELL_TIME] = 0.2;
+    v[MT_TUNE_SM_CELL_WORK] = 3.0;
     v[MT_TUNE_ORDER_GROUPS] = (double)kOrdGroups;  // workgroups of order_kernel (mt_order.h)
     v[MT_TUNE_XCD_QUEUES] = 2.0;  // one work order per XCD over a 4 x 2 grid of regions of equal forecast cost (L2 hit rate 0.82 -> 0.92 room, 0.66 -> 0.82 loft)
   }
@@ -109,6 +112,9 @@ struct mt_scene {
   unsigned int *d_item_unit = nullptr;
   size_t item_unit_bytes = 0;
   unsigned order_epoch = 0;             // order_kernel launches of this scene so far
+  mt_sensor irr_sensor{};               // the sensor `irr_sensor_has` was found for (image irr_w x irr_h)
+  int irr_w = 0, irr_h = 0, irr_sensor_has = 0;
+  bool irr_sensor_valid = false;
   DevScene dev_uploaded;                // what d_dev holds
   bool dev_uploaded_valid = false;
   unsigned short *d_item_cell = nullptr;
@@ -586,9 +592,16 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     return 0;
   };
   int old_irr = 0, new_irr = 0;
+  if (history) {  // (kept per sensor: a camera at rest is looked at once)
+    if (!s->irr_sensor_valid || memcmp(&s->irr_sensor, sensor, sizeof(mt_sensor)) != 0 || s->irr_w != image_w || s->irr_h != image_h) {
+      s->irr_sensor = *sensor; s->irr_w = image_w; s->irr_h = image_h;
+      s->irr_sensor_has = has_zero_component_pixel(*sensor);
+      s->irr_sensor_valid = true;
+    }
+    new_irr = s->irr_sensor_has;
+  }
   if (history && memcmp(&s->cost_sensor, sensor, sizeof(mt_sensor)) != 0) {
     old_irr = has_zero_component_pixel(s->cost_sensor);
-    new_irr = has_zero_component_pixel(*sensor);
     reproject = 1;
     radius = memcmp(s->cost_sensor.origin, sensor->origin, sizeof sensor->origin) != 0 ? 2 : 1;
     if (s->tune.v[MT_TUNE_FORECAST_RADIUS] >= 0.0) radius = (int)s->tune.v[MT_TUNE_FORECAST_RADIUS];
@@ -621,7 +634,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
     ForecastArgs fa{s->cost_sensor, reproject, radius, (history && (s->last_engine == 1 || s->last_engine == 3)) ? 0 : 1,
                     (history && s->last_engine == 1) ? 1.7f : sp.piece_work[1], sp.piece_work[2], 16000u, blend,
                     (history && s->last_engine == 3) ? s->d_item_form : nullptr, (float)tv[MT_TUNE_HYBRID_WORK1],
-                    (float)tv[MT_TUNE_HYBRID_WORK2], (float)tv[MT_TUNE_FORECAST_STEP], old_irr, new_irr};
+                    (float)tv[MT_TUNE_HYBRID_WORK2], (float)tv[MT_TUNE_FORECAST_STEP], (float)tv[MT_TUNE_SM_CELL_WORK], old_irr, new_irr};
     OrderArgs oa{};
     oa.n_waves = s->grid_blocks * s->waves_per_block;
     oa.epoch = s->order_epoch++;
@@ -649,7 +662,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       const double *tv = s->tune.v;
       ForecastArgs fa{s->cost_sensor, reproject, radius, s->last_engine == 2 ? 1 : 0, s->last_engine == 2 ? 1.1f : quad_work, 3.0f,
                       16000u, blend, s->last_engine == 3 ? s->d_item_form : nullptr, (float)tv[MT_TUNE_HYBRID_WORK1],
-                      (float)tv[MT_TUNE_HYBRID_WORK2], (float)tv[MT_TUNE_FORECAST_STEP], old_irr, new_irr};
+                      (float)tv[MT_TUNE_HYBRID_WORK2], (float)tv[MT_TUNE_FORECAST_STEP], (float)tv[MT_TUNE_SM_CELL_WORK], old_irr, new_irr};
       OrderArgs oa{};
       oa.n_waves = s->grid_blocks * s->waves_per_block;
       oa.epoch = s->order_epoch++;
@@ -670,6 +683,9 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
       } else {
         oa.quad_share = quad_share;
         oa.quad_keep = quad_keep;
+        oa.cell_share = (float)tv[MT_TUNE_SM_CELL_SHARE];
+        oa.new_irr = new_irr;
+        oa.cell_time = (float)tv[MT_TUNE_SM_CELL_TIME];
         oa.queue_mode = (int)tv[MT_TUNE_XCD_QUEUES];
         hipLaunchKernelGGL(order_forecast_kernel<0>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, fa, oa);
         hipLaunchKernelGGL(order_count_kernel<0>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, oa);
@@ -1375,6 +1391,7 @@ int mt_scene_set_tuning(mt_scene *s, int knob, double value) {
     case MT_TUNE_POOL_PIECE_TIME1: case MT_TUNE_POOL_PIECE_TIME2: case MT_TUNE_POOL_PIECE_WORK1: case MT_TUNE_POOL_PIECE_WORK2:
     case MT_TUNE_POOL_CELL_FACTOR: case MT_TUNE_QUAD_SHARE: case MT_TUNE_QUAD_SHARE_MOVING: case MT_TUNE_QUAD_KEEP:
     case MT_TUNE_QUAD_WORK: case MT_TUNE_QUAD_WORK_MOVING: case MT_TUNE_HYBRID_POOL_SHARE: case MT_TUNE_HYBRID_QUAD_SHARE:
+    case MT_TUNE_SM_CELL_SHARE: case MT_TUNE_SM_CELL_TIME: case MT_TUNE_SM_CELL_WORK:
     case MT_TUNE_HYBRID_WORK1: case MT_TUNE_HYBRID_WORK2: case MT_TUNE_FORECAST_STEP: case MT_TUNE_HYBRID_STARTER_SHARE:
       if (!(value >= 1e-6 && value <= 1e6)) return fail(MT_ERR_ARG, "tuning knob %d must lie in [1e-6, 1e6]", knob);
       break;
@@ -1430,7 +1447,7 @@ int mt_scene_export_costs_device(mt_scene *s, void *d_map, int map_w, int map_h,
   const bool hy = s->last_engine == 3;
   hipLaunchKernelGGL(export_costs_kernel, dim3((P.n_items + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, s->last_engine,
                      (float)(hy ? tv[MT_TUNE_HYBRID_WORK1] : tv[MT_TUNE_POOL_PIECE_WORK1]),
-                     (float)(hy ? tv[MT_TUNE_HYBRID_WORK2] : tv[MT_TUNE_POOL_PIECE_WORK2]),
+                     (float)(hy ? tv[MT_TUNE_HYBRID_WORK2] : tv[MT_TUNE_POOL_PIECE_WORK2]), (float)tv[MT_TUNE_SM_CELL_WORK],
                      (const unsigned char *)s->d_item_form, (unsigned *)d_map, map_w, map_h);
   HIP_TRY(hipGetLastError());
   return MT_OK;

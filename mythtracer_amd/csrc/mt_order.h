@@ -42,6 +42,7 @@ struct ForecastArgs {
   float blend;
   const unsigned char *form;
   float wq, wc, step_px;
+  float w_cells;  // state machine: summed cost of a block's sixteen cells over its cost as one unit
   int old_irr;   // the old camera's frame had pixels whose primary rays have a zero direction component
   int new_irr;   // ... and so has this one's (found on the host, exactly: most frames have none, and looking for them is half of a forecast's instructions)
 };
@@ -50,6 +51,8 @@ struct OrderArgs {
   unsigned epoch;          // this scene's order launches so far (which area)
   int queue_mode;          // state machine: MT_TUNE_XCD_QUEUES (0: one order)
   float quad_share, quad_keep;                                         // state machine
+  float cell_share, cell_time;   // ... blocks with zero-component rays whose quarters are expected above cell_share x the cutting threshold go out as sixteen cells
+  int new_irr;                   // this frame has pixels whose primary rays have a zero direction component (ForecastArgs::new_irr)
   float pool_share, piece_time1, piece_time2, cell_factor, starter_share;  // hybrid
   unsigned max_starters;
   unsigned char *form_out;
@@ -100,8 +103,9 @@ __device__ __forceinline__ unsigned forecast_item(const RenderParams &P, const F
       const float c = (float)(word & 0x3fffffffu);
       return (unsigned)(lvl == 1u ? c / A.w1 : (lvl >= 2u ? c / A.w2 : c));
     }
-    const float c = (float)(word & 0x7fffffffu);
-    return (unsigned)((word >> 31) ? c / A.w1 : c);
+    // state machine: bit 31 = measured as quarters (their sum), bits 31 + 30 = as sixteen cells
+    const float c = (float)(word & ((word >> 31) ? 0x3fffffffu : 0x7fffffffu));
+    return (unsigned)((word >> 31) ? c / (((word >> 30) & 1u) ? A.w_cells : A.w1) : c);
   };
   auto cost_of = [&](unsigned word, unsigned idx) -> unsigned { return cost_from(word, form != nullptr ? (unsigned)form[idx] : 0u); };
   const int per_tile = P.blocks_x * P.blocks_y;
@@ -141,12 +145,12 @@ __device__ __forceinline__ unsigned forecast_item(const RenderParams &P, const F
     const unsigned w_old = forms ? P.item_whole[i] : 0u, qs_old = forms ? P.item_qsum[i] : 0u;
     const unsigned f_old = A.blend > 0.0f ? P.item_forecast[i] : 0u;
     unsigned f = cost_of(word, i);
-    if (forms && !(form != nullptr && form[i] >= 2)) {
+    if (forms && !(form != nullptr && form[i] >= 2) && (word >> 30) != 3u) {  // (a block measured in cells keeps the fixed factor)
       // A block near the cutting threshold: measured whole it costs c, in four pieces s, and s / w1 is only a guess
       // of c -- when the guess is below the threshold and c above it, the block changes its form every few frames
       // and every frame that renders it whole ends late.  Once both have been measured, THEIR ratio scales the one to
       // the other, and the forecast of the block no longer depends on the form it was rendered in.
-      const unsigned c = word & 0x7fffffffu;
+      const unsigned c = word & ((word >> 31) ? 0x3fffffffu : 0x7fffffffu);
       if (word >> 31) P.item_qsum[i] = c; else P.item_whole[i] = c;
       const unsigned w = (word >> 31) ? w_old : c, qs = (word >> 31) ? c : qs_old;
       if ((word >> 31) && w > 0u && qs > 0u) {
@@ -268,7 +272,7 @@ __device__ __forceinline__ unsigned forecast_item(const RenderParams &P, const F
 
 // What block i becomes in the coming launch: `n` units under sort key `key`, order_sub of unit q = sub0 + q (sub0 = -1:
 // the whole block), the word its cost starts from, and (hybrid) its form.  Packed into one word between the count and
-// the scatter kernel: key 0..10, n code 11..12 (1 / 4 / 16), sub0 code 13..15, cost word code 16..17, form 18..19, starter 20.
+// the scatter kernel: key 0..10, n code 11..12 (1 / 4 / 16), sub0 code 13..15, cost word code 16..18, form 19..20, starter 21.
 struct OrderUnit {
   unsigned key, n, cost_word;
   int sub0, form;
@@ -276,17 +280,17 @@ struct OrderUnit {
   __device__ __forceinline__ unsigned pack() const {
     const unsigned nc = n == 1u ? 0u : (n == 4u ? 1u : 2u);
     const unsigned sc = sub0 < 0 ? 0u : (sub0 == 0 ? 1u : (sub0 == 4 ? 2u : (sub0 == kHybridPoolSub ? 3u : 4u)));
-    const unsigned cc = cost_word == 0u ? 0u : (cost_word == 0x80000000u ? 1u : (cost_word == (1u << 30) ? 2u : 3u));
-    return key | (nc << 11) | (sc << 13) | (cc << 16) | ((unsigned)form << 18) | (starter ? 1u << 20 : 0u);
+    const unsigned cc = cost_word == 0u ? 0u : (cost_word == 0x80000000u ? 1u : (cost_word == (1u << 30) ? 2u : (cost_word == (2u << 30) ? 3u : 4u)));
+    return key | (nc << 11) | (sc << 13) | (cc << 16) | ((unsigned)form << 19) | (starter ? 1u << 21 : 0u);
   }
   __device__ __forceinline__ void unpack(unsigned w) {
     key = w & 0x7ffu;
-    const unsigned nc = (w >> 11) & 3u, sc = (w >> 13) & 7u, cc = (w >> 16) & 3u;
+    const unsigned nc = (w >> 11) & 3u, sc = (w >> 13) & 7u, cc = (w >> 16) & 7u;
     n = nc == 0u ? 1u : (nc == 1u ? 4u : 16u);
     sub0 = sc == 0u ? -1 : (sc == 1u ? 0 : (sc == 2u ? 4 : (sc == 3u ? kHybridPoolSub : kHybridPoolSub + 4)));
-    cost_word = cc == 0u ? 0u : (cc == 1u ? 0x80000000u : (cc == 2u ? (1u << 30) : (2u << 30)));
-    form = (int)((w >> 18) & 3u);
-    starter = ((w >> 20) & 1u) != 0u;
+    cost_word = cc == 0u ? 0u : (cc == 1u ? 0x80000000u : (cc == 2u ? (1u << 30) : (cc == 3u ? (2u << 30) : 0xc0000000u)));
+    form = (int)((w >> 19) & 3u);
+    starter = ((w >> 21) & 1u) != 0u;
   }
 };
 static_assert(kOrdKeysMax <= 2048, "an OrderUnit packs its key into 11 bits");
@@ -368,12 +372,26 @@ __global__ __launch_bounds__(kOrdThreads) void order_count_kernel(RenderParams P
       const unsigned f = P.item_forecast[i], c = f & 0x7fffffffu;
       const float quad_above = share * O.quad_share, quad_keep = quad_above * O.quad_keep;
       const bool quad = (float)c > ((f >> 31) ? quad_keep : quad_above) && c > 0u;
-      const unsigned unit = quad ? (unsigned)((float)c * kQuarterTime) : c;
+      // ... and as sixteen 2x2 cells when a QUARTER would still be among the launch's longest units AND the block holds
+      // rays with a zero direction component (a pixel column or row of a camera on an axis): their passes cost with the
+      // number of such rays in them (1.14 M cycles with one, 1.66 M with four), so smaller pieces shorten the chain --
+      // the loft's repeated frame was ONE such quarter's 16 passes, 13.1 ms, with every other wave done at 9.2.  (Any
+      // other block in cells is only more work: room panning 4.79 -> 6.9 ms with every long block cut so.)
+      bool cells = false;
+      if (quad && O.new_irr && (float)c * kQuarterTime > O.cell_share * quad_above) {
+        const int per_tile = P.blocks_x * P.blocks_y;
+        const int j = (int)(i / (unsigned)per_tile), b = (int)(i % (unsigned)per_tile);
+        const int tile = tile_of_slot(P, j);
+        const int x0 = P.region_x + (tile % P.tiles_x) * P.tile_w + (b % P.blocks_x) * 8;
+        const int y0 = P.region_y + (tile / P.tiles_x) * P.tile_h + (b / P.blocks_x) * 8;
+        cells = block_has_zero_component_ray(P.sensor, x0, y0);
+      }
+      const unsigned unit = cells ? (unsigned)((float)c * O.cell_time) : (quad ? (unsigned)((float)c * kQuarterTime) : c);
       const unsigned reg = queues ? (unsigned)s_reg.cellreg[P.item_cell[i]] : 0u;
       u.key = reg * 256u + (unsigned)cost_bucket(unit);
-      u.n = quad ? 4u : 1u;
-      u.sub0 = quad ? 0 : -1;
-      u.cost_word = quad ? 0x80000000u : 0u;
+      u.n = cells ? 16u : (quad ? 4u : 1u);
+      u.sub0 = cells ? 4 : (quad ? 0 : -1);
+      u.cost_word = cells ? 0xc0000000u : (quad ? 0x80000000u : 0u);
     } else if constexpr (KIND == 1) {
       // blocks whose forecast lies above pool_share of an even share go to the ray pool in pieces (4x4 quarters; 2x2
       // cells when a quarter would still be cell_factor times above that); the others to the state machine

@@ -59,7 +59,10 @@ struct FrameIO {
 // tile slot.  sub < 0: one lane per pixel, all 64 pixels.  sub = 0..3: the 4x4
 // quarter `sub` of the block with FOUR lanes per pixel (pixel = lane / 4,
 // role = lane % 4), used to run the shadow loops of up to four lights of a
-// pixel side by side.
+// pixel side by side.  sub = 4..19: one of the block's sixteen 2x2 cells, four lanes
+// per pixel likewise -- blocks whose QUARTERS would be the launch's longest units
+// (a pixel column of rays with a zero direction component: a pass costs with the
+// number of such rays in it).
 struct ItemGeom {
   int px, py;        // image coordinates of this lane's pixel
   bool inside;       // lane has a pixel
@@ -75,20 +78,26 @@ __device__ __forceinline__ ItemGeom item_geometry(const RenderParams &P, unsigne
   const int cw = min(P.tile_w, P.region_x + P.region_w - tx0);  // edge clipping as
   const int ch = min(P.tile_h, P.region_y + P.region_h - ty0);  // main_net_master.cc:205-206
   int ox, oy;
+  bool lane_used = true;
   if (sub < 0) {
     ox = lane & 7;
     oy = lane >> 3;
-  } else {
+  } else if (sub < 4) {
     const int q = lane >> 2;
     ox = (sub & 1) * 4 + (q & 3);
     oy = (sub >> 1) * 4 + (q >> 2);
+  } else {  // a 2x2 cell (sub = 4 + cell), four lanes per pixel: lanes 0..15
+    const int c = sub - 4, q = (lane >> 2) & 3;
+    ox = (c & 3) * 2 + (q & 1);
+    oy = (c >> 2) * 2 + (q >> 1);
+    lane_used = lane < 16;
   }
   const int lx = (b % P.blocks_x) * 8 + ox;
   const int ly = (b / P.blocks_x) * 8 + oy;
   ItemGeom g;
   g.px = tx0 + lx;
   g.py = ty0 + ly;
-  g.inside = (lx < cw) && (ly < ch);
+  g.inside = lane_used && (lx < cw) && (ly < ch);
   g.px_index = (size_t)j * (size_t)P.tile_w * (size_t)P.tile_h + (size_t)ly * (size_t)cw + (size_t)lx;
   return g;
 }
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256, MT_WAVES_PER_SIMD) void primary_kernel(DevScen
 // map (see RenderParams::cost_map): block (bx, by) of the IMAGE -> map[by * map_w + bx]; blocks of tiles that are not
 // this launch's keep what the map holds (the caller zeroes it).  engine = the engine that measured the costs (how
 // to read the words: forecast_kernel), wq1 / wq2 = the work factors of its pieces.
-__global__ void export_costs_kernel(RenderParams P, int engine, float wq1, float wq2, const unsigned char *form,
+__global__ void export_costs_kernel(RenderParams P, int engine, float wq1, float wq2, float w_cells, const unsigned char *form,
                                     unsigned *map, int map_w, int map_h) {
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= P.n_items) return;
@@ -248,8 +257,9 @@ __global__ void export_costs_kernel(RenderParams P, int engine, float wq1, float
     c = (float)(word & 0x3fffffffu);
     c = lvl == 1u ? c / wq1 : (lvl >= 2u ? c / wq2 : c);
   } else {
-    c = (float)(word & 0x7fffffffu);
-    if (word >> 31) c /= 1.7f;
+    // (state machine: bit 31 = measured as quarters, bits 31 + 30 = as cells)
+    c = (float)(word & ((word >> 31) ? 0x3fffffffu : 0x7fffffffu));
+    if (word >> 31) c /= ((word >> 30) & 1u) ? w_cells : 1.7f;
   }
   const int per_tile = P.blocks_x * P.blocks_y;
   const int j = (int)(i / (unsigned)per_tile), b = (int)(i % (unsigned)per_tile);

@@ -222,6 +222,38 @@ def test_work_order_on_any_number_of_workgroups(groups, scenes, engine):
         abi.scene_destroy(h)
 
 
+def test_state_machine_cells_for_blocks_with_zero_component_rays(scenes):
+    """A camera on an axis has a pixel column whose primary rays have a zero direction component (exact, lane-serial
+    descent: a pass costs with the number of such rays in it).  The state machine hands such blocks out as sixteen 2x2
+    cells, four lanes per pixel, when even their quarters would be the launch's longest units (MT_TUNE_SM_CELL_SHARE;
+    mt_order.h).  Forced here for every block of the column (and, with a tiny cutting share, quarters for nearly every
+    other block): same pixels, debug-free counters and ray counts as the unordered first launch and as the golden."""
+    abi = M.hip_abi()
+    m = M.MythTracer(scenes["room"])
+    h = abi.scene_create(m.flatten())
+    try:
+        abi.set_engine(h, 1)
+        abi.set_lights(h, scenegen.ROOM_LIGHTS)
+        g = load("room_240x135")
+        W, H = 240, 135   # (odd height, even width: the column x = 120 holds the zero-component rays)
+        sens = binding.sensor(scenegen.ROOM_CAMERA, W, H)
+        first = abi.render_chunk(h, sens, W, H)
+        assert_rgb_close(first["rgb"], g["rgb"], "first launch")
+        for share, quad in ((1e-6, 0.05), (1e-6, 0.95), (0.8, 0.95)):
+            abi.set_tuning(h, "SM_CELL_SHARE", share)
+            abi.set_tuning(h, "QUAD_SHARE", quad)
+            for launch in range(4):  # (the first one after set_tuning has no cost history)
+                r = abi.render_chunk(h, sens, W, H)
+                assert np.array_equal(r["rgb"], first["rgb"]), (share, quad, launch)
+                assert {k: r["stats"][k] for k in ALL_KEYS if k not in PRUNED} == {k: first["stats"][k] for k in ALL_KEYS if k not in PRUNED}, (share, quad, launch)
+            # a ragged chunk through the column: cells at the clipped edge
+            part = abi.render_chunk(h, sens, W, H, chunk=(101, 3, 37, 129))
+            part = abi.render_chunk(h, sens, W, H, chunk=(101, 3, 37, 129))
+            assert np.array_equal(part["rgb"], first["rgb"][3:132, 101:138]), (share, quad)
+    finally:
+        abi.scene_destroy(h)
+
+
 def test_bad_chunks_are_rejected(scenes):
     m = M.MythTracer(scenes["cornell"])
     for chunk in [(-1, 0, 4, 4), (0, 0, 0, 4), (60, 60, 8, 8), (0, 0, 65, 1)]:
@@ -1471,7 +1503,7 @@ def test_cost_balanced_tile_ownership(scenes, engine):
             abi.render_tile_list_device(hs[0], sens, W, H, T, T, vp(lists[0]), total + 1, 0, 5, vp(slots))
         # the tuning knobs refuse values the kernels would divide by or overflow on (mt_scene_set_tuning)
         for knob, bad in (("QUAD_SHARE", 0.0), ("HYBRID_WORK1", 0.0), ("POOL_PIECE_WORK1", -1.0), ("POOL_SCRATCH_MB", float("inf")),
-                          ("BLEND", 1.5), ("HYBRID_POOL_SHARE", float("nan")), ("ORDER_GROUPS", 0.0), ("ORDER_GROUPS", 257.0),
+                          ("BLEND", 1.5), ("HYBRID_POOL_SHARE", float("nan")), ("ORDER_GROUPS", 0.0), ("ORDER_GROUPS", 257.0), ("SM_CELL_SHARE", 0.0), ("SM_CELL_WORK", -1.0),
                           ("XCD_QUEUES", 3.0)):
             with pytest.raises(RuntimeError):
                 abi.set_tuning(hs[0], knob, bad)
