@@ -684,7 +684,10 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
         oa.quad_share = quad_share;
         oa.quad_keep = quad_keep;
         oa.cell_share = (float)tv[MT_TUNE_SM_CELL_SHARE];
-        oa.new_irr = new_irr;
+        // (cells only on MEASURED costs: a re-projected forecast of such a block is a guess -- thirty times a mean block --
+        // that cannot tell the loft's column, 1.4 frames long as quarters, from the room's, 0.87: room panning +0.5 % with
+        // the guess trusted, loft -2 %)
+        oa.new_irr = reproject ? 0 : new_irr;
         oa.cell_time = (float)tv[MT_TUNE_SM_CELL_TIME];
         oa.queue_mode = (int)tv[MT_TUNE_XCD_QUEUES];
         hipLaunchKernelGGL(order_forecast_kernel<0>, dim3(ord_groups), dim3(kOrdThreads), 0, stream, P, fa, oa);
