@@ -2,7 +2,7 @@
 duration, and its start stamp and wave.)  Prints the launch's makespan in s_memtime ticks, the units that end last, the
 waves' idle time at the end, and how much of the launch had fewer than all waves busy.
 
-  WHAT=1080p|rank  RANK=5 WORLD=8  ENGINE=3  YAW=0  python scripts/unit_timeline.py"""
+  WHAT=1080p|rank  RANK=5 WORLD=8  ENGINE=3  YAW=0  COLD=  python scripts/unit_timeline.py"""
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,7 +25,7 @@ if what == "1080p":
     sens = binding.sensor(cam1080, W, H)
     buf = torch.zeros((H, W, 3), dtype=torch.uint8, device="cuda")
     n_items = (W // 8) * (H // 8)
-    for i in range(10):
+    for i in range(1 if os.environ.get("COLD") else 10):  # (COLD=1: the first frame of a geometry -- probe_kernel's guess, ray pool)
         abi.render_chunk_device(h, sens, W, H, (0, 0, W, H), 5, ctypes.c_void_p(buf.data_ptr()))
 else:
     W, H, T = 3840, 2160, int(os.environ.get("TILE", "64"))
