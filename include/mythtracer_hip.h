@@ -345,7 +345,7 @@ enum {
   MT_TUNE_QUAD_SHARE, MT_TUNE_QUAD_SHARE_MOVING, MT_TUNE_QUAD_KEEP,
   MT_TUNE_QUAD_WORK, MT_TUNE_QUAD_WORK_MOVING,
   MT_TUNE_POOL_SCRATCH_MB,    /* scratch budget of the ray pool (4096) */
-  MT_TUNE_HYBRID_POOL_SHARE,  /* engine 3: blocks above this share of an even split go to the ray pool in pieces (1.0) */
+  MT_TUNE_HYBRID_POOL_SHARE,  /* engine 3: blocks above this share of an even split go to the ray pool in pieces (1.3) */
   MT_TUNE_HYBRID_QUAD_SHARE,  /* ... above this one to the state machine as quarters, four lanes per pixel (1.0 = none) */
   MT_TUNE_HYBRID_WORK1, MT_TUNE_HYBRID_WORK2, /* pool quarters / cells: summed cost over the whole block's (1.3, 3.3) */
   MT_TUNE_FORECAST_STEP,      /* pixels between the positions a re-projected forecast takes its maximum over (8) */
@@ -365,6 +365,8 @@ enum {
   MT_TUNE_SM_CELL_SHARE,      /* state machine: a block goes out as sixteen 2x2 cells (four lanes per pixel) when a QUARTER
                                  of it is expected above this multiple of the quarters' cutting threshold */
   MT_TUNE_SM_CELL_TIME, MT_TUNE_SM_CELL_WORK, /* a cell's expected time / the cells' summed cost, over the block as one unit */
+  MT_TUNE_HYBRID_CELL_FACTOR, /* engine 3: the pool's pieces of a block are 2x2 cells when a quarter is expected above this
+                                 multiple of the pool's threshold (0.85; the ray pool by itself: MT_TUNE_POOL_CELL_FACTOR) */
   MT_TUNE_COUNT
 };
 int mt_scene_set_tuning(mt_scene *scene, int knob, double value);

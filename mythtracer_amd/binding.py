@@ -34,7 +34,7 @@ TUNE = {name: i for i, name in enumerate([
     "POOL_CELL_FACTOR", "QUAD_SHARE", "QUAD_SHARE_MOVING", "QUAD_KEEP", "QUAD_WORK", "QUAD_WORK_MOVING",
     "POOL_SCRATCH_MB", "HYBRID_POOL_SHARE", "HYBRID_QUAD_SHARE", "HYBRID_WORK1", "HYBRID_WORK2", "FORECAST_STEP",
     "HYBRID_STARTER_SHARE", "DEEP_LAYOUT", "MULTI_FORCE_PEER_COPY", "MULTI_BALANCE", "XCD_QUEUES",
-    "ORDER_GROUPS", "SM_CELL_SHARE", "SM_CELL_TIME", "SM_CELL_WORK"])}
+    "ORDER_GROUPS", "SM_CELL_SHARE", "SM_CELL_TIME", "SM_CELL_WORK", "HYBRID_CELL_FACTOR"])}
 
 STAT_NAMES = ["rays_primary", "rays_secondary", "rays_shadow", "box_tests",
               "node_visits", "tri_tests", "mt_tests", "shaded_hits"]

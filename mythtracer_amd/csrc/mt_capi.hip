@@ -77,7 +77,8 @@ struct Tuning {
     // the state machine as quarters with four lanes per pixel (swept on one rank's share of the 4K frame at N = 8,
     // scripts/hybrid_sweep.py: 0.8 / 0.9 / 1.0 / 1.15 / 1.3 -> slowest rank 3.90 / 3.65 / 3.65 / 3.72 / 3.92 ms; with the
     // quarters' threshold below the pool's the state machine's 1.7x work per quartered block comes back: +0.3 ms)
-    v[MT_TUNE_HYBRID_POOL_SHARE] = 1.0;
+    v[MT_TUNE_HYBRID_POOL_SHARE] = 1.3;   // (swept with HYBRID_CELL_FACTOR at N = 8, panning: (1.0, 1.0) 3.03 ms, (1.3, 0.85) 2.88: fewer blocks through the pool as quarters, the cells' threshold where it was)
+    v[MT_TUNE_HYBRID_CELL_FACTOR] = 0.85;
     v[MT_TUNE_HYBRID_QUAD_SHARE] = 1.0;
     v[MT_TUNE_FORECAST_STEP] = 8.0;       // pixels between the old-image positions a re-projected forecast takes its maximum over
     v[MT_TUNE_HYBRID_WORK1] = 1.3; v[MT_TUNE_HYBRID_WORK2] = 2.6;  // pool quarters / cells: summed cost over the state machine's whole-block cost
@@ -673,7 +674,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
         oa.pool_share = k * (float)tv[MT_TUNE_HYBRID_POOL_SHARE];
         oa.piece_time1 = (float)tv[MT_TUNE_POOL_PIECE_TIME1];
         oa.piece_time2 = (float)tv[MT_TUNE_POOL_PIECE_TIME2];
-        oa.cell_factor = (float)tv[MT_TUNE_POOL_CELL_FACTOR];
+        oa.cell_factor = (float)tv[MT_TUNE_HYBRID_CELL_FACTOR];
         oa.form_out = s->d_item_form;
         oa.starter_share = (float)tv[MT_TUNE_HYBRID_STARTER_SHARE];
         oa.max_starters = (unsigned)std::min(s->grid_blocks, (int)(0.25 * s->grid_blocks * s->waves_per_block));
@@ -1394,7 +1395,7 @@ int mt_scene_set_tuning(mt_scene *s, int knob, double value) {
     case MT_TUNE_POOL_PIECE_TIME1: case MT_TUNE_POOL_PIECE_TIME2: case MT_TUNE_POOL_PIECE_WORK1: case MT_TUNE_POOL_PIECE_WORK2:
     case MT_TUNE_POOL_CELL_FACTOR: case MT_TUNE_QUAD_SHARE: case MT_TUNE_QUAD_SHARE_MOVING: case MT_TUNE_QUAD_KEEP:
     case MT_TUNE_QUAD_WORK: case MT_TUNE_QUAD_WORK_MOVING: case MT_TUNE_HYBRID_POOL_SHARE: case MT_TUNE_HYBRID_QUAD_SHARE:
-    case MT_TUNE_SM_CELL_SHARE: case MT_TUNE_SM_CELL_TIME: case MT_TUNE_SM_CELL_WORK:
+    case MT_TUNE_SM_CELL_SHARE: case MT_TUNE_SM_CELL_TIME: case MT_TUNE_SM_CELL_WORK: case MT_TUNE_HYBRID_CELL_FACTOR:
     case MT_TUNE_HYBRID_WORK1: case MT_TUNE_HYBRID_WORK2: case MT_TUNE_FORECAST_STEP: case MT_TUNE_HYBRID_STARTER_SHARE:
       if (!(value >= 1e-6 && value <= 1e6)) return fail(MT_ERR_ARG, "tuning knob %d must lie in [1e-6, 1e6]", knob);
       break;

@@ -43,7 +43,7 @@ def full4k():
     return float((a + b)[-4:].mean())
 if mode == "cells":
     for cf in (3.0, 1.5, 1.0, 0.6, 0.35):
-        abi.set_tuning(h, "POOL_CELL_FACTOR", cf)
+        abi.set_tuning(h, "HYBRID_CELL_FACTOR", cf)
         for pt2 in (0.12, 0.2):
             abi.set_tuning(h, "POOL_PIECE_TIME2", pt2)
             for ps in (0.9, 1.0):
