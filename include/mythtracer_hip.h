@@ -360,8 +360,8 @@ enum {
                                  orders, one per XCD, each over a stripe of the picture with an eighth of the forecast cost
                                  (an XCD's L2 then holds its stripe's part of the tree; an XCD that runs dry takes units
                                  from the fullest other queue); 2 = a 4 x 2 grid of regions instead of stripes */
-  MT_TUNE_ORDER_GROUPS,       /* workgroups of the kernel that makes a launch's work order (forecast per block, units
-                                 longest first): 64; 1 .. 256, at most one per CU */
+  MT_TUNE_ORDER_GROUPS,       /* workgroups of the three kernels that make a launch's work order (forecast per block,
+                                 counting sort, units longest first): 64; 1 .. 256 */
   MT_TUNE_SM_CELL_SHARE,      /* state machine: a block goes out as sixteen 2x2 cells (four lanes per pixel) when a QUARTER
                                  of it is expected above this multiple of the quarters' cutting threshold */
   MT_TUNE_SM_CELL_TIME, MT_TUNE_SM_CELL_WORK, /* a cell's expected time / the cells' summed cost, over the block as one unit */

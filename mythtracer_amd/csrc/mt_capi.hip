@@ -109,7 +109,7 @@ struct mt_scene {
   unsigned int *d_work = nullptr;
   unsigned int *d_queues = nullptr;  // kQueueWords: the per-XCD work orders' counters and bounds (RenderParams::queues)
   unsigned int *d_order_ctl = nullptr;  // kOrdWords: the order kernels' sums, histograms, grids (zero at creation, never reset by the host)
-  unsigned int *d_order_woff = nullptr; // [kOrdGroupsMax][kOrdKeysMax]
+  unsigned int *d_order_whist = nullptr; // [kOrdGroupsMax][kOrdKeysMax]
   unsigned int *d_item_unit = nullptr;
   size_t item_unit_bytes = 0;
   unsigned order_epoch = 0;             // order_kernel launches of this scene so far
@@ -537,7 +537,7 @@ int launch_render(mt_scene *s, const mt_sensor *sensor, int image_w, int image_h
   // (launches with a work order: order_kernel zeroes the counters on its way)
   if (!history && !pool_engine) HIP_TRY(hipMemsetAsync(s->d_work, 0, 16 * sizeof(unsigned), stream));
   P.order_ctl = s->d_order_ctl;
-  P.order_whist = s->d_order_woff;
+  P.order_whist = s->d_order_whist;
   P.item_unit = s->d_item_unit;
   // one work order per XCD: state-machine launches with a cost history only (the other engines keep the one order)
   // (measured and left out: first frames through the ray pool -- room 8.4 -> 8.9 ms, loft 19.7 -> 20.9: the probe's guess
@@ -1281,8 +1281,8 @@ static int scene_create_impl(mt_scene *s, const mt_scene_desc *d) {
   HIP_TRY(hipMalloc((void **)&s->d_order_ctl, kOrdWords * sizeof(unsigned)));
   s->allocs.push_back(s->d_order_ctl);
   HIP_TRY(hipMemset(s->d_order_ctl, 0, kOrdWords * sizeof(unsigned)));
-  HIP_TRY(hipMalloc((void **)&s->d_order_woff, (size_t)kOrdGroupsMax * kOrdKeysMax * sizeof(unsigned)));
-  s->allocs.push_back(s->d_order_woff);
+  HIP_TRY(hipMalloc((void **)&s->d_order_whist, (size_t)kOrdGroupsMax * kOrdKeysMax * sizeof(unsigned)));
+  s->allocs.push_back(s->d_order_whist);
   HIP_TRY(hipEventCreate(&s->ev0));
   HIP_TRY(hipEventCreate(&s->ev1));
   if ((rc = mt_scene_set_lights(s, nullptr, 0)) != MT_OK) return rc;

@@ -24,7 +24,7 @@
 
 namespace mt {
 
-constexpr int kOrdGroups = 64;       // workgroups of the order kernel (MT_TUNE_ORDER_GROUPS; all resident: one per CU at most)
+constexpr int kOrdGroups = 64;       // workgroups of each of the three kernels (MT_TUNE_ORDER_GROUPS; swept 16 .. 256: 64)
 constexpr int kOrdGroupsMax = 256;
 constexpr int kOrdThreads = 1024;
 constexpr int kOrdKeysMax = kQueues * 256;
